@@ -1,0 +1,195 @@
+"""Oracle: the whole TreeLearn forward on CPU, driven by a reference-layout state dict.
+
+Restates (functionally, no nn.Module) reference
+  tree_learn/model/tree_learn.py:83-103   forward_backbone / forward_head
+  tree_learn/model/blocks.py:8-18         MLP
+  tree_learn/model/blocks.py:29-39        Custom1x1Subm3d
+  tree_learn/model/blocks.py:42-79        ResidualBlock
+  tree_learn/model/blocks.py:81-149       UBlock
+  tree_learn/util/train.py:145-166, tree_learn.py:106-126   loss
+State-dict key names are the reference's, so any checkpoint the
+reference can load drives this oracle unchanged.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import voxel, sparse_ops
+
+BN_EPS = 1e-4           # tree_learn.py:34
+LOSS_MULTIPLIER_SEMANTIC = 50   # tree_learn.py:9
+
+
+def bn_relu(x, sd, prefix, training=False, relu=True):
+    """BatchNorm1d(eps=1e-4) [+ ReLU] on features (spconv SparseSequential applies plain
+    modules to .features -> normalises over all active voxels)."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    if training:
+        mean = x.mean(0); var = x.var(0, unbiased=False)
+    else:
+        mean, var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    y = (x - mean) / torch.sqrt(var + BN_EPS) * w + b
+    return torch.relu(y) if relu else y
+
+
+class Level:
+    """Per-level geometry: coords + subm table (+ down tables to the next level)."""
+    def __init__(self, coords, shape):
+        self.coords = coords
+        self.shape = np.asarray(shape, np.int64)
+        self.nbr = voxel.rulebook_subm(coords, 3)
+        self.parent = self.child = None
+
+
+def build_levels(vcoords, spatial_shape, num_blocks):
+    levels = [Level(vcoords, spatial_shape)]
+    for _ in range(num_blocks - 1):
+        cur = levels[-1]
+        cc, parent, child, oshape = voxel.rulebook_down(cur.coords, cur.shape)
+        cur.parent, cur.child = parent, child
+        levels.append(Level(cc, oshape))
+    return levels
+
+
+def residual_block(x, sd, p, nbr, training):
+    """blocks.py:72-79: out = conv_branch(x) + i_branch(x)."""
+    key1x1 = p + ".i_branch.0.weight"
+    if key1x1 in sd:                                              # Custom1x1Subm3d, blocks.py:29-39
+        W = sd[key1x1]
+        idt = x @ W.view(W.shape[0], W.shape[-1]).T
+    else:
+        idt = x
+    y = bn_relu(x, sd, p + ".conv_branch.0", training)
+    y = sparse_ops.conv_table(y, sd[p + ".conv_branch.2.weight"], nbr)
+    y = bn_relu(y, sd, p + ".conv_branch.3", training)
+    y = sparse_ops.conv_table(y, sd[p + ".conv_branch.5.weight"], nbr)
+    return y + idt
+
+
+def ublock(x, sd, p, levels, li, training, block_reps=2):
+    """blocks.py:137-149."""
+    L = levels[li]
+    for i in range(block_reps):
+        x = residual_block(x, sd, f"{p}.blocks.block{i}", L.nbr, training)
+    if li + 1 < len(levels):
+        identity = x
+        d = bn_relu(x, sd, p + ".conv.0", training)
+        d = sparse_ops.conv_table(d, sd[p + ".conv.2.weight"], L.child)
+        d = ublock(d, sd, p + ".u", levels, li + 1, training, block_reps)
+        d = bn_relu(d, sd, p + ".deconv.0", training)
+        d = sparse_ops.inverse_conv(d, sd[p + ".deconv.2.weight"], L.parent, L.coords)
+        x = torch.cat((identity, d), dim=1)
+        for i in range(block_reps):
+            x = residual_block(x, sd, f"{p}.blocks_tail.block{i}", L.nbr, training)
+    return x
+
+
+def mlp(x, sd, p, training):
+    """blocks.py:8-18 with num_layers=2: Linear, BN, ReLU, Linear."""
+    y = x @ sd[p + ".0.weight"].T + sd[p + ".0.bias"]
+    y = bn_relu(y, sd, p + ".1", training)
+    return y @ sd[p + ".3.weight"].T + sd[p + ".3.bias"]
+
+
+def forward(sd, coords, input_feats, batch_ids, batch_size, voxel_size=0.1, num_blocks=7,
+            use_coords=False, use_feats=False, spatial_shape=None, max_num_points_per_voxel=3,
+            training=False, return_intermediates=False):
+    """tree_learn.py:75-103.  `sd`: reference-layout state dict of CPU fp32 tensors."""
+    vfeats, vcoords, v2p, sshape = voxel.voxelize(
+        coords, input_feats, batch_ids, batch_size, voxel_size, use_coords, use_feats, max_num_points_per_voxel)
+    if spatial_shape is not None:
+        sshape = np.asarray(spatial_shape, np.int64)                  # tree_learn.py:86-87
+    levels = build_levels(vcoords, sshape, num_blocks)
+    x = torch.from_numpy(vfeats)
+    x = sparse_ops.conv_table(x, sd["input_conv.0.weight"], levels[0].nbr)       # tree_learn.py:90
+    x = ublock(x, sd, "unet", levels, 0, training)                               # :92
+    x = bn_relu(x, sd, "output_layer.0", training)                               # :93
+    bf = x[torch.from_numpy(v2p)]                                                # :99
+    out = dict(backbone_feats=bf,
+               semantic_prediction_logits=mlp(bf, sd, "semantic_linear", training),
+               offset_predictions=mlp(bf, sd, "offset_linear", training))
+    if return_intermediates:
+        out["_levels"] = levels; out["_v2p"] = v2p; out["_voxel_feats"] = x
+    return out
+
+
+def point_wise_loss(logits, offsets, masks_sem, masks_off, semantic_labels, offset_labels):
+    """tree_learn/util/train.py:145-166."""
+    if masks_sem.sum() == 0:
+        sem = 0 * logits.sum()
+    else:
+        sem = F.cross_entropy(logits[masks_sem], semantic_labels[masks_sem], reduction="sum") / int(masks_sem.sum())
+    if masks_off.sum() == 0:
+        off = 0 * offsets.sum()
+    else:
+        off = (offsets[masks_off] - offset_labels[masks_off]).pow(2).sum(1).sqrt().mean()
+    return sem, off
+
+
+def get_loss(model_output, semantic_labels, offset_labels, masks_off, masks_sem):
+    """tree_learn.py:106-126."""
+    sem, off = point_wise_loss(model_output["semantic_prediction_logits"].float(),
+                               model_output["offset_predictions"].float(),
+                               masks_sem, masks_off, semantic_labels, offset_labels)
+    d = dict(semantic_loss=sem * LOSS_MULTIPLIER_SEMANTIC, offset_loss=off)
+    return sum(d.values()), d
+
+
+# ---------------------------------------------------------------- state-dict helpers (test side)
+def state_dict_manifest(channels=32, num_blocks=7, dim_coord=3, dim_feat=1, kernel_size=3):
+    """(key, shape) list in the reference's registration order."""
+    m = []
+    def bn(p, c):
+        m.extend([(p + ".weight", (c,)), (p + ".bias", (c,)), (p + ".running_mean", (c,)),
+                  (p + ".running_var", (c,)), (p + ".num_batches_tracked", ())])
+    k = kernel_size
+    m.append(("input_conv.0.weight", (channels, k, k, k, dim_coord + dim_feat)))
+    planes = [channels * (i + 1) for i in range(num_blocks)]
+    def resblock(p, cin, cout):
+        if cin != cout:
+            m.append((p + ".i_branch.0.weight", (cout, 1, 1, 1, cin)))
+        bn(p + ".conv_branch.0", cin)
+        m.append((p + ".conv_branch.2.weight", (cout, k, k, k, cin)))
+        bn(p + ".conv_branch.3", cout)
+        m.append((p + ".conv_branch.5.weight", (cout, k, k, k, cout)))
+    def ub(p, pl):
+        for i in range(2):
+            resblock(f"{p}.blocks.block{i}", pl[0], pl[0])
+        if len(pl) > 1:
+            bn(p + ".conv.0", pl[0]); m.append((p + ".conv.2.weight", (pl[1], 2, 2, 2, pl[0])))
+            ub(p + ".u", pl[1:])
+            bn(p + ".deconv.0", pl[1]); m.append((p + ".deconv.2.weight", (pl[0], 2, 2, 2, pl[1])))
+            for i in range(2):
+                resblock(f"{p}.blocks_tail.block{i}", pl[0] * (2 - i), pl[0])
+    ub("unet", planes)
+    bn("output_layer.0", channels)
+    for name, co in (("semantic_linear", 2), ("offset_linear", 3)):
+        m.append((name + ".0.weight", (channels, channels))); m.append((name + ".0.bias", (channels,)))
+        bn(name + ".1", channels)
+        m.append((name + ".3.weight", (co, channels))); m.append((name + ".3.bias", (co,)))
+    return m
+
+
+def random_state_dict(seed, **cfg):
+    """Deterministic non-trivial weights/BN statistics, generated key by key from a numpy
+    Generator so tests and the golden script agree without storing 30 M parameters."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for key, shape in state_dict_manifest(**cfg):
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.tensor(7, dtype=torch.long); continue
+        if key.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif key.endswith("running_mean"):
+            v = rng.normal(0, 0.2, shape)
+        elif key.endswith(".bias"):
+            v = rng.normal(0, 0.1, shape)
+        elif len(shape) == 1:                               # BN weight
+            v = rng.uniform(0.7, 1.3, shape)
+        elif len(shape) == 5:                               # conv: keep activations O(1)
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            v = rng.normal(0, (2.0 / fan_in) ** 0.5 * 1.5, shape)
+        else:                                               # linear
+            v = rng.normal(0, (1.0 / shape[1]) ** 0.5, shape)
+        sd[key] = torch.from_numpy(np.asarray(v, np.float32))
+    return sd

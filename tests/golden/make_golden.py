@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (needs /root/reference; nothing here travels to the
+GPU box except the .npz/.json outputs):
+
+    python tests/golden/make_golden.py
+
+What is real reference code and what is a stand-in
+--------------------------------------------------
+* Real (imported from /root/reference): TreeLearn / UBlock / ResidualBlock / MLP /
+  Custom1x1Subm3d module wiring and state-dict layout, `voxelize` post-processing,
+  `get_loss`, `point_wise_loss`, `get_pointwise_preds`, `get_instances`, `group_dbscan`,
+  `group_hdbscan`, `make_labels_consecutive`, `ensemble`,
+  `assign_remaining_points_nearest_neighbor`, `TreeDataset.collate_fn`.
+* Stand-in (defined in THIS file, because the third-party `spconv` wheel is neither in
+  /root/reference nor installable here): `spconv.pytorch` = a *dense* implementation
+  -- every sparse conv is torch.nn.functional.conv3d / conv_transpose3d on a dense grid,
+  sampled at the active sites (SURVEY.md Appendix B identities) -- and `PointToVoxel`
+  = a dict-based voxelizer.  They share no code with oracle/ (which uses rulebooks).
+* Other missing third-party imports (open3d, laspy, geopandas, ...) are inert mocks;
+  none of them is touched by the functions exercised here.
+* `Tensor.cuda()` is patched to the identity so `cuda_cast`-wrapped methods run on CPU.
+
+Weights come from oracle.model.random_state_dict(seed) -- a pure function of the seed --
+so the fixtures hold inputs/outputs only.
+"""
+import json
+import os
+import sys
+import types
+from collections import OrderedDict
+from unittest import mock
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+# --------------------------------------------------------------------------- inert mocks
+for name in ["open3d", "jakteristics", "laspy", "munch", "timm", "timm.scheduler", "tensorboardX",
+             "geopandas", "alphashape", "shapely", "shapely.geometry", "plotly", "plotly.express",
+             "torchvision", "torchvision.datasets", "torchvision.datasets.utils"]:
+    sys.modules.setdefault(name, mock.MagicMock())
+sys.modules["munch"].Munch = dict
+
+
+# --------------------------------------------------------------------------- dense spconv stand-in
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in (spatial_shape.tolist() if torch.is_tensor(spatial_shape) else spatial_shape)]
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self.grid = None
+
+    def replace_feature(self, f):
+        t = SparseConvTensor(f, self.indices, self.spatial_shape, self.batch_size)
+        t.indice_dict = self.indice_dict
+        t.grid = self.grid
+        return t
+
+    def dense(self):
+        c = self.indices.long()
+        d = torch.zeros(self.batch_size, self.features.shape[1], *self.spatial_shape, dtype=self.features.dtype)
+        d[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]] = self.features
+        return d
+
+
+class SparseModule(nn.Module):
+    pass
+
+
+class SparseSequential(SparseModule):
+    def __init__(self, *args):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            if isinstance(m, SparseModule):
+                x = m(x)
+            else:
+                x = x.replace_feature(m(x.features))
+        return x
+
+
+class _Conv(SparseModule):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.indice_key = kernel_size, stride, padding, indice_key
+        k = kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels).uniform_(-0.05, 0.05))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+
+def _sample(d, c):
+    c = c.long()
+    return d[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]]
+
+
+class SubMConv3d(_Conv):
+    def forward(self, x):
+        y = F.conv3d(x.dense(), self.weight.permute(0, 4, 1, 2, 3), padding=self.padding)
+        return x.replace_feature(_sample(y, x.indices))
+
+
+class SparseConv3d(_Conv):
+    def forward(self, x):
+        assert self.kernel_size == 2 and self.stride == 2
+        out_shape = [s // 2 for s in x.spatial_shape]
+        if min(out_shape) <= 0:
+            raise ValueError("your out spatial shape reach zero!!!")
+        y = F.conv3d(x.dense(), self.weight.permute(0, 4, 1, 2, 3), stride=2)
+        c = x.indices.clone().long()
+        c[:, 1:] //= 2
+        ok = (c[:, 1:] < torch.tensor(out_shape)[None]).all(1)
+        lin = ((c[:, 0] * 70000 + c[:, 1]) * 70000 + c[:, 2]) * 70000 + c[:, 3]
+        _, first = np.unique(lin[ok].numpy(), return_index=True)
+        oc = c[ok][torch.from_numpy(first)].int()
+        out = SparseConvTensor(_sample(y, oc), oc, out_shape, x.batch_size)
+        out.indice_dict = dict(x.indice_dict)
+        out.indice_dict[self.indice_key] = (x.indices, x.spatial_shape)
+        return out
+
+
+class SparseInverseConv3d(_Conv):
+    def forward(self, x):
+        fine_idx, fine_shape = x.indice_dict[self.indice_key]
+        y = F.conv_transpose3d(x.dense(), self.weight.permute(4, 0, 1, 2, 3), stride=2)
+        full = torch.zeros(y.shape[0], y.shape[1], *fine_shape, dtype=y.dtype)
+        sx, sy, sz = [min(a, b) for a, b in zip(y.shape[2:], fine_shape)]
+        full[:, :, :sx, :sy, :sz] = y[:, :, :sx, :sy, :sz]
+        out = SparseConvTensor(_sample(full, fine_idx), fine_idx, fine_shape, x.batch_size)
+        out.indice_dict = x.indice_dict
+        return out
+
+
+class PointToVoxel:
+    """dict-based voxelizer: c = floor((p - lo) / vsize) in fp32, voxels in ascending (x,y,z),
+    first <= P points in input order kept; returns spconv's (voxels, zyx indices, num, ids)."""
+    def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels,
+                 max_num_points_per_voxel, device=None):
+        self.vs = np.asarray(vsize_xyz, np.float32)
+        self.lo = np.asarray(coors_range_xyz[:3], np.float32)
+        self.hi = np.asarray(coors_range_xyz[3:], np.float32)
+        self.P, self.C = max_num_points_per_voxel, num_point_features
+
+    def generate_voxel_with_id(self, pc):
+        p = pc.numpy().astype(np.float32)
+        grid = np.round((self.hi.astype(np.float64) - self.lo) / self.vs).astype(np.int64)
+        table = {}
+        for i in range(len(p)):
+            c = np.floor((p[i, :3] - self.lo) / self.vs).astype(np.int64)
+            if (c < 0).any() or (c >= grid).any():
+                continue
+            table.setdefault(tuple(c.tolist()), []).append(i)
+        cells = sorted(table)
+        M = len(cells)
+        voxels = np.zeros((M, self.P, self.C), np.float32)
+        idx = np.zeros((M, 3), np.int32); num = np.zeros(M, np.int32)
+        ids = np.full(len(p), -1, np.int64)
+        for m, cell in enumerate(cells):
+            members = table[cell]
+            ids[members] = m
+            take = members[: self.P]
+            voxels[m, : len(take)] = p[take]
+            num[m] = len(take)
+            idx[m] = cell[::-1]                                   # spconv returns zyx
+        return torch.from_numpy(voxels), torch.from_numpy(idx), torch.from_numpy(num), torch.from_numpy(ids)
+
+
+sp = types.ModuleType("spconv"); spp = types.ModuleType("spconv.pytorch")
+spm = types.ModuleType("spconv.pytorch.modules"); spu = types.ModuleType("spconv.pytorch.utils")
+for k in ["SparseConvTensor", "SparseSequential", "SubMConv3d", "SparseConv3d", "SparseInverseConv3d", "SparseModule"]:
+    setattr(spp, k, globals()[k])
+spm.SparseModule = SparseModule
+spu.PointToVoxel = PointToVoxel
+sp.pytorch = spp; spp.modules = spm; spp.utils = spu
+sys.modules.update({"spconv": sp, "spconv.pytorch": spp, "spconv.pytorch.modules": spm, "spconv.pytorch.utils": spu})
+
+torch.Tensor.cuda = lambda self, *a, **k: self               # cuda_cast -> identity on CPU
+
+# --------------------------------------------------------------------------- the reference, imported
+from tree_learn.model.tree_learn import TreeLearn, voxelize as ref_voxelize       # noqa: E402
+from tree_learn.util.train import point_wise_loss                                  # noqa: E402
+from tree_learn.util import pipeline as ref_pipe                                   # noqa: E402
+from tree_learn.dataset.dataset import TreeDataset                                 # noqa: E402
+
+from oracle.model import random_state_dict                                         # noqa: E402
+from treelearn_amd.synth import make_tile, make_batch                              # noqa: E402
+
+import sklearn                                                                     # noqa: E402
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name), **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", name, {k: np.asarray(v).shape for k, v in arrs.items()})
+
+
+def small_tile(seed, extent, voxel, n_trees, zmax, drop_frac=0.0):
+    t = make_tile(extent=extent, voxel=voxel, n_trees=n_trees, fill=0.10, seed=seed)
+    keep = t["points"][:, 2] < zmax
+    if drop_frac:
+        keep &= np.random.default_rng(seed + 99).uniform(size=len(keep)) > drop_frac
+    return {k: (v[keep] if k != "center" else v) for k, v in t.items()}
+
+
+def g1_g2_loss():
+    rng = np.random.default_rng(1)
+    cases = {}
+    for name, (n, sem_all_false, off_all_false) in dict(a=(500, False, False), b=(300, True, False), c=(300, False, True), d=(64, True, True)).items():
+        logits = rng.normal(size=(n, 2)).astype(np.float32); offs = rng.normal(size=(n, 3)).astype(np.float32)
+        ms = np.zeros(n, bool) if sem_all_false else rng.uniform(size=n) < 0.6
+        mo = np.zeros(n, bool) if off_all_false else rng.uniform(size=n) < 0.3
+        sl = rng.integers(0, 2, n).astype(np.int64); ol = rng.normal(size=(n, 3)).astype(np.float32)
+        T = torch.from_numpy
+        sem, off = point_wise_loss.__wrapped__(T(logits), T(offs), T(ms), T(mo), T(sl), T(ol))
+        model = TreeLearn.__new__(TreeLearn)
+        loss, ld = TreeLearn.get_loss.__wrapped__(model, dict(semantic_prediction_logits=T(logits), offset_predictions=T(offs)),
+                                                  T(sl), T(ol), T(mo), T(ms))
+        for k, v in dict(logits=logits, offsets=offs, masks_sem=ms, masks_off=mo, semantic_labels=sl, offset_labels=ol,
+                         pw_sem=float(sem), pw_off=float(off), loss=float(loss),
+                         semantic_loss=float(ld["semantic_loss"]), offset_loss=float(ld["offset_loss"])).items():
+            cases[f"{name}_{k}"] = v
+    save("g1_g2_loss.npz", **cases)
+
+
+def g3_voxelize():
+    tiles = [small_tile(3, 6, 0.2, 2, 8.0), small_tile(4, 5, 0.2, 1, 6.0)]
+    # put a few duplicate-voxel points in (tiles are de-duplicated per global voxel, not per min-relative voxel)
+    b = make_batch(tiles)
+    out = {}
+    feats = torch.hstack([b["coords"], b["input_feats"]])
+    out["coords"] = b["coords"].numpy(); out["input_feats"] = b["input_feats"].numpy(); out["batch_ids"] = b["batch_ids"].numpy()
+    for uc in (False, True):
+        for uf in (False, True):
+            vf, vc, v2p, ss = ref_voxelize(feats, b["batch_ids"], 2, 0.2, uc, uf, max_num_points_per_voxel=3)
+            tag = f"c{int(uc)}f{int(uf)}"
+            assert vc.dtype == torch.float32 and v2p.dtype == torch.int64
+            out[f"{tag}_voxel_feats"] = vf.numpy(); out[f"{tag}_voxel_coords"] = vc.numpy()
+            out[f"{tag}_v2p"] = v2p.numpy(); out[f"{tag}_spatial_shape"] = ss.numpy()
+    save("g3_voxelize.npz", **out)
+
+
+def g4_collate(tmp="/tmp/tl_golden_tiles"):
+    import logging, shutil
+    shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp)
+    names = []
+    for s in (11, 12):
+        t = small_tile(s, 7, 0.2, 2, 8.0)
+        t["center"] = np.array([10.0 * s, -3.0, 1.5])
+        np.savez(os.path.join(tmp, f"tile{s}.npz"), **t); names.append(f"tile{s}.npz")
+    ds = TreeDataset(tmp, 4, False, logging.getLogger("golden"))
+    ds.data_paths = [os.path.join(tmp, n) for n in names]          # deterministic order
+    batch = ds.collate_fn([ds[0], ds[1]])
+    out = {f"in{i}_{k}": np.load(os.path.join(tmp, n))[k] for i, n in enumerate(names) for k in ("points", "feat", "instance_label", "center")}
+    for k, v in batch.items():
+        out[f"batch_{k}"] = v.numpy() if torch.is_tensor(v) else v
+    save("g4_collate.npz", **out)
+
+
+def _cluster_inputs(seed, n_trees=6, per_tree=400, n_ground=3000):
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(-15, 15, size=(n_trees, 2))
+    coords, offs, logits, vert = [], [], [], []
+    for c in centers:
+        n = per_tree + int(rng.integers(0, 200))
+        p = np.column_stack([c[0] + rng.normal(0, 1.5, n), c[1] + rng.normal(0, 1.5, n), rng.uniform(0, 20, n)])
+        base = np.array([c[0], c[1], 0.0])
+        o = base - p + rng.normal(0, 0.04, (n, 3))
+        coords.append(p); offs.append(o)
+        lg = np.column_stack([rng.normal(2, 1, n), rng.normal(-2, 1, n)]); logits.append(lg)
+        vert.append(rng.uniform(0.3, 1.0, n))
+    n = n_ground
+    p = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.normal(0, 0.1, n)])
+    coords.append(p); offs.append(rng.normal(0, 0.5, (n, 3)))
+    logits.append(np.column_stack([rng.normal(-2, 1, n), rng.normal(2, 1, n)])); vert.append(rng.uniform(0, 1, n))
+    f = lambda xs: np.concatenate(xs).astype(np.float32)
+    return f(coords), f(offs), f(logits), f(vert)
+
+
+def g5_clustering():
+    out = {"sklearn_version": sklearn.__version__}
+    for case, seed in (("a", 5), ("b", 6)):
+        coords, offs, logits, vert = _cluster_inputs(seed)
+        out.update({f"{case}_coords": coords, f"{case}_offsets": offs, f"{case}_logits": logits, f"{case}_vert": vert})
+        for use_h in (False, True):
+            cfg = types.SimpleNamespace(tree_conf_thresh=0.5, tau_vert=0.6, tau_off=4, tau_group=0.15, tau_min=50, use_hdbscan=use_h)
+            pred = ref_pipe.get_instances(coords, offs, logits, cfg, vert, 0, 0, -1, 1)
+            out[f"{case}_{'hdbscan' if use_h else 'dbscan'}_pred"] = pred
+    rng = np.random.default_rng(7)
+    lab = rng.choice([3, 7, 8, 20, 21], 200)
+    new, mapping = ref_pipe.make_labels_consecutive(lab, start_num=1)
+    out.update(mlc_in=lab, mlc_out=new, mlc_map_keys=np.array(list(mapping.keys())), mlc_map_vals=np.array(list(mapping.values())))
+    # raw group_dbscan on 2-D points incl. small clusters and noise
+    xy = np.concatenate([rng.normal(0, 0.05, (120, 2)), rng.normal(3, 0.05, (30, 2)), rng.uniform(-10, 10, (40, 2)),
+                         rng.normal((0, 5), 0.08, (300, 2))]).astype(np.float32)
+    out["gd_xy"] = xy
+    out["gd_pred"] = ref_pipe.group_dbscan(xy, 0.15, 50, -1, 1)
+    save("g5_clustering.npz", **out)
+
+
+def g6_g7_next_rows():
+    rng = np.random.default_rng(8)
+    base = np.round(rng.uniform(-5, 5, (400, 3)), 2).astype(np.float32)
+    rep = np.concatenate([base, base[:250], base[100:180]])
+    perm = rng.permutation(len(rep)); coords = rep[perm]
+    n = len(coords)
+    sem = rng.normal(size=(n, 2)).astype(np.float32); seml = rng.integers(0, 2, n).astype(np.int64)
+    off = rng.normal(size=(n, 3)).astype(np.float32); offl = rng.normal(size=(n, 3)).astype(np.float32)
+    inst = rng.integers(0, 5, n).astype(np.int64); feats = rng.normal(size=(n, 4)).astype(np.float32)
+    inf = rng.uniform(size=(n, 1)).astype(np.float32)
+    res = ref_pipe.ensemble(coords, sem, seml, off, offl, inst, feats, inf)
+    out = dict(e_coords=coords, e_sem=sem, e_seml=seml, e_off=off, e_offl=offl, e_inst=inst, e_feats=feats, e_inf=inf)
+    for i, r in enumerate(res):
+        out[f"e_out{i}"] = r
+    pts = rng.normal(size=(600, 3)).astype(np.float32) + rng.integers(0, 3, 600)[:, None].astype(np.float32) * 4
+    pred = (pts[:, 0] // 4 + 1).clip(1, 3).astype(np.int64); pred[rng.uniform(size=600) < 0.3] = -1
+    out.update(k_coords=pts, k_pred=pred, k_out=ref_pipe.assign_remaining_points_nearest_neighbor(pts, pred, -1))
+    save("g6_g7_next.npz", **out)
+
+
+def g8_manifest():
+    m = TreeLearn(channels=32, num_blocks=7, use_feats=False, use_coords=False)
+    sd = m.state_dict()
+    man = [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]
+    nparam = sum(p.numel() for p in m.parameters())
+    with open(os.path.join(HERE, "g8_manifest.json"), "w") as f:
+        json.dump(dict(n_params=nparam, n_keys=len(man), keys=man), f)
+    print("wrote g8_manifest.json", nparam, len(man))
+
+
+def g9_tile_loop():
+    class Fake(nn.Module):
+        def forward(self, batch, return_loss):
+            c = batch["coords"]
+            if float(c[:, 0].mean()) > 900:
+                raise RuntimeError("your out spatial shape reach zero!!! (fake)")
+            return dict(offset_predictions=c * 0.5 + 1, semantic_prediction_logits=torch.stack([c[:, 0], -c[:, 1]], 1),
+                        backbone_feats=c.repeat(1, 11)[:, :32])
+    tiles = []
+    for s, shift in ((21, 0.0), (22, 1000.0), (23, 0.0)):
+        t = small_tile(s, 7, 0.2, 2, 8.0)
+        t["center"] = np.array([float(s), 2.0, 0.5])
+        b = make_batch([t], inner_square_edge_length=4.0)
+        b["coords"] = b["coords"] + shift * torch.tensor([1.0, 0, 0])
+        tiles.append(b)
+    out = {}
+    for i, b in enumerate(tiles):
+        for k, v in b.items():
+            out[f"t{i}_{k}"] = v.numpy() if torch.is_tensor(v) else v
+    res = ref_pipe.get_pointwise_preds(Fake(), [dict(b) for b in tiles], types.SimpleNamespace(voxel_size=0.2))
+    for i, r in enumerate(res):
+        out[f"out{i}"] = r
+    save("g9_tile_loop.npz", **out)
+
+
+def g10_forward():
+    """The reference's own module tree, executed through the dense stand-in."""
+    out = {}
+    cases = {
+        # name: (model cfg, tile, spatial_shape, batch tiles)
+        "m3": (dict(channels=32, num_blocks=3), [small_tile(31, 7, 0.2, 2, 9.0)], None, 0.2),
+        "m7": (dict(channels=8, num_blocks=7), [small_tile(32, 9, 0.2, 3, 20.0, 0.3)], [64, 64, 128], 0.2),
+        "m2b": (dict(channels=16, num_blocks=2), [small_tile(33, 5, 0.2, 1, 6.0), small_tile(34, 4, 0.2, 1, 5.0)], None, 0.2),
+    }
+    for name, (cfg, tiles, sshape, vs) in cases.items():
+        model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=sshape, voxel_size=vs, **cfg)
+        sd = random_state_dict(1000 + len(name) + cfg["channels"], **cfg)
+        missing, unexpected = model.load_state_dict(sd, strict=True)
+        batch = make_batch(tiles, inner_square_edge_length=4.0)
+        for k, v in batch.items():
+            out[f"{name}_in_{k}"] = v.numpy() if torch.is_tensor(v) else v
+        out[f"{name}_cfg"] = json.dumps(dict(cfg=cfg, spatial_shape=sshape, voxel_size=vs, seed=1000 + len(name) + cfg["channels"]))
+        model.eval()
+        with torch.no_grad():
+            o = model(batch, return_loss=False)
+            loss, ld = model(batch, return_loss=True)
+        for k, v in o.items():
+            out[f"{name}_eval_{k}"] = v.numpy()
+        out[f"{name}_eval_loss"] = float(loss); out[f"{name}_eval_semantic_loss"] = float(ld["semantic_loss"]); out[f"{name}_eval_offset_loss"] = float(ld["offset_loss"])
+        if name != "m7":
+            model.train()
+            model.zero_grad()
+            loss, ld = model(batch, return_loss=True)
+            loss.backward()
+            out[f"{name}_train_loss"] = float(loss)
+            out[f"{name}_train_semantic_loss"] = float(ld["semantic_loss"]); out[f"{name}_train_offset_loss"] = float(ld["offset_loss"])
+            # a handful of gradients (full set would be MBs): norms for every parameter + two full tensors
+            names, norms = [], []
+            for k, p in model.named_parameters():
+                names.append(k); norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+            out[f"{name}_grad_names"] = np.array(names); out[f"{name}_grad_norms"] = np.array(norms, np.float64)
+            out[f"{name}_grad_input_conv"] = getattr(model.input_conv, "0").weight.grad.numpy()
+            out[f"{name}_grad_sem3"] = model.semantic_linear[3].weight.grad.numpy()
+            out[f"{name}_bn_running_mean_after"] = getattr(model.output_layer, "0").running_mean.numpy()
+    # reach-zero behaviour: 3 levels on a 5-voxel-high tile with spatial_shape None
+    t = small_tile(35, 3, 0.5, 1, 1.0)
+    model = TreeLearn(channels=8, num_blocks=4, use_feats=False, use_coords=False, spatial_shape=None, voxel_size=0.5)
+    try:
+        with torch.no_grad():
+            model.eval(); model(make_batch([t]), return_loss=False)
+        out["reach_zero_raised"] = False
+    except Exception as e:                                   # noqa: BLE001
+        out["reach_zero_raised"] = "reach zero!!!" in str(e)
+    for k, v in make_batch([t]).items():
+        out[f"rz_in_{k}"] = v.numpy() if torch.is_tensor(v) else v
+    save("g10_forward.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
+    fns = dict(g1=g1_g2_loss, g3=g3_voxelize, g4=g4_collate, g5=g5_clustering, g6=g6_g7_next_rows, g8=g8_manifest, g9=g9_tile_loop, g10=g10_forward)
+    for w in which:
+        fns[w]()

@@ -1,0 +1,100 @@
+"""Pin the CPU oracle to the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from oracle import voxel as ov
+
+T = torch.from_numpy
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_g1_g2_loss(golden_dir):
+    g = _load(golden_dir, "g1_g2_loss.npz")
+    for c in "abcd":
+        args = [T(g[f"{c}_{k}"]) for k in ("logits", "offsets", "masks_sem", "masks_off", "semantic_labels", "offset_labels")]
+        sem, off = om.point_wise_loss(*args)
+        assert float(sem) == pytest.approx(float(g[f"{c}_pw_sem"]), rel=1e-6, abs=1e-7)
+        assert float(off) == pytest.approx(float(g[f"{c}_pw_off"]), rel=1e-6, abs=1e-7)
+        loss, ld = om.get_loss(dict(semantic_prediction_logits=args[0], offset_predictions=args[1]),
+                               args[4], args[5], args[3], args[2])
+        assert float(loss) == pytest.approx(float(g[f"{c}_loss"]), rel=1e-6, abs=1e-7)
+        assert float(ld["semantic_loss"]) == pytest.approx(float(g[f"{c}_semantic_loss"]), rel=1e-6, abs=1e-7)
+        assert float(ld["offset_loss"]) == pytest.approx(float(g[f"{c}_offset_loss"]), rel=1e-6, abs=1e-7)
+
+
+@pytest.mark.parametrize("uc,uf", [(False, False), (False, True), (True, False), (True, True)])
+def test_g3_voxelize(golden_dir, uc, uf):
+    g = _load(golden_dir, "g3_voxelize.npz")
+    tag = f"c{int(uc)}f{int(uf)}"
+    vf, vc, v2p, ss = ov.voxelize(g["coords"], g["input_feats"], g["batch_ids"], 2, 0.2, uc, uf, 3)
+    # reference returns float coords (b,x,y,z) in per-element ascending (x,y,z) order == ascending key
+    np.testing.assert_array_equal(vc.astype(np.float32), g[f"{tag}_voxel_coords"])
+    np.testing.assert_array_equal(v2p, g[f"{tag}_v2p"])
+    np.testing.assert_array_equal(ss.astype(np.float32), g[f"{tag}_spatial_shape"])
+    np.testing.assert_allclose(vf, g[f"{tag}_voxel_feats"], rtol=1e-6, atol=1e-6)
+
+
+def test_g8_manifest(golden_dir):
+    with open(os.path.join(golden_dir, "g8_manifest.json")) as f:
+        man = json.load(f)
+    ours = om.state_dict_manifest(channels=32, num_blocks=7)
+    assert man["n_keys"] == 414 == len(ours)
+    assert [k for k, _, _ in man["keys"]] == [k for k, _ in ours]
+    assert [tuple(s) for _, s, _ in man["keys"]] == [tuple(s) for _, s in ours]
+    n_params = sum(int(np.prod(s)) for k, s in ours if "running_" not in k and "num_batches" not in k)
+    assert n_params == man["n_params"] == 30106981
+
+
+def _batch(g, name):
+    keys = ["coords", "input_feats", "batch_ids", "semantic_labels", "instance_labels", "masks_inner", "masks_off",
+            "masks_sem", "offset_labels", "centers"]
+    b = {k: T(g[f"{name}_in_{k}"]) for k in keys}
+    b["batch_size"] = int(g[f"{name}_in_batch_size"])
+    return b
+
+
+@pytest.mark.parametrize("name", ["m3", "m7", "m2b"])
+def test_g10_forward_eval(golden_dir, name):
+    g = _load(golden_dir, "g10_forward.npz")
+    cfg = json.loads(str(g[f"{name}_cfg"]))
+    sd = om.random_state_dict(cfg["seed"], **cfg["cfg"])
+    b = _batch(g, name)
+    out = om.forward(sd, b["coords"].numpy(), b["input_feats"].numpy(), b["batch_ids"].numpy(), b["batch_size"],
+                     voxel_size=cfg["voxel_size"], num_blocks=cfg["cfg"]["num_blocks"], spatial_shape=cfg["spatial_shape"])
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        ref = g[f"{name}_eval_{k}"]
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(out[k].numpy(), ref, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    loss, ld = om.get_loss(out, b["semantic_labels"], b["offset_labels"], b["masks_off"], b["masks_sem"])
+    assert float(loss) == pytest.approx(float(g[f"{name}_eval_loss"]), rel=1e-4)
+
+
+@pytest.mark.parametrize("name", ["m3", "m2b"])
+def test_g10_forward_train_loss(golden_dir, name):
+    g = _load(golden_dir, "g10_forward.npz")
+    cfg = json.loads(str(g[f"{name}_cfg"]))
+    sd = om.random_state_dict(cfg["seed"], **cfg["cfg"])
+    b = _batch(g, name)
+    out = om.forward(sd, b["coords"].numpy(), b["input_feats"].numpy(), b["batch_ids"].numpy(), b["batch_size"],
+                     voxel_size=cfg["voxel_size"], num_blocks=cfg["cfg"]["num_blocks"], spatial_shape=cfg["spatial_shape"],
+                     training=True)
+    loss, ld = om.get_loss(out, b["semantic_labels"], b["offset_labels"], b["masks_off"], b["masks_sem"])
+    assert float(loss) == pytest.approx(float(g[f"{name}_train_loss"]), rel=2e-4)
+    assert float(ld["offset_loss"]) == pytest.approx(float(g[f"{name}_train_offset_loss"]), rel=2e-4)
+
+
+def test_g10_reach_zero(golden_dir):
+    g = _load(golden_dir, "g10_forward.npz")
+    assert bool(g["reach_zero_raised"])
+    sd = om.random_state_dict(1, channels=8, num_blocks=4)
+    with pytest.raises(ValueError, match="reach zero!!!"):
+        om.forward(sd, g["rz_in_coords"], g["rz_in_input_feats"], g["rz_in_batch_ids"], 1, voxel_size=0.5, num_blocks=4)
