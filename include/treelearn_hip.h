@@ -1,0 +1,166 @@
+/*
+ * treelearn_hip.h -- C ABI of libtreelearn_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the TreeLearn per-tile sparse-conv segmentation path.  The
+ * reference (ecker-lab/TreeLearn) has no FFI of its own: its device work is delegated to
+ * the third-party `spconv` wheel and to ATen.  Each entry point below replaces one of
+ * those call sites (cited as reference file:line).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch-ROCm caching
+ *     allocator in our host code); the library never allocates or frees device memory;
+ *   - every call takes the hipStream_t to enqueue on (as void*) and returns immediately;
+ *   - return value: 0 = TL_OK, negative = error (tl_error_string); no exceptions, no
+ *     global state; calls on one stream must not be issued concurrently;
+ *   - "table" = rulebook in tap-major layout i32[K][n_out], entry = input row or -1
+ *     (SURVEY.md Appendix F canonical form, transposed for coalesced access).
+ */
+#ifndef TREELEARN_HIP_H
+#define TREELEARN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tl_stream_t; /* hipStream_t */
+
+enum {
+  TL_OK = 0,
+  TL_ERR_ARG = -1,       /* bad argument (null pointer, unsupported size) */
+  TL_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch was not hipSuccess */
+  TL_ERR_UNSUPPORTED = -3
+};
+
+enum { TL_F32 = 0, TL_BF16 = 1 };
+
+int tl_version(void);
+const char* tl_error_string(int code);
+
+/* ------------------------------------------------------------------ voxel hashing
+ * Replaces spconv PointToVoxel.generate_voxel_with_id + the min/max/.tolist() prologue of
+ * `voxelize` (reference tree_learn/model/tree_learn.py:129-167, call site :136-143).
+ *
+ * The "hash table" is a succinct rank structure instead of an open-addressing table:
+ * an occupancy bitmap over the tile's voxel grid (1 bit per cell, z along the 64-bit word)
+ * plus an exclusive prefix sum of word popcounts.  rank(cell) = prefix[word] +
+ * popc(word & below(bit)) is the voxel's row in ascending (b,x,y,z) order, i.e. the
+ * canonical order of SURVEY.md Appendix F, with no sort and no probing.
+ */
+
+/* Per-point integer voxel coordinates.
+ *   xyz f32[N,3], batch_ids i64[N], B batch elements, voxel_size.
+ *   ws_minmax u32[B*6] scratch; pcoords i32[N,4] out = (b,x,y,z) with
+ *   x = floorf((p - min_b) / voxel_size) in fp32 (tree_learn.py:134, spconv PointToVoxel);
+ *   maxc i32[4] out = {max x, max y, max z, error flag}. */
+int tl_voxel_point_coords(const float* xyz, const int64_t* batch_ids, int64_t N, int B, float voxel_size,
+                          uint32_t* ws_minmax, int32_t* pcoords, int32_t* maxc, tl_stream_t stream);
+
+/* Occupancy bitmap of the level-1 grid.  dims = {B, X, Y, Z}; bitmap u64[B*X*Y*ceil(Z/64)] (zeroed here). */
+int tl_bitmap_from_points(const int32_t* pcoords, int64_t N, const int32_t dims[4], uint64_t* bitmap, tl_stream_t stream);
+
+/* Occupancy of the stride-2 coarse grid (SparseConv3d k=2 s=2 output set, reference
+ * tree_learn/model/blocks.py:104-110): coarse cell = OR of its 2x2x2 children; cells at or beyond
+ * out_shape[3] (= in_shape // 2) are dropped.
+ * fdims = {B,Xf,Yf,Zf}; cdims = {B, ceil(Xf/2), ceil(Yf/2), ceil(Zf/2)}. */
+int tl_bitmap_down(const uint64_t* fine, const int32_t fdims[4], const int32_t out_shape[3],
+                   uint64_t* coarse, const int32_t cdims[4], tl_stream_t stream);
+
+/* Exclusive prefix sum of popcounts.  prefix u32[nwords]; total u32[1] (device); ws u32[tl_scan_ws_words(nwords)]. */
+int64_t tl_scan_ws_words(int64_t nwords);
+int tl_bitmap_scan(const uint64_t* bitmap, int64_t nwords, uint32_t* prefix, uint32_t* total, uint32_t* ws, tl_stream_t stream);
+
+/* coords i32[M,4] = (b,x,y,z) of every set bit, in rank order. */
+int tl_expand_coords(const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4], int32_t* coords, tl_stream_t stream);
+
+/* v2p i64[N]: voxel row of every point (tree_learn.py:143 pc_voxel_id, :160-161 batch offsets implicit). */
+int tl_point_rank(const int32_t* pcoords, int64_t N, const uint64_t* bitmap, const uint32_t* prefix,
+                  const int32_t dims[4], int64_t* v2p, tl_stream_t stream);
+
+/* Optional voxel features (use_coords / use_feats, tree_learn.py:149-156): mean over the first <= P points of
+ * each voxel in input order, all-zero point rows skipped; pf f32[N,C] rows (x,y,z,feat..); out f32[M,C]
+ * in (x,y,z,feat..) order; ws i32[M*P] scratch. */
+int tl_voxel_mean_feats(const float* pf, int C, const int64_t* v2p, int64_t N, int64_t M, int P,
+                        int32_t* ws, float* out, tl_stream_t stream);
+
+/* ------------------------------------------------------------------ rulebooks
+ * Replaces spconv's indice generation for SubMConv3d(k=3,pad=1) (`subm{l}`, tree_learn.py:37-39,
+ * blocks.py:57-70) and SparseConv3d(k=2,s=2)/SparseInverseConv3d(k=2) (`spconv{l}`, blocks.py:104-123). */
+
+/* nbr i32[27][M]: tap = (dx+1)*9 + (dy+1)*3 + (dz+1), entry = input row or -1; nbr[13][i] == i. */
+int tl_rulebook_subm(const int32_t* coords, int64_t M, const uint64_t* bitmap, const uint32_t* prefix,
+                     const int32_t dims[4], int32_t* nbr, tl_stream_t stream);
+
+/* child i32[8][Mc] (tap = (x&1)*4+(y&1)*2+(z&1)), parent i32[Mf] (-1 = dropped), inv i32[8][Mf]
+ * (inv[tap(p)][p] = parent[p], other taps -1: the inverse conv's table).  parent and inv are filled here. */
+int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap, const uint32_t* fprefix,
+                     const int32_t fdims[4], int64_t Mf, int32_t* child, int32_t* parent, int32_t* inv, tl_stream_t stream);
+
+/* tapmask u32[ceil(n_out/32)]: bit k set iff some row of the 32-row group has table[k][row] >= 0. */
+int tl_table_tapmask(const int32_t* table, int K, int64_t n_out, uint32_t* tapmask, tl_stream_t stream);
+
+/* ------------------------------------------------------------------ sparse convolution
+ * Replaces spconv SubMConv3d / SparseConv3d / SparseInverseConv3d forward (blocks.py:57-70,104-123,
+ * tree_learn.py:37-39) and Custom1x1Subm3d's torch.mm (blocks.py:29-39), with the surrounding
+ * BatchNorm1d+ReLU (blocks.py:56,63,103,117; tree_learn.py:42), residual add (blocks.py:76) and skip
+ * concat (blocks.py:146, via in_ld/out_ld column views) fused as prologue / epilogue.
+ *
+ *   out[o, :] = epi( sum_k  W[k] . pro(in[table[k][o], :]) )        (absent rows contribute 0)
+ *   pro(x) = relu?(x * in_scale + in_shift)       epi(y) = relu?((y + residual[o]) * out_scale + out_shift)
+ */
+typedef struct tl_conv_args {
+  const void* in;        int64_t in_ld;   /* row stride in elements (>= Cin) */
+  const void* weight;                     /* [K][Cout][Cin], same dtype as `in` */
+  const int32_t* table;                   /* [K][n_out], or NULL = identity (K must be 1) */
+  const uint32_t* tapmask;                /* [ceil(n_out/32)] or NULL */
+  int64_t n_out;         int64_t n_in;
+  int32_t K;             int32_t Cin;     int32_t Cout;   int32_t dtype;   /* TL_F32 | TL_BF16 */
+  const float* in_scale; const float* in_shift;  int32_t in_relu;  int32_t out_relu;
+  const void* residual;  int64_t res_ld;
+  const float* out_scale; const float* out_shift;
+  void* out;             int64_t out_ld;
+  float* stats;                           /* optional f32[2*Cout]: += sum, sumsq of (acc+residual) per channel */
+} tl_conv_args;
+
+int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
+
+/* Repack a reference-layout conv weight [Cout, k,k,k, Cin] (spconv `.weight`)
+ * into the kernel layout [K=k^3][Cout][Cin] with dtype conversion. */
+int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream);
+
+/* ------------------------------------------------------------------ per-point heads
+ * Replaces forward_head (tree_learn.py:97-103): features[v2p] gather, output_layer BN+ReLU
+ * (tree_learn.py:42,93) as prologue, then both MLPs (blocks.py:8-18) with eval-mode BN folded:
+ *   h = relu(W1' f + b1'),  y = W2 h + b2.
+ * feats [M,C] (dtype), v2p i64[N]; w1 f32[2][C][C], b1 f32[2][C] (BN folded), w2 f32[5][C] (2 semantic rows
+ * then 3 offset rows), b2 f32[5].  backbone f32[N,C] may be NULL (skip the 128 B/point write). */
+int tl_head_mlp(const void* feats, int64_t feats_ld, int dtype, int C, const int64_t* v2p, int64_t N,
+                const float* pro_scale, const float* pro_shift,
+                const float* w1, const float* b1, const float* w2, const float* b2,
+                float* backbone, float* logits, float* offsets, tl_stream_t stream);
+
+/* ------------------------------------------------------------------ elementwise helpers */
+/* out = relu?(in * scale + shift) over [n, C] with row strides (BatchNorm1d eval + ReLU, tree_learn.py:42). */
+int tl_affine_relu(const void* in, int64_t in_ld, void* out, int64_t out_ld, int64_t n, int C, int dtype,
+                   const float* scale, const float* shift, int relu, tl_stream_t stream);
+
+/* Keep rows where mask != 0 (masks_inner filtering before D2H, util/pipeline.py:100-103).
+ * in f32[n,C] -> out f32[count,C]; count i32[1] device.  Stable (input order kept).
+ * ws i32[tl_compact_ws_words(n)] scratch. */
+int64_t tl_compact_ws_words(int64_t n);
+int tl_compact_rows(const float* in, int C, const uint8_t* mask, int64_t n, float* out, int32_t* count,
+                    int32_t* ws, tl_stream_t stream);
+
+/* ------------------------------------------------------------------ clustering
+ * Replaces sklearn DBSCAN(eps, min_samples=2) in group_dbscan (tree_learn/util/pipeline.py:173-180):
+ * connected components of the eps-graph on 2-D points; isolated points = -1; component labels
+ * 0..K-1 ordered by the smallest point index of each component (sklearn's numbering).
+ * xy f32[n,2]; labels i32[n] out; n_clusters i32[1] device out;
+ * ws: tl_cluster_ws_bytes(n) bytes. */
+int64_t tl_cluster_ws_bytes(int64_t n);
+int tl_cluster_grid(const float* xy, int64_t n, float eps, int32_t* labels, int32_t* n_clusters,
+                    void* ws, tl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TREELEARN_HIP_H */

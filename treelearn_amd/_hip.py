@@ -1,0 +1,109 @@
+"""ctypes binding of libtreelearn_hip.so (the C ABI declared in include/treelearn_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  PyTorch only provides device memory (`tensor.data_ptr()`) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtreelearn_hip.so")
+
+TL_F32, TL_BF16 = 0, 1
+_c = ctypes
+_vp, _i64, _i32, _f32 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_float
+
+
+class ConvArgs(_c.Structure):
+    _fields_ = [
+        ("in_", _vp), ("in_ld", _i64), ("weight", _vp), ("table", _vp), ("tapmask", _vp),
+        ("n_out", _i64), ("n_in", _i64), ("K", _i32), ("Cin", _i32), ("Cout", _i32), ("dtype", _i32),
+        ("in_scale", _vp), ("in_shift", _vp), ("in_relu", _i32), ("out_relu", _i32),
+        ("residual", _vp), ("res_ld", _i64), ("out_scale", _vp), ("out_shift", _vp),
+        ("out", _vp), ("out_ld", _i64), ("stats", _vp),
+    ]
+
+
+_I4 = _i32 * 4
+_I3 = _i32 * 3
+
+# name -> (restype, argtypes); every symbol include/treelearn_hip.h declares
+PROTOTYPES = {
+    "tl_version": (_i32, []),
+    "tl_error_string": (_c.c_char_p, [_i32]),
+    "tl_voxel_point_coords": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "tl_bitmap_from_points": (_i32, [_vp, _i64, _I4, _vp, _vp]),
+    "tl_bitmap_down": (_i32, [_vp, _I4, _I3, _vp, _I4, _vp]),
+    "tl_scan_ws_words": (_i64, [_i64]),
+    "tl_bitmap_scan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "tl_expand_coords": (_i32, [_vp, _vp, _I4, _vp, _vp]),
+    "tl_point_rank": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
+    "tl_voxel_mean_feats": (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
+    "tl_rulebook_down": (_i32, [_vp, _i64, _vp, _vp, _I4, _i64, _vp, _vp, _vp, _vp]),
+    "tl_table_tapmask": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
+    "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "tl_head_mlp": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tl_affine_relu": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "tl_compact_ws_words": (_i64, [_i64]),
+    "tl_compact_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tl_cluster_ws_bytes": (_i64, [_i64]),
+    "tl_cluster_grid": (_i32, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m treelearn_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the product path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib().tl_error_string(rc).decode()} ({rc})")
+
+
+def ptr(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def dims4(d):
+    return _I4(*[int(v) for v in d])
+
+
+def dims3(d):
+    return _I3(*[int(v) for v in d])
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return TL_F32
+    if dt == torch.bfloat16:
+        return TL_BF16
+    raise ValueError(f"unsupported compute dtype {dt}")
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")

@@ -1,0 +1,62 @@
+"""Build libtreelearn_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m treelearn_amd.build [--force]
+
+The library is built IN-TREE (treelearn_amd/lib/) so it travels with the repo snapshot to the
+GPU box; it is git-ignored.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libtreelearn_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "treelearn_hip.h"))
+    srcs = sources()
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+
+    def compile_one(so):
+        s, o = so
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            return True
+        return False
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        changed = list(ex.map(compile_one, zip(srcs, objs)))
+    if force or any(changed) or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,307 @@
+// Sparse convolution forward (SubMConv3d / SparseConv3d / SparseInverseConv3d / 1x1) for gfx950.
+//
+// Output-stationary gather-GEMM: a workgroup owns 128 consecutive output rows (ascending voxel
+// key => spatially adjacent), walks the kernel taps that have at least one present neighbour in the
+// tile, gathers the neighbour rows (16-B loads, 128 B contiguous per row segment), applies the
+// fused BatchNorm+ReLU prologue, stages them with the tap's weight slice in padded LDS and
+// contracts on the matrix cores; every output row is written exactly once (no atomics =>
+// bit-deterministic), with the residual add / BatchNorm+ReLU epilogue fused into the store.
+//
+//   fp32 : v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf chain) -- the parity path.
+//   bf16 : v_mfma_f32_32x32x16_bf16, fp32 accumulate                  -- the throughput path.
+//
+// LDS row pitch = 32 channels + 16 B pad: ds_read_b128 of 16 different rows at one column offset
+// lands on 16 different 16-B slots (36*r mod 64 is a permutation of multiples of 4 for r mod 16),
+// i.e. conflict-free for the b128 lane groups of MI355X_MICROARCH.md §LDS.
+#include "tl_common.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvP {
+  const void* in; int64_t in_ld;
+  const void* w;
+  const int32_t* table;
+  int64_t n_out, n_in;
+  int K, Cin, Cout;
+  const float* in_scale; const float* in_shift; int in_relu, out_relu;
+  const void* res; int64_t res_ld;
+  const float* out_scale; const float* out_shift;
+  void* out; int64_t out_ld;
+  int nblk;
+};
+
+__device__ __forceinline__ float ld_elem(const float* p) { return *p; }
+__device__ __forceinline__ float ld_elem(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+__device__ __forceinline__ void st_elem(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_elem(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+// XCD-aware tile order: block b runs on XCD b % 8 (observed, speed only); give each XCD a contiguous
+// range of tiles so neighbouring tiles -- which gather overlapping input rows -- share one L2.
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// ------------------------------------------------------------------ generic fallback (any Cin/Cout)
+template <typename T>
+__global__ void __launch_bounds__(256) k_conv_generic(ConvP p) {
+  const T* in = (const T*)p.in; const T* w = (const T*)p.w; const T* res = (const T*)p.res; T* out = (T*)p.out;
+  const int64_t total = p.n_out * p.Cout;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / p.Cout; const int j = (int)(t % p.Cout);
+    float acc = 0.f;
+    for (int k = 0; k < p.K; ++k) {
+      const int64_t idx = p.table ? (int64_t)p.table[(int64_t)k * p.n_out + o] : o;
+      if (idx < 0) continue;
+      const T* x = in + idx * p.in_ld;
+      const T* wr = w + ((int64_t)k * p.Cout + j) * p.Cin;
+      for (int c = 0; c < p.Cin; ++c) {
+        float v = ld_elem(x + c);
+        if (p.in_scale) v = fmaf(v, p.in_scale[c], p.in_shift[c]);
+        if (p.in_relu) v = fmaxf(v, 0.f);
+        if (sizeof(T) == 2) v = __bfloat162float(__float2bfloat16(v));   // bf16 path feeds bf16 to the MFMA
+        acc = fmaf(v, ld_elem(wr + c), acc);
+      }
+    }
+    if (res) acc += ld_elem(res + o * p.res_ld + j);
+    if (p.out_scale) acc = fmaf(acc, p.out_scale[j], p.out_shift[j]);
+    if (p.out_relu) acc = fmaxf(acc, 0.f);
+    st_elem(out + o * p.out_ld + j, acc);
+  }
+}
+
+// ------------------------------------------------------------------ fp32 MFMA kernel
+constexpr int TM = 128;          // output rows per workgroup
+constexpr int KC = 32;           // input channels per step
+constexpr int LDA = KC + 4;      // padded LDS pitch in floats (144 B)
+
+template <int NB>                // NB = Cout / 32
+__global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* idx_s = reinterpret_cast<int*>(smem);                                   // [K][TM]
+  unsigned* mask_s = reinterpret_cast<unsigned*>(idx_s + p.K * TM);             // [4] (16 B keeps alignment)
+  float* As = reinterpret_cast<float*>(mask_s + 4);                             // [2][TM][LDA]
+  float* Bs = As + 2 * TM * LDA;                                                // [2][NB*32][LDA]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tile = xcd_tile(blockIdx.x, p.nblk);
+  const int64_t r0 = (int64_t)tile * TM;
+  const float* in = (const float*)p.in; const float* W = (const float*)p.w;
+
+  if (tid == 0) mask_s[0] = 0;
+  __syncthreads();
+  unsigned local = 0;
+  for (int e = tid; e < p.K * TM; e += 256) {
+    const int k = e >> 7, r = e & (TM - 1);
+    const int64_t row = r0 + r;
+    int idx = -1;
+    if (row < p.n_out) idx = p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row;
+    idx_s[e] = idx;
+    if (idx >= 0) local |= 1u << k;
+  }
+  if (local) atomicOr(&mask_s[0], local);
+  __syncthreads();
+  unsigned mask = __builtin_amdgcn_readfirstlane(mask_s[0]);
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  const int nchunk = p.Cin / KC;
+  const int lrow = tid >> 3, c4 = (tid & 7) * 4;
+  float4 ra[4], rb[NB];
+  bool va[4];
+
+  auto issue = [&](int k, int ch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = idx_s[k * TM + lrow + 32 * i];
+      va[i] = idx >= 0;
+      ra[i] = va[i] ? *reinterpret_cast<const float4*>(in + (int64_t)idx * p.in_ld + ch * KC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(W + ((int64_t)k * p.Cout + lrow + 32 * i) * p.Cin + ch * KC + c4);
+  };
+  auto stage = [&](int buf, int ch) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.in_scale) {
+      sc = *reinterpret_cast<const float4*>(p.in_scale + ch * KC + c4);
+      sh = *reinterpret_cast<const float4*>(p.in_shift + ch * KC + c4);
+    }
+    float* a = As + buf * TM * LDA;
+    float* b = Bs + buf * NB * 32 * LDA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if (va[i]) {
+        if (p.in_scale) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
+        if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      *reinterpret_cast<float4*>(a + (lrow + 32 * i) * LDA + c4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDA + c4) = rb[i];
+  };
+
+  if (mask) {
+    int k = __builtin_ctz(mask), ch = 0;
+    issue(k, ch);
+    stage(0, ch);
+    __syncthreads();
+    int buf = 0;
+    const int fi = lane & 31, fh = lane >> 5;
+    while (true) {
+      // next step
+      int nk = k, nch = ch + 1;
+      unsigned nmask = mask;
+      if (nch == nchunk) { nch = 0; nmask = mask & (mask - 1); nk = nmask ? __builtin_ctz(nmask) : -1; }
+      const bool more = nk >= 0;
+      if (more) issue(nk, nch);
+
+      const float* a = As + buf * TM * LDA + (wv * 32 + fi) * LDA + fh * 4;
+      float4 af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const float4*>(a + 8 * j);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float* b = Bs + buf * NB * 32 * LDA + (nb * 32 + fi) * LDA + fh * 4;
+        float4 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const float4*>(b + 8 * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, bf[j].x, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, bf[j].y, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].z, bf[j].z, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].w, bf[j].w, acc[nb], 0, 0, 0);
+        }
+      }
+      if (!more) break;
+      stage(buf ^ 1, nch);
+      __syncthreads();
+      buf ^= 1; k = nk; ch = nch; mask = nmask;
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const float* res = (const float*)p.res; float* out = (float*)p.out;
+  const int col = lane & 31;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = nb * 32 + col;
+    float osc = 1.f, osh = 0.f;
+    if (p.out_scale) { osc = p.out_scale[j]; osh = p.out_shift[j]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = r0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= p.n_out) continue;
+      float v = acc[nb][r];
+      if (res) v += res[row * p.res_ld + j];
+      if (p.out_scale) v = fmaf(v, osc, osh);
+      if (p.out_relu) v = fmaxf(v, 0.f);
+      out[row * p.out_ld + j] = v;
+    }
+  }
+}
+
+template <int NB>
+int launch_mfma_f32(const ConvP& p, hipStream_t s) {
+  const size_t lds = (size_t)p.K * TM * 4 + 16 + 2 * (size_t)TM * LDA * 4 + 2 * (size_t)NB * 32 * LDA * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma_f32<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return TL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  k_conv_mfma_f32<NB><<<p.nblk, 256, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+__global__ void k_pack_weight(const float* __restrict__ w, int Cout, int K, int Cin, void* __restrict__ o, int dtype) {
+  const int64_t total = (int64_t)Cout * K * Cin;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % Cin); const int64_t r = t / Cin; const int j = (int)(r % Cout); const int k = (int)(r / Cout);
+    const float v = w[((int64_t)j * K + k) * Cin + c];                 // reference layout [Cout][K][Cin]
+    if (dtype == TL_F32) reinterpret_cast<float*>(o)[t] = v;
+    else reinterpret_cast<__hip_bfloat16*>(o)[t] = __float2bfloat16(v);
+  }
+}
+
+template <typename T>
+__global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld, int64_t n, int C,
+                              const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+  const int64_t total = n * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C; const int c = (int)(t % C);
+    float v = ld_elem(in + r * in_ld + c);
+    if (scale) v = fmaf(v, scale[c], shift[c]);
+    if (relu) v = fmaxf(v, 0.f);
+    st_elem(out + r * out_ld + c, v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
+  if (!a || !a->in || !a->weight || !a->out || a->n_out <= 0 || a->K <= 0 || a->K > 27 || a->Cin <= 0 || a->Cout <= 0) return TL_ERR_ARG;
+  if (!a->table && a->K != 1) return TL_ERR_ARG;
+  if ((a->in_scale == nullptr) != (a->in_shift == nullptr)) return TL_ERR_ARG;
+  if ((a->out_scale == nullptr) != (a->out_shift == nullptr)) return TL_ERR_ARG;
+  if (a->stats) return TL_ERR_UNSUPPORTED;
+  if (a->dtype != TL_F32 && a->dtype != TL_BF16) return TL_ERR_ARG;
+  ConvP p;
+  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.table = a->table; p.n_out = a->n_out; p.n_in = a->n_in;
+  p.K = a->K; p.Cin = a->Cin; p.Cout = a->Cout; p.in_scale = a->in_scale; p.in_shift = a->in_shift;
+  p.in_relu = a->in_relu; p.out_relu = a->out_relu; p.res = a->residual; p.res_ld = a->res_ld;
+  p.out_scale = a->out_scale; p.out_shift = a->out_shift; p.out = a->out; p.out_ld = a->out_ld;
+  p.nblk = (int)tl_cdiv(a->n_out, TM);
+  hipStream_t s = tl_s(stream);
+  const bool aligned = (a->in_ld % 4 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0) &&
+                       (!a->in_scale || (((uintptr_t)a->in_scale) % 16 == 0 && ((uintptr_t)a->in_shift) % 16 == 0));
+  if (a->dtype == TL_F32 && aligned && a->Cin % KC == 0 && a->Cout % 32 == 0 && a->Cout <= 224) {
+    switch (a->Cout / 32) {
+      case 1: return launch_mfma_f32<1>(p, s);
+      case 2: return launch_mfma_f32<2>(p, s);
+      case 3: return launch_mfma_f32<3>(p, s);
+      case 4: return launch_mfma_f32<4>(p, s);
+      case 5: return launch_mfma_f32<5>(p, s);
+      case 6: return launch_mfma_f32<6>(p, s);
+      case 7: return launch_mfma_f32<7>(p, s);
+    }
+  }
+  const unsigned g = tl_grid(a->n_out * a->Cout, 256);
+  if (a->dtype == TL_F32) k_conv_generic<float><<<g, 256, 0, s>>>(p);
+  else k_conv_generic<__hip_bfloat16><<<g, 256, 0, s>>>(p);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream) {
+  if (!w_ref || !w_packed || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  k_pack_weight<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_packed, dtype);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_affine_relu(const void* in, int64_t in_ld, void* out, int64_t out_ld, int64_t n, int C, int dtype, const float* scale,
+                   const float* shift, int relu, tl_stream_t stream) {
+  if (!in || !out || n <= 0 || C <= 0 || (scale == nullptr) != (shift == nullptr)) return TL_ERR_ARG;
+  const unsigned g = tl_grid(n * C, 256);
+  if (dtype == TL_F32) k_affine_relu<float><<<g, 256, 0, tl_s(stream)>>>((const float*)in, in_ld, (float*)out, out_ld, n, C, scale, shift, relu);
+  else if (dtype == TL_BF16) k_affine_relu<__hip_bfloat16><<<g, 256, 0, tl_s(stream)>>>((const __hip_bfloat16*)in, in_ld, (__hip_bfloat16*)out, out_ld, n, C, scale, shift, relu);
+  else return TL_ERR_ARG;
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// Voxel hashing + rulebook construction for gfx950.
+//
+// Integer / bit work, HBM- and L2-bound: no MFMA here.  The tile's voxel grid is held as an
+// occupancy bitmap (z along the 64-bit word) plus an exclusive prefix sum of word popcounts;
+// rank(cell) = prefix[word] + popc(word & below(bit)) is the voxel row in ascending (b,x,y,z)
+// order.  For a 40x40 m tile at 0.1 m the bitmap is 6 MB and the prefix 3 MB: both stay in the
+// 256 MB Infinity Cache (mostly in the 4 MB/XCD L2), so the 27 probes per voxel of the
+// submanifold rulebook never touch HBM and need neither hashing nor sorting.
+#include "tl_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+__global__ void k_init_minmax(uint32_t* __restrict__ mm, int B, int32_t* __restrict__ maxc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 6) mm[i] = ((i % 6) < 3) ? 0xFFFFFFFFu : 0u;
+  if (i < 4) maxc[i] = 0;
+}
+
+// per-batch-element min / max of xyz  (tree_learn.py:134-135)
+__global__ void __launch_bounds__(kBlock) k_minmax(const float* __restrict__ xyz, const int64_t* __restrict__ bid,
+                                                   int64_t N, int B, uint32_t* __restrict__ mm) {
+  const int64_t nround = (N + 63) & ~(int64_t)63;            // whole waves iterate together
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = i < N;
+    int b = -1;
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    if (live) {
+      b = (int)bid[i];
+      for (int j = 0; j < 3; ++j) lo[j] = hi[j] = enc_f32(xyz[i * 3 + j]);
+    }
+    const int b0 = __shfl(b, 0);                               // lane 0 is live whenever any lane is
+    const bool uniform = __all(!live || b == b0) && b0 >= 0;
+    if (uniform) {
+      for (int j = 0; j < 3; ++j)
+        for (int off = 32; off > 0; off >>= 1) {
+          lo[j] = min(lo[j], (uint32_t)__shfl_xor((int)lo[j], off));
+          hi[j] = max(hi[j], (uint32_t)__shfl_xor((int)hi[j], off));
+        }
+      if ((threadIdx.x & 63) == 0 && b0 < B)
+        for (int j = 0; j < 3; ++j) { atomicMin(&mm[b0 * 6 + j], lo[j]); atomicMax(&mm[b0 * 6 + 3 + j], hi[j]); }
+    } else if (live && b >= 0 && b < B) {
+      for (int j = 0; j < 3; ++j) { atomicMin(&mm[b * 6 + j], lo[j]); atomicMax(&mm[b * 6 + 3 + j], hi[j]); }
+    }
+  }
+}
+
+// c = floorf((p - min_b) / vs) in fp32 (IEEE sub, IEEE div): spconv PointToVoxel arithmetic
+__global__ void __launch_bounds__(kBlock) k_point_coords(const float* __restrict__ xyz, const int64_t* __restrict__ bid,
+                                                         int64_t N, int B, float vs, const uint32_t* __restrict__ mm,
+                                                         int32_t* __restrict__ pc, int32_t* __restrict__ maxc) {
+  int mx[3] = {0, 0, 0};
+  int err = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)bid[i];
+    int c[3] = {0, 0, 0};
+    if (b < 0 || b >= B) {
+      err = 1;
+    } else {
+      for (int j = 0; j < 3; ++j) {
+        const float mn = dec_f32(mm[b * 6 + j]);
+        const float q = floorf(__fdiv_rn(__fsub_rn(xyz[i * 3 + j], mn), vs));
+        int v = (int)q;
+        if (!(q >= 0.f) || q >= 65536.f) { err = 1; v = 0; }
+        c[j] = v;
+        mx[j] = max(mx[j], v);
+      }
+    }
+    reinterpret_cast<int4*>(pc)[i] = make_int4(b, c[0], c[1], c[2]);
+  }
+  for (int j = 0; j < 3; ++j) {
+    for (int off = 32; off > 0; off >>= 1) mx[j] = max(mx[j], __shfl_xor(mx[j], off));
+  }
+  err = __any(err);
+  if ((threadIdx.x & 63) == 0) {
+    for (int j = 0; j < 3; ++j) atomicMax(&maxc[j], mx[j]);
+    if (err) atomicMax(&maxc[3], 1);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_set_bits(const int32_t* __restrict__ pc, int64_t N, TlDims d,
+                                                     unsigned long long* __restrict__ bm) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(pc)[i];
+    if (c.x < 0 || c.x >= d.B || c.y >= d.X || c.z >= d.Y || c.w >= d.Z) continue;
+    const int64_t w = tl_col_word(d, c.x, c.y, c.z) + (c.w >> 6);
+    const unsigned long long bit = 1ull << (c.w & 63);
+    // most tiles are de-duplicated upstream: test first to keep the atomic off the hot path when set
+    if (!(__hip_atomic_load(&bm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&bm[w], bit);
+  }
+}
+
+__device__ __forceinline__ uint64_t pair_or_compress(uint64_t w) {  // bit i of result = w[2i] | w[2i+1]
+  uint64_t t = (w | (w >> 1)) & 0x5555555555555555ull;
+  t = (t | (t >> 1)) & 0x3333333333333333ull;
+  t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full;
+  t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+  t = (t | (t >> 8)) & 0x0000ffff0000ffffull;
+  t = (t | (t >> 16)) & 0x00000000ffffffffull;
+  return t;
+}
+
+__global__ void __launch_bounds__(kBlock) k_bitmap_down(const uint64_t* __restrict__ fine, TlDims f, int ox, int oy, int oz,
+                                                        uint64_t* __restrict__ coarse, TlDims c) {
+  const int64_t n = tl_nwords(c);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int zw = (int)(i % c.Zw);
+    int64_t r = i / c.Zw;
+    const int y = (int)(r % c.Y); r /= c.Y;
+    const int x = (int)(r % c.X);
+    const int b = (int)(r / c.X);
+    uint64_t lo = 0, hi = 0;
+    if (x < ox && y < oy) {
+      for (int dx = 0; dx < 2; ++dx)
+        for (int dy = 0; dy < 2; ++dy) {
+          const int fx = 2 * x + dx, fy = 2 * y + dy;
+          if (fx >= f.X || fy >= f.Y) continue;
+          const int64_t wc = tl_col_word(f, b, fx, fy);
+          if (2 * zw < f.Zw) lo |= fine[wc + 2 * zw];
+          if (2 * zw + 1 < f.Zw) hi |= fine[wc + 2 * zw + 1];
+        }
+    }
+    uint64_t w = pair_or_compress(lo) | (pair_or_compress(hi) << 32);
+    const int z0 = zw * 64;                       // drop cells at or beyond out_shape.z
+    if (oz <= z0) w = 0;
+    else if (oz < z0 + 64) w &= (1ull << (oz - z0)) - 1;
+    coarse[i] = w;
+  }
+}
+
+// ---------------------------------------------------------------- popcount exclusive scan (3 passes)
+constexpr int kScanItems = 8;                       // words per thread
+constexpr int kScanTile = kBlock * kScanItems;      // words per block
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total_out) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < kBlock / 64; ++w) { if (w < wid) base += wsum[w]; tot += wsum[w]; }
+  __syncthreads();
+  *total_out = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_partials(const uint64_t* __restrict__ bm, int64_t n, uint32_t* __restrict__ part) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+  for (int j = 0; j < kScanItems; ++j) if (base + j < n) s += __popcll(bm[base + j]);
+  uint32_t tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_blocks(uint32_t* __restrict__ part, int64_t nb, uint32_t* __restrict__ total) {
+  uint32_t carry = 0;                               // single block walks the partials
+  for (int64_t base = 0; base < nb; base += kBlock) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? part[i] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan(v, &tot);
+    if (i < nb) part[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_final(const uint64_t* __restrict__ bm, int64_t n, const uint32_t* __restrict__ part,
+                                                       uint32_t* __restrict__ prefix) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t c[kScanItems];
+  uint32_t s = 0;
+  for (int j = 0; j < kScanItems; ++j) { c[j] = (base + j < n) ? __popcll(bm[base + j]) : 0; s += c[j]; }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot) + part[blockIdx.x];
+  for (int j = 0; j < kScanItems; ++j) { if (base + j < n) prefix[base + j] = ex; ex += c[j]; }
+}
+
+__global__ void __launch_bounds__(kBlock) k_expand_coords(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, TlDims d,
+                                                          int32_t* __restrict__ coords) {
+  const int64_t n = tl_nwords(d);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t w = bm[i];
+    if (!w) continue;
+    const int zw = (int)(i % d.Zw);
+    int64_t r = i / d.Zw;
+    const int y = (int)(r % d.Y); r /= d.Y;
+    const int x = (int)(r % d.X);
+    const int b = (int)(r / d.X);
+    int64_t row = pf[i];
+    while (w) {
+      const int bit = __ffsll((unsigned long long)w) - 1;
+      reinterpret_cast<int4*>(coords)[row++] = make_int4(b, x, y, zw * 64 + bit);
+      w &= w - 1;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_point_rank(const int32_t* __restrict__ pc, int64_t N, const uint64_t* __restrict__ bm,
+                                                       const uint32_t* __restrict__ pf, TlDims d, int64_t* __restrict__ v2p) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(pc)[i];
+    int r = -1;
+    if (c.x >= 0 && c.x < d.B && c.y < d.X && c.z < d.Y && c.w < d.Z) r = tl_rank_at(bm, pf, tl_col_word(d, c.x, c.y, c.z), c.w);
+    v2p[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------- rulebooks
+__global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restrict__ coords, int64_t M, const uint64_t* __restrict__ bm,
+                                                          const uint32_t* __restrict__ pf, TlDims d, int32_t* __restrict__ nbr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int x = c.y + dx, y = c.z + dy;
+        const int tap0 = (dx + 1) * 9 + (dy + 1) * 3;
+        int r0 = -1, r1 = -1, r2 = -1;
+        if (x >= 0 && x < d.X && y >= 0 && y < d.Y) {
+          const int64_t wc = tl_col_word(d, c.x, x, y);
+          const int z = c.w;
+          // one word + its prefix serve all three dz taps unless z sits on a word edge
+          const int64_t w = wc + (z >> 6);
+          const uint64_t word = bm[w];
+          const uint32_t base = pf[w];
+          const int bit = z & 63;
+          const uint64_t below = (1ull << bit) - 1;
+          if (word & (1ull << bit)) r1 = (int)(base + __popcll(word & below));
+          if (bit > 0) { if (word & (1ull << (bit - 1))) r0 = (int)(base + __popcll(word & (below >> 1))); }
+          else if (z > 0) r0 = tl_rank_at(bm, pf, wc, z - 1);
+          if (bit < 63) { if (word & (2ull << bit)) r2 = (int)(base + __popcll(word & ((below << 1) | 1ull))); }
+          else if (z + 1 < d.Z) r2 = tl_rank_at(bm, pf, wc, z + 1);
+        }
+        nbr[(int64_t)(tap0 + 0) * M + i] = r0;
+        nbr[(int64_t)(tap0 + 1) * M + i] = r1;
+        nbr[(int64_t)(tap0 + 2) * M + i] = r2;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
+                                                          const uint32_t* __restrict__ fpf, TlDims f, int64_t Mf,
+                                                          int32_t* __restrict__ child, int32_t* __restrict__ parent, int32_t* __restrict__ inv) {
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Mc; q += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(cc)[q];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int x = 2 * c.y + (k >> 2), y = 2 * c.z + ((k >> 1) & 1), z = 2 * c.w + (k & 1);
+      int r = -1;
+      if (x < f.X && y < f.Y && z < f.Z) r = tl_rank_at(fbm, fpf, tl_col_word(f, c.x, x, y), z);
+      child[(int64_t)k * Mc + q] = r;
+      if (r >= 0) { parent[r] = (int)q; inv[(int64_t)k * Mf + r] = (int)q; }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_tapmask(const int32_t* __restrict__ table, int K, int64_t n, uint32_t* __restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per row, 64 rows per wave
+  const int lane = threadIdx.x & 63;
+  uint32_t m = 0;
+  for (int k = 0; k < K; ++k) {
+    const bool v = (i < n) && table[(int64_t)k * n + i] >= 0;
+    const unsigned long long bal = __ballot(v);
+    const uint32_t half = (lane < 32) ? (uint32_t)bal : (uint32_t)(bal >> 32);
+    if (half) m |= 1u << k;
+  }
+  if ((lane & 31) == 0 && i < n) mask[i >> 5] = m;
+}
+
+// ---------------------------------------------------------------- optional voxel features (use_coords/use_feats)
+__global__ void __launch_bounds__(kBlock) k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_first_points(const int64_t* __restrict__ v2p, int64_t N, int P, int r, int32_t* __restrict__ sel) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = v2p[i];
+    if (v < 0) continue;
+    if (r > 0 && (int32_t)i <= sel[v * P + r - 1]) continue;   // already taken by an earlier rank
+    atomicMin(&sel[v * P + r], (int32_t)i);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_mean_feats(const float* __restrict__ pf, int C, int64_t M, int P, const int32_t* __restrict__ sel,
+                                                       float* __restrict__ out) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < M * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = t / C; const int c = (int)(t % C);
+    float s = 0.f; int n = 0;
+    for (int r = 0; r < P; ++r) {
+      const int32_t i = sel[v * P + r];
+      if (i == 0x7FFFFFFF) break;
+      bool allzero = true;                              // zero rows are padding (tree_learn.py:149-150)
+      for (int j = 0; j < C; ++j) allzero &= (pf[(int64_t)i * C + j] == 0.f);
+      if (allzero) continue;
+      s += pf[(int64_t)i * C + c]; ++n;
+    }
+    out[t] = n ? __fdiv_rn(s, (float)n) : __uint_as_float(0x7FC00000u);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tl_voxel_point_coords(const float* xyz, const int64_t* batch_ids, int64_t N, int B, float voxel_size,
+                          uint32_t* ws_minmax, int32_t* pcoords, int32_t* maxc, tl_stream_t stream) {
+  if (!xyz || !batch_ids || !ws_minmax || !pcoords || !maxc || N <= 0 || B <= 0 || !(voxel_size > 0.f)) return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  k_init_minmax<<<tl_cdiv(B * 6 > 4 ? B * 6 : 4, 64), 64, 0, s>>>(ws_minmax, B, maxc);
+  k_minmax<<<tl_grid(N, kBlock), kBlock, 0, s>>>(xyz, batch_ids, N, B, ws_minmax);
+  k_point_coords<<<tl_grid(N, kBlock), kBlock, 0, s>>>(xyz, batch_ids, N, B, voxel_size, ws_minmax, pcoords, maxc);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_bitmap_from_points(const int32_t* pcoords, int64_t N, const int32_t dims[4], uint64_t* bitmap, tl_stream_t stream) {
+  if (!pcoords || !dims || !bitmap || N <= 0) return TL_ERR_ARG;
+  const TlDims d = tl_dims(dims);
+  hipStream_t s = tl_s(stream);
+  if (hipMemsetAsync(bitmap, 0, tl_nwords(d) * 8, s) != hipSuccess) return TL_ERR_LAUNCH;
+  k_set_bits<<<tl_grid(N, kBlock), kBlock, 0, s>>>(pcoords, N, d, reinterpret_cast<unsigned long long*>(bitmap));
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_bitmap_down(const uint64_t* fine, const int32_t fdims[4], const int32_t out_shape[3], uint64_t* coarse,
+                   const int32_t cdims[4], tl_stream_t stream) {
+  if (!fine || !fdims || !out_shape || !coarse || !cdims) return TL_ERR_ARG;
+  const TlDims f = tl_dims(fdims), c = tl_dims(cdims);
+  if (c.B != f.B || c.X != (f.X + 1) / 2 || c.Y != (f.Y + 1) / 2 || c.Z != (f.Z + 1) / 2) return TL_ERR_ARG;
+  k_bitmap_down<<<tl_grid(tl_nwords(c), kBlock), kBlock, 0, tl_s(stream)>>>(fine, f, out_shape[0], out_shape[1], out_shape[2], coarse, c);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int64_t tl_scan_ws_words(int64_t nwords) { return tl_cdiv(nwords, kScanTile) + 1; }
+
+int tl_bitmap_scan(const uint64_t* bitmap, int64_t nwords, uint32_t* prefix, uint32_t* total, uint32_t* ws, tl_stream_t stream) {
+  if (!bitmap || !prefix || !total || !ws || nwords <= 0) return TL_ERR_ARG;
+  const int64_t nb = tl_cdiv(nwords, kScanTile);
+  hipStream_t s = tl_s(stream);
+  k_scan_partials<<<(unsigned)nb, kBlock, 0, s>>>(bitmap, nwords, ws);
+  k_scan_blocks<<<1, kBlock, 0, s>>>(ws, nb, total);
+  k_scan_final<<<(unsigned)nb, kBlock, 0, s>>>(bitmap, nwords, ws, prefix);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_expand_coords(const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4], int32_t* coords, tl_stream_t stream) {
+  if (!bitmap || !prefix || !dims || !coords) return TL_ERR_ARG;
+  const TlDims d = tl_dims(dims);
+  k_expand_coords<<<tl_grid(tl_nwords(d), kBlock), kBlock, 0, tl_s(stream)>>>(bitmap, prefix, d, coords);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_point_rank(const int32_t* pcoords, int64_t N, const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4],
+                  int64_t* v2p, tl_stream_t stream) {
+  if (!pcoords || !bitmap || !prefix || !dims || !v2p || N <= 0) return TL_ERR_ARG;
+  k_point_rank<<<tl_grid(N, kBlock), kBlock, 0, tl_s(stream)>>>(pcoords, N, bitmap, prefix, tl_dims(dims), v2p);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_voxel_mean_feats(const float* pf, int C, const int64_t* v2p, int64_t N, int64_t M, int P, int32_t* ws, float* out,
+                        tl_stream_t stream) {
+  if (!pf || !v2p || !ws || !out || C <= 0 || C > 64 || N <= 0 || M <= 0 || P <= 0 || N > 0x7FFFFFFE) return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  k_fill_i32<<<tl_grid(M * P, kBlock), kBlock, 0, s>>>(ws, M * P, 0x7FFFFFFF);
+  for (int r = 0; r < P; ++r) k_first_points<<<tl_grid(N, kBlock), kBlock, 0, s>>>(v2p, N, P, r, ws);
+  k_mean_feats<<<tl_grid(M * C, kBlock), kBlock, 0, s>>>(pf, C, M, P, ws, out);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_rulebook_subm(const int32_t* coords, int64_t M, const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4],
+                     int32_t* nbr, tl_stream_t stream) {
+  if (!coords || !bitmap || !prefix || !dims || !nbr || M <= 0) return TL_ERR_ARG;
+  k_rulebook_subm<<<tl_grid(M, kBlock), kBlock, 0, tl_s(stream)>>>(coords, M, bitmap, prefix, tl_dims(dims), nbr);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap, const uint32_t* fprefix, const int32_t fdims[4],
+                     int64_t Mf, int32_t* child, int32_t* parent, int32_t* inv, tl_stream_t stream) {
+  if (!ccoords || !fbitmap || !fprefix || !fdims || !child || !parent || !inv || Mc <= 0 || Mf <= 0) return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  if (hipMemsetAsync(parent, 0xFF, Mf * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
+  if (hipMemsetAsync(inv, 0xFF, Mf * 8 * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
+  k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_table_tapmask(const int32_t* table, int K, int64_t n_out, uint32_t* tapmask, tl_stream_t stream) {
+  if (!table || !tapmask || K <= 0 || K > 32 || n_out <= 0) return TL_ERR_ARG;
+  k_tapmask<<<(unsigned)tl_cdiv(n_out, kBlock), kBlock, 0, tl_s(stream)>>>(table, K, n_out, tapmask);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+"""Tile geometry: voxel hashing + every rulebook of the U-Net, built on the GPU by the HIP library.
+
+Host-side orchestration of include/treelearn_hip.h's voxel/rulebook entry points.  Replaces, for one
+batch of tiles, the PointToVoxel call and `.tolist()` syncs of `voxelize`
+(reference tree_learn/model/tree_learn.py:129-167) and spconv's lazy per-`indice_key` indice
+generation (`subm1..7`, `spconv1..6`; blocks.py:57-70,104-123).  Two host syncs per batch in total:
+the grid extent (3 ints) and the per-level voxel counts (L ints).
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _hip
+
+
+@dataclass
+class Level:
+    n: int                      # active voxels
+    dims: tuple                 # bitmap grid (B, X, Y, Z)
+    shape: tuple                # spconv spatial_shape at this level (drives the out-of-range drop)
+    bitmap: torch.Tensor        # u64 words (int64 storage)
+    prefix: torch.Tensor        # u32 (int32 storage)
+    coords: torch.Tensor = None     # i32[n,4] (b,x,y,z), ascending key
+    nbr: torch.Tensor = None        # i32[27,n]   subm{l}
+    child: torch.Tensor = None      # i32[8,n_next]  spconv{l} (down)
+    parent: torch.Tensor = None     # i32[n]
+    inv: torch.Tensor = None        # i32[8,n]    spconv{l} (inverse)
+
+
+@dataclass
+class TileGeometry:
+    levels: List[Level]
+    v2p: torch.Tensor            # i64[N]
+    n_points: int
+    batch_size: int
+    pcoords: torch.Tensor = None
+
+
+def _nwords(d):
+    return d[0] * d[1] * d[2] * ((d[3] + 63) // 64)
+
+
+def level_shapes(shape1, num_levels):
+    """spatial_shape per level: shape_{l+1} = shape_l // 2; raises the reference's skip-tile error
+    (util/pipeline.py:91-97 looks for "reach zero!!!") when a dim collapses."""
+    shapes = [tuple(int(s) for s in shape1)]
+    for _ in range(num_levels - 1):
+        nxt = tuple(s // 2 for s in shapes[-1])
+        if min(nxt) <= 0:
+            raise ValueError(f"sparse conv output spatial shape {list(nxt)} reach zero!!! (input shape {list(shapes[-1])})")
+        shapes.append(nxt)
+    return shapes
+
+
+def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: int, voxel_size: float,
+                   num_levels: int, spatial_shape: Optional[List[int]] = None, need_inverse: bool = True) -> TileGeometry:
+    L = _hip.lib()
+    st = _hip.stream()
+    _hip.require_cuda(coords, "coords"); _hip.require_cuda(batch_ids, "batch_ids")
+    if coords.dtype != torch.float32 or batch_ids.dtype != torch.int64:
+        raise TypeError("coords must be float32 [N,3] and batch_ids int64 [N]")
+    N = coords.shape[0]
+    dev = coords.device
+    if N == 0:
+        raise ValueError("empty tile")
+
+    # 1. per-point voxel coordinates (fp32 floor((p - min_b)/vs)) + grid extent
+    pcoords = torch.empty((N, 4), dtype=torch.int32, device=dev)
+    maxc = torch.empty(4, dtype=torch.int32, device=dev)
+    ws_mm = torch.empty(batch_size * 6, dtype=torch.int32, device=dev)
+    _hip.check(L.tl_voxel_point_coords(_hip.ptr(coords), _hip.ptr(batch_ids), N, batch_size, float(voxel_size),
+                                       _hip.ptr(ws_mm), _hip.ptr(pcoords), _hip.ptr(maxc), st), "tl_voxel_point_coords")
+    mx = maxc.tolist()                                     # host sync #1
+    if mx[3]:
+        raise ValueError("voxelize: batch id out of range or voxel coordinate outside [0, 65536)")
+    extent = (mx[0] + 1, mx[1] + 1, mx[2] + 1)
+    shape1 = tuple(spatial_shape) if spatial_shape is not None else extent      # tree_learn.py:86-87,165
+    if any(e > s for e, s in zip(extent, shape1)):
+        raise ValueError(f"tile extent {extent} voxels exceeds spatial_shape {shape1}")
+    shapes = level_shapes(shape1, num_levels)
+
+    # 2. occupancy bitmaps + popcount prefix sums for every level (no host involvement)
+    dims = [(batch_size,) + extent]
+    for _ in range(num_levels - 1):
+        d = dims[-1]
+        dims.append((d[0], (d[1] + 1) // 2, (d[2] + 1) // 2, (d[3] + 1) // 2))
+    nw = [_nwords(d) for d in dims]
+    bm_all = torch.empty(sum(nw), dtype=torch.int64, device=dev)
+    pf_all = torch.empty(sum(nw), dtype=torch.int32, device=dev)
+    counts = torch.empty(num_levels, dtype=torch.int32, device=dev)
+    scan_ws = torch.empty(int(L.tl_scan_ws_words(max(nw))), dtype=torch.int32, device=dev)
+    levels = []
+    off = 0
+    for li in range(num_levels):
+        bm = bm_all[off:off + nw[li]]; pf = pf_all[off:off + nw[li]]; off += nw[li]
+        if li == 0:
+            _hip.check(L.tl_bitmap_from_points(_hip.ptr(pcoords), N, _hip.dims4(dims[0]), _hip.ptr(bm), st), "tl_bitmap_from_points")
+        else:
+            _hip.check(L.tl_bitmap_down(_hip.ptr(levels[-1].bitmap), _hip.dims4(dims[li - 1]), _hip.dims3(shapes[li]),
+                                        _hip.ptr(bm), _hip.dims4(dims[li]), st), "tl_bitmap_down")
+        _hip.check(L.tl_bitmap_scan(_hip.ptr(bm), nw[li], _hip.ptr(pf), _hip.ptr(counts[li:li + 1]), _hip.ptr(scan_ws), st), "tl_bitmap_scan")
+        levels.append(Level(n=0, dims=dims[li], shape=shapes[li], bitmap=bm, prefix=pf))
+    ns = counts.tolist()                                   # host sync #2
+    for lv, n in zip(levels, ns):
+        lv.n = int(n)
+        if lv.n <= 0:
+            raise ValueError("sparse conv produced an empty level: output spatial shape reach zero!!!")
+
+    # 3. coords, v2p, rulebooks
+    for li, lv in enumerate(levels):
+        lv.coords = torch.empty((lv.n, 4), dtype=torch.int32, device=dev)
+        _hip.check(L.tl_expand_coords(_hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims), _hip.ptr(lv.coords), st), "tl_expand_coords")
+        lv.nbr = torch.empty((27, lv.n), dtype=torch.int32, device=dev)
+        _hip.check(L.tl_rulebook_subm(_hip.ptr(lv.coords), lv.n, _hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims),
+                                      _hip.ptr(lv.nbr), st), "tl_rulebook_subm")
+    for li in range(num_levels - 1):
+        f, c = levels[li], levels[li + 1]
+        f.child = torch.empty((8, c.n), dtype=torch.int32, device=dev)
+        f.parent = torch.empty(f.n, dtype=torch.int32, device=dev)
+        f.inv = torch.empty((8, f.n), dtype=torch.int32, device=dev)
+        _hip.check(L.tl_rulebook_down(_hip.ptr(c.coords), c.n, _hip.ptr(f.bitmap), _hip.ptr(f.prefix), _hip.dims4(f.dims), f.n,
+                                      _hip.ptr(f.child), _hip.ptr(f.parent), _hip.ptr(f.inv), st), "tl_rulebook_down")
+    v2p = torch.empty(N, dtype=torch.int64, device=dev)
+    _hip.check(L.tl_point_rank(_hip.ptr(pcoords), N, _hip.ptr(levels[0].bitmap), _hip.ptr(levels[0].prefix), _hip.dims4(levels[0].dims),
+                               _hip.ptr(v2p), st), "tl_point_rank")
+    return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords)
+
+
+def voxel_mean_feats(point_feats: torch.Tensor, geom: TileGeometry, max_points: int) -> torch.Tensor:
+    """Mean of the first <= P points per voxel in input order (tree_learn.py:149-151); [M,C] in the
+    (x,y,z,feat..) column order of `point_feats`."""
+    L = _hip.lib()
+    _hip.require_cuda(point_feats, "point_feats")
+    M = geom.levels[0].n
+    C = point_feats.shape[1]
+    ws = torch.empty(M * max_points, dtype=torch.int32, device=point_feats.device)
+    out = torch.empty((M, C), dtype=torch.float32, device=point_feats.device)
+    _hip.check(L.tl_voxel_mean_feats(_hip.ptr(point_feats), C, _hip.ptr(geom.v2p), geom.n_points, M, max_points,
+                                     _hip.ptr(ws), _hip.ptr(out), _hip.stream()), "tl_voxel_mean_feats")
+    return out

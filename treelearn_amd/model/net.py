@@ -1,0 +1,139 @@
+"""TreeLearn -- the drop-in for reference `tree_learn.model.TreeLearn` (tree_learn/model/tree_learn.py).
+
+Same constructor keywords (tree_learn.py:12-24), same `forward(batch, return_loss)` contract
+(:75-81), same 414 state-dict keys, same `train()` handling of
+`fixed_modules` (:66-72), same "reach zero!!!" failure mode for collapsing tiles.  The device work is
+done by libtreelearn_hip.so: voxel hashing + rulebooks (treelearn_amd.geometry), fused sparse convs
+and heads (treelearn_amd.model.engine) -- no spconv, no CPU fallback.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+
+from .. import geometry as G
+from .. import spconv_compat as spconv
+from ..util.train import cuda_cast, point_wise_loss
+from .engine import InferencePlan
+from .unet import MLP, ResidualBlock, UBlock
+
+LOSS_MULTIPLIER_SEMANTIC = 50          # tree_learn.py:9
+
+
+class TreeLearn(nn.Module):
+    def __init__(self, channels=32, num_blocks=7, kernel_size=3, dim_coord=3, dim_feat=1, fixed_modules=[],
+                 use_feats=True, use_coords=False, spatial_shape=None, max_num_points_per_voxel=3, voxel_size=0.1,
+                 compute_dtype=torch.float32, **kwargs):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.fixed_modules = fixed_modules
+        self.use_feats = use_feats
+        self.use_coords = use_coords
+        self.spatial_shape = spatial_shape
+        self.max_num_points_per_voxel = max_num_points_per_voxel
+        self.num_blocks = num_blocks
+        self.compute_dtype = compute_dtype          # torch.float32 (parity) | torch.bfloat16 (throughput)
+        self.return_backbone_feats = True           # reference always returns them (tree_learn.py:100)
+        self._plan = None
+
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        self.input_conv = spconv.SparseSequential(
+            spconv.SubMConv3d(dim_coord + dim_feat, channels, kernel_size=kernel_size, padding=1, bias=False, indice_key='subm1'))
+        self.unet = UBlock([channels * (i + 1) for i in range(num_blocks)], norm_fn, 2, ResidualBlock, kernel_size, indice_key_id=1)
+        self.output_layer = spconv.SparseSequential(norm_fn(channels), nn.ReLU())
+        self.semantic_linear = MLP(channels, 2, norm_fn=norm_fn, num_layers=2)
+        self.offset_linear = MLP(channels, 3, norm_fn=norm_fn, num_layers=2)
+        self.init_weights()
+        for name in fixed_modules:
+            for param in getattr(self, name).parameters():
+                param.requires_grad = False
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plan())
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, MLP):
+                m.init_weights()
+
+    def invalidate_plan(self):
+        """Drop the folded-BN / packed-weight cache (call after mutating parameters in place)."""
+        self._plan = None
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._plan = None
+        for name in self.fixed_modules:
+            for m in getattr(self, name).modules():
+                if isinstance(m, nn.BatchNorm1d):
+                    m.eval()
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch, return_loss):
+        backbone_output, v2p_map = self.forward_backbone(**batch)
+        output = self.forward_head(backbone_output, v2p_map)
+        if return_loss:
+            output = self.get_loss(model_output=output, **batch)
+        return output
+
+    def _voxelize(self, coords, input_feats, batch_ids, batch_size):
+        """`voxelize` of tree_learn.py:129-167 on the HIP library: geometry + voxel features
+        ([M, dim_feat+dim_coord] in (feat, x, y, z) order; ones unless use_feats/use_coords)."""
+        geom = G.build_geometry(coords.contiguous(), batch_ids.contiguous(), int(batch_size), self.voxel_size,
+                                self.num_blocks, self.spatial_shape)
+        M = geom.levels[0].n
+        C = coords.shape[1] + input_feats.shape[1]
+        if self.use_coords or self.use_feats:
+            pf = torch.hstack([coords, input_feats]).contiguous()
+            mean = G.voxel_mean_feats(pf, geom, self.max_num_points_per_voxel)
+            if not self.use_coords:
+                mean[:, :3] = 1.0
+            if not self.use_feats:
+                mean[:, 3:] = 1.0
+            vfeats = torch.hstack([mean[:, 3:], mean[:, :3]]).contiguous()
+        else:
+            vfeats = torch.ones((M, C), dtype=torch.float32, device=coords.device)
+        return vfeats, geom
+
+    @cuda_cast
+    def forward_backbone(self, coords, input_feats, batch_ids, batch_size, **kwargs):
+        vfeats, geom = self._voxelize(coords.float(), input_feats.float(), batch_ids.long(), batch_size)
+        if self.training or torch.is_grad_enabled():
+            # module-by-module path (batch-statistics BatchNorm, autograd through the HIP convs)
+            lv = geom.levels[0]
+            x = spconv.SparseConvTensor(vfeats, lv.coords, list(lv.shape), batch_size, geometry=geom, level=0)
+            x = self.output_layer(self.unet(self.input_conv(x)))
+            return x, geom.v2p
+        if self._plan is None or self._plan.dtype != self.compute_dtype:
+            self._plan = InferencePlan(self, self.compute_dtype)
+        return (vfeats, geom), geom.v2p
+
+    def forward_head(self, backbone_output, v2p_map):
+        output = dict()
+        if isinstance(backbone_output, tuple):                       # fused inference path
+            vfeats, geom = backbone_output
+            bb, logits, offsets = self._plan.run(vfeats, geom, want_backbone=self.return_backbone_feats)
+            output['backbone_feats'] = bb
+            output['semantic_prediction_logits'] = logits
+            output['offset_predictions'] = offsets
+            return output
+        backbone_feats = backbone_output.features[v2p_map]
+        output['backbone_feats'] = backbone_feats
+        output['semantic_prediction_logits'] = self.semantic_linear(backbone_feats)
+        output['offset_predictions'] = self.offset_linear(backbone_feats)
+        return output
+
+    @cuda_cast
+    def get_loss(self, model_output, semantic_labels, offset_labels, masks_off, masks_sem, **kwargs):
+        semantic_loss, offset_loss = point_wise_loss(
+            model_output['semantic_prediction_logits'].float(), model_output['offset_predictions'].float(),
+            masks_sem, masks_off, semantic_labels, offset_labels)
+        loss_dict = dict(semantic_loss=semantic_loss * LOSS_MULTIPLIER_SEMANTIC, offset_loss=offset_loss)
+        loss = sum(v for v in loss_dict.values())
+        return loss, loss_dict

@@ -1,0 +1,96 @@
+"""Building blocks of the sparse U-Net -- same module tree (names, parameter shapes) as reference
+tree_learn/model/blocks.py, expressed over treelearn_amd.spconv_compat instead of spconv.
+
+  MLP              blocks.py:8-26      Custom1x1Subm3d  blocks.py:29-39
+  ResidualBlock    blocks.py:42-79     UBlock           blocks.py:81-149
+The module-by-module `forward`s below are the unfused path (used for training and as a cross-check);
+inference goes through treelearn_amd.model.engine, which walks the same modules and issues fused
+HIP calls.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import spconv_compat as spconv
+from ..spconv_compat import SparseModule
+
+
+class MLP(nn.Sequential):
+    def __init__(self, in_channels, out_channels, norm_fn=None, num_layers=2):
+        modules = []
+        for _ in range(num_layers - 1):
+            modules.append(nn.Linear(in_channels, in_channels))
+            if norm_fn:
+                modules.append(norm_fn(in_channels))
+            modules.append(nn.ReLU())
+        modules.append(nn.Linear(in_channels, out_channels))
+        super().__init__(*modules)
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self[-1].weight, 0, 0.01)
+        nn.init.constant_(self[-1].bias, 0)
+
+
+class Custom1x1Subm3d(spconv.SparseConv3d):
+    """1x1 'conv' = dense GEMM on the feature matrix (blocks.py:29-39)."""
+    def forward(self, input):
+        from ..autograd import sparse_conv
+        feats = sparse_conv(input.features, self.weight, None, input.features.shape[0])
+        if self.bias is not None:
+            feats = feats + self.bias
+        return input.replace_feature(feats)
+
+
+class ResidualBlock(SparseModule):
+    def __init__(self, in_channels, out_channels, norm_fn, kernel_size, indice_key=None):
+        super().__init__()
+        if in_channels == out_channels:
+            self.i_branch = spconv.SparseSequential(nn.Identity())
+        else:
+            self.i_branch = spconv.SparseSequential(Custom1x1Subm3d(in_channels, out_channels, kernel_size=1, bias=False))
+        pad = int((kernel_size - 1) / 2)
+        self.conv_branch = spconv.SparseSequential(
+            norm_fn(in_channels), nn.ReLU(),
+            spconv.SubMConv3d(in_channels, out_channels, kernel_size=int(kernel_size), padding=pad, bias=False, indice_key=indice_key),
+            norm_fn(out_channels), nn.ReLU(),
+            spconv.SubMConv3d(out_channels, out_channels, kernel_size=int(kernel_size), padding=pad, bias=False, indice_key=indice_key))
+
+    def forward(self, input):
+        identity = input.replace_feature(input.features)
+        output = self.conv_branch(input)
+        return output.replace_feature(output.features + self.i_branch(identity).features)
+
+
+class UBlock(nn.Module):
+    def __init__(self, nPlanes, norm_fn, block_reps, block, kernel_size, indice_key_id=1):
+        super().__init__()
+        self.nPlanes = nPlanes
+        key = 'subm{}'.format(indice_key_id)
+        self.blocks = spconv.SparseSequential(OrderedDict(
+            ('block{}'.format(i), block(nPlanes[0], nPlanes[0], norm_fn, kernel_size, indice_key=key)) for i in range(block_reps)))
+        if len(nPlanes) > 1:
+            skey = 'spconv{}'.format(indice_key_id)
+            self.conv = spconv.SparseSequential(
+                norm_fn(nPlanes[0]), nn.ReLU(),
+                spconv.SparseConv3d(nPlanes[0], nPlanes[1], kernel_size=2, stride=2, bias=False, indice_key=skey))
+            self.u = UBlock(nPlanes[1:], norm_fn, block_reps, block, kernel_size, indice_key_id=indice_key_id + 1)
+            self.deconv = spconv.SparseSequential(
+                norm_fn(nPlanes[1]), nn.ReLU(),
+                spconv.SparseInverseConv3d(nPlanes[1], nPlanes[0], kernel_size=2, bias=False, indice_key=skey))
+            self.blocks_tail = spconv.SparseSequential(OrderedDict(
+                ('block{}'.format(i), block(nPlanes[0] * (2 - i), nPlanes[0], norm_fn, kernel_size, indice_key=key))
+                for i in range(block_reps)))
+
+    def forward(self, input):
+        output = self.blocks(input)
+        identity = output.replace_feature(output.features)
+        if len(self.nPlanes) > 1:
+            dec = self.deconv(self.u(self.conv(output)))
+            output = output.replace_feature(torch.cat((identity.features, dec.features), dim=1))
+            output = self.blocks_tail(output)
+        return output

@@ -1,0 +1,82 @@
+"""Thin host wrappers over the HIP operators (tl_conv_fwd, tl_head_mlp, ...)."""
+import ctypes
+
+import torch
+
+from . import _hip
+
+
+def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Reference conv weight [Cout,k,k,k,Cin] (spconv layout) -> kernel layout [K,Cout,Cin] in `dtype`."""
+    L = _hip.lib()
+    w = w_ref.detach().contiguous().float()
+    _hip.require_cuda(w, "weight")
+    co, ci = w.shape[0], w.shape[-1]
+    K = w.numel() // (co * ci)
+    out = torch.empty((K, co, ci), dtype=dtype, device=w.device)
+    _hip.check(L.tl_pack_weight(_hip.ptr(w), co, K, ci, _hip.ptr(out), _hip.dtype_code(dtype), _hip.stream()), "tl_pack_weight")
+    return out
+
+
+def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
+             in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False):
+    """out[o] = epi(sum_k W[k] . pro(x[table[k][o]])); x / out / residual may be column views of wider
+    row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused."""
+    L = _hip.lib()
+    K, Cout, Cin = w_packed.shape
+    if x.stride(1) != 1 or x.shape[1] != Cin:
+        raise ValueError("bad input view")
+    if out is None:
+        out = torch.empty((n_out, Cout), dtype=x.dtype, device=x.device)
+    if out.stride(1) != 1 or out.shape[1] != Cout or out.shape[0] != n_out:
+        raise ValueError("bad output view")
+    if w_packed.dtype != x.dtype or out.dtype != x.dtype:
+        raise ValueError("dtype mismatch")
+    a = _hip.ConvArgs()
+    a.in_ = x.data_ptr(); a.in_ld = x.stride(0)
+    a.weight = w_packed.data_ptr()
+    a.table = table.data_ptr() if table is not None else None
+    a.tapmask = None
+    a.n_out = n_out; a.n_in = x.shape[0]
+    a.K = K; a.Cin = Cin; a.Cout = Cout; a.dtype = _hip.dtype_code(x.dtype)
+    a.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    a.in_shift = in_shift.data_ptr() if in_shift is not None else None
+    a.in_relu = int(bool(in_relu)); a.out_relu = int(bool(out_relu))
+    if residual is not None:
+        if residual.dtype != x.dtype or residual.stride(1) != 1:
+            raise ValueError("bad residual view")
+        a.residual = residual.data_ptr(); a.res_ld = residual.stride(0)
+    else:
+        a.residual = None; a.res_ld = 0
+    a.out_scale = out_scale.data_ptr() if out_scale is not None else None
+    a.out_shift = out_shift.data_ptr() if out_shift is not None else None
+    a.out = out.data_ptr(); a.out_ld = out.stride(0)
+    a.stats = None
+    _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
+    return out
+
+
+def head_mlp(feats, v2p, pro_scale, pro_shift, w1, b1, w2, b2, want_backbone=True):
+    L = _hip.lib()
+    N = v2p.shape[0]
+    C = feats.shape[1]
+    dev = feats.device
+    backbone = torch.empty((N, C), dtype=torch.float32, device=dev) if want_backbone else None
+    logits = torch.empty((N, 2), dtype=torch.float32, device=dev)
+    offsets = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    _hip.check(L.tl_head_mlp(_hip.ptr(feats), feats.stride(0), _hip.dtype_code(feats.dtype), C, _hip.ptr(v2p), N,
+                             _hip.ptr(pro_scale), _hip.ptr(pro_shift), _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(w2), _hip.ptr(b2),
+                             _hip.ptr(backbone), _hip.ptr(logits), _hip.ptr(offsets), _hip.stream()), "tl_head_mlp")
+    return backbone, logits, offsets
+
+
+def compact_rows(x: torch.Tensor, mask: torch.Tensor):
+    """x[mask] on the device without a boolean-index sync storm: returns (buffer [n,C], count tensor)."""
+    L = _hip.lib()
+    n, C = x.shape
+    m8 = mask.to(torch.uint8).contiguous()
+    out = torch.empty_like(x)
+    count = torch.empty(1, dtype=torch.int32, device=x.device)
+    ws = torch.empty(int(L.tl_compact_ws_words(n)), dtype=torch.int32, device=x.device)
+    _hip.check(L.tl_compact_rows(_hip.ptr(x), C, _hip.ptr(m8), n, _hip.ptr(out), _hip.ptr(count), _hip.ptr(ws), _hip.stream()), "tl_compact_rows")
+    return out, count

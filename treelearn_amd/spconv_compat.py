@@ -1,0 +1,144 @@
+"""The slice of the `spconv.pytorch` API that the reference model consumes, on the HIP library.
+
+Lower surface of the drop-in boundary: `SparseConvTensor`, `SparseModule`,
+`SparseSequential`, `SubMConv3d`, `SparseConv3d`, `SparseInverseConv3d` -- same constructor
+arguments, attribute names and `.weight` layout [Cout, k, k, k, Cin] as spconv v2, so that
+reference tree_learn/model/blocks.py and tree_learn.py:37-42 build an identical module tree
+(identical state-dict keys) on top of it.
+
+A SparseConvTensor here always carries a `TileGeometry` (treelearn_amd.geometry): the rulebooks of
+every `indice_key` are built once per batch by the HIP voxel/rulebook kernels, which is what spconv's
+`indice_dict` cache amounts to.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, geometry=None, level=0):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = spatial_shape
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self.grid = None
+        self.geometry = geometry
+        self.level = level
+
+    def replace_feature(self, feature):
+        t = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size, self.geometry, self.level)
+        t.indice_dict = self.indice_dict
+        t.grid = self.grid
+        return t
+
+
+class SparseModule(nn.Module):
+    """marker base class (spconv.pytorch.modules.SparseModule)"""
+
+
+class SparseSequential(SparseModule):
+    def __init__(self, *args):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def forward(self, x):
+        for module in self._modules.values():
+            if isinstance(module, SparseModule):
+                x = module(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.features.shape[0] != 0:
+                    x = x.replace_feature(module(x.features))
+            else:
+                x = module(x)
+        return x
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, subm=False, inverse=False):
+        super().__init__()
+        assert dilation == 1 and groups == 1
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.indice_key, self.subm, self.inverse = indice_key, subm, inverse
+        k = int(kernel_size)
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # spconv default: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)), fan_in = Cin * k^3
+        fan_in = self.in_channels * int(self.kernel_size) ** 3
+        bound = 1.0 / math.sqrt(fan_in)
+        nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _table(self, x):
+        raise NotImplementedError
+
+    def forward(self, x):
+        from .autograd import sparse_conv                  # late import (autograd depends on ops)
+        table, n_out, out_level = self._table(x)
+        feats = sparse_conv(x.features, self.weight, table, n_out)
+        if self.bias is not None:
+            feats = feats + self.bias
+        lv = x.geometry.levels[out_level]
+        out = SparseConvTensor(feats, lv.coords, list(lv.shape), x.batch_size, x.geometry, out_level)
+        out.indice_dict = x.indice_dict
+        out.grid = x.grid
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, indice_key, subm=True)
+
+    def _table(self, x):
+        lv = x.geometry.levels[x.level]
+        if int(self.kernel_size) == 1:
+            return None, lv.n, x.level
+        assert int(self.kernel_size) == 3, "rulebooks are built for kernel_size 3 (reference configs/_modular/model.yaml:2)"
+        return lv.nbr, lv.n, x.level
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, indice_key)
+
+    def _table(self, x):
+        if int(self.kernel_size) == 1 and int(self.stride) == 1:
+            return None, x.geometry.levels[x.level].n, x.level
+        assert int(self.kernel_size) == 2 and int(self.stride) == 2
+        lv = x.geometry.levels[x.level]
+        if lv.child is None:
+            raise ValueError("geometry was built with too few levels for this SparseConv3d")
+        return lv.child, x.geometry.levels[x.level + 1].n, x.level + 1
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, bias=bias, indice_key=indice_key, inverse=True)
+
+    def _table(self, x):
+        assert int(self.kernel_size) == 2 and x.level > 0
+        lv = x.geometry.levels[x.level - 1]
+        return lv.inv, lv.n, x.level - 1

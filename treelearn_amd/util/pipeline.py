@@ -1,0 +1,88 @@
+"""Tile loop and instance grouping -- mirrors reference tree_learn/util/pipeline.py
+(`get_pointwise_preds` :79-109, `get_instances` :145-169, `group_dbscan` :173-180,
+`make_labels_consecutive` :195-206) with the device work on the HIP library."""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True):
+    """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one small D2H
+    instead of the reference's three full-tile `.cpu()` copies), `coords += centers`, and skip tiles
+    whose forward raises "... reach zero!!! ..." (pipeline.py:91-97)."""
+    outs = [[] for _ in range(8)]
+    with torch.no_grad():
+        model.eval()
+        for batch in dataloader:
+            batch['voxel_size'] = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
+            try:
+                output = model(batch, return_loss=False)
+            except Exception as e:                                     # noqa: BLE001
+                if "reach zero!!!" in str(e):
+                    if logger:
+                        logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
+                                    'If this does not happen too often, the results should not be influenced.')
+                    continue
+                raise
+            m = batch['masks_inner']
+            m_dev = m.to(output['offset_predictions'].device, non_blocking=True)
+            off = output['offset_predictions'][m_dev].cpu()
+            sem = output['semantic_prediction_logits'][m_dev].cpu()
+            bb = output['backbone_feats']
+            bb = bb[m_dev].cpu() if bb is not None else torch.zeros((int(m.sum()), 0))
+            coords = batch['coords'] + batch['centers']
+            outs[0].append(sem); outs[1].append(batch['semantic_labels'][m])
+            outs[2].append(off); outs[3].append(batch['offset_labels'][m])
+            outs[4].append(coords[m]); outs[5].append(batch['instance_labels'][m])
+            outs[6].append(bb); outs[7].append(batch['input_feats'][m])
+    return tuple(torch.cat(o, 0).numpy() for o in outs)
+
+
+def make_labels_consecutive(labels, start_num):
+    """Relabel to start_num.. in ascending order of the original labels; also the new->old map."""
+    palette = np.unique(labels)
+    new = np.searchsorted(palette, labels) + start_num
+    return new, {i + start_num: orig for i, orig in enumerate(palette)}
+
+
+def _filter_small(labels, npoint_thr, not_assigned, start_num):
+    nums, counts = np.unique(labels, return_counts=True)
+    valid = nums[(counts >= npoint_thr) & (nums != -1)]
+    ok = np.isin(labels, valid)
+    out = np.full(len(labels), not_assigned, dtype=np.int64)
+    if ok.any():
+        out[ok], _ = make_labels_consecutive(labels[ok], start_num)
+    return out
+
+
+def group_dbscan(cluster_coords, radius, npoint_thr, not_assigned_label_in_grouping, start_num_preds):
+    """DBSCAN(eps=radius, min_samples=2) == connected components of the eps-graph; on the GPU."""
+    from ..cluster import dbscan_min2
+    labels = dbscan_min2(cluster_coords, radius)
+    return _filter_small(labels, npoint_thr, not_assigned_label_in_grouping, start_num_preds)
+
+
+def group_hdbscan(cluster_coords, npoint_thr, not_assigned_label_in_grouping, start_num_preds):
+    from ..cluster import hdbscan
+    labels = hdbscan(cluster_coords, npoint_thr)
+    return _filter_small(labels, npoint_thr, not_assigned_label_in_grouping, start_num_preds)
+
+
+def get_instances(coords, offset, semantic_prediction_logits, grouping_cfg, verticality_feat, tree_class_in_dataset,
+                  non_trees_label_in_grouping, not_assigned_label_in_grouping, start_num_preds):
+    g = (lambda k: grouping_cfg[k]) if isinstance(grouping_cfg, dict) else (lambda k: getattr(grouping_cfg, k))
+    cluster_coords = (coords + offset)[:, :3]
+    probs = torch.from_numpy(semantic_prediction_logits).float().softmax(dim=-1)
+    tree_mask = (probs[:, tree_class_in_dataset] >= g('tree_conf_thresh')).numpy()
+    mask = tree_mask & (verticality_feat > g('tau_vert')) & (np.abs(offset[:, 2]) < g('tau_off'))
+    ind = np.where(mask)[0]
+    xy = cluster_coords[ind][:, :2]
+    predictions = non_trees_label_in_grouping * np.ones(len(cluster_coords))
+    predictions[tree_mask] = not_assigned_label_in_grouping
+    if g('use_hdbscan'):
+        inst = group_hdbscan(xy, g('tau_min'), not_assigned_label_in_grouping, start_num_preds)
+    else:
+        inst = group_dbscan(xy, g('tau_group'), g('tau_min'), not_assigned_label_in_grouping, start_num_preds)
+    predictions[ind] = inst
+    return predictions.astype(np.int64)
