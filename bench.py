@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpoints/s through the sparse U-Net forward on a synthetic 40x40 m / 0.1 m tile
+(BASELINE.json configs[1]).  One step = model(batch, return_loss=False) on one tile whose points are
+already resident in HBM: voxel hashing, all 13 rulebooks, 65 sparse convs, heads.
+
+    python bench.py --gpus 1 --steps K --warmup W [--dtype bf16|fp32]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Multi-GPU: tiles are independent -> every rank runs its own tile, no data-path
+collective; weak scaling; value = points processed by all ranks / max-over-ranks time.
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the gather-GEMM conv, timed live with
+HIP events) and `cpu_baseline` (the oracle port on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_MFMA_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = vector rate
+PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_work(meta):
+    """Algorithmic work of one conv launch: flops = 2*pairs*Cin*Cout;
+    compulsory bytes = (N_in*Cin + N_out*Cout [+ N_out*Cout residual]) * e + 8*pairs."""
+    t = meta["table"]
+    pairs = int((t >= 0).sum()) if t is not None else meta["n_out"]
+    e = meta["esize"]
+    flops = 2.0 * pairs * meta["Cin"] * meta["Cout"]
+    byts = (meta["n_in"] * meta["Cin"] + meta["n_out"] * meta["Cout"] * (2 if meta["residual"] else 1)) * e + 8.0 * pairs
+    return flops, byts, pairs
+
+
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:                                    # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline_worker():
+    """Oracle (CPU port of the same path) on a bounded sample: a 12x12 m tile of the config-2
+    generator, same voxel size / model; all usable host cores.  Runs in a child process."""
+    from oracle import model as om
+    from treelearn_amd.synth import make_tile
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    t = make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=0)
+    pts = t["points"]; n = len(pts)
+    sd = om.random_state_dict(7, channels=32, num_blocks=7)
+    t0 = time.time()
+    om.forward(sd, pts, t["feat"], np.zeros(n, np.int64), 1, voxel_size=0.1, num_blocks=7, spatial_shape=[500, 500, 1000])
+    dt = time.time() - t0
+    return dict(value=n / dt / 1e6, unit="Mpoints/s", cores=cores, kind="port",
+                sample=f"12x12 m tile of the config-2 generator (voxel 0.1 m, 7-level 32-ch model), {n} points, 1 forward, "
+                       f"fp32 torch-CPU oracle, {dt:.1f} s")
+
+
+def cpu_baseline(timeout_s=240):
+    """Timed in a child process (never touches the GPU; bounded by a timeout so the bench cannot hang)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()), MKL_NUM_THREADS=str(host_cores()), HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
+                           timeout=timeout_s, env=env)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                               # noqa: BLE001
+        return dict(value=None, unit="Mpoints/s", cores=host_cores(), kind="port", sample=f"failed: {type(e).__name__}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--cpu-baseline-worker", action="store_true")
+    args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker()), flush=True)
+        return
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    from oracle import model as om                                    # only for the deterministic random weights
+    from treelearn_amd import ops
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import CONFIGS, make_batch, make_tile
+
+    cfg = CONFIGS[args.workload]
+    tile = make_tile(**cfg, seed=rank)                                 # every rank its own tile
+    batch = make_batch([tile])
+    n_pts = batch["coords"].shape[0]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000] if cfg["voxel"] >= 0.1 else None,
+                      voxel_size=cfg["voxel"], compute_dtype=dtype)
+    model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7), strict=True)
+    model = model.cuda().eval()
+    model.return_backbone_feats = True
+    gbatch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}     # inputs resident in HBM
+
+    def step():
+        with torch.no_grad():
+            return model(gbatch, return_loss=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    npts = torch.tensor([float(n_pts)], device="cuda", dtype=torch.float64)
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(npts, op=dist.ReduceOp.SUM)
+    dt = float(tmax); total_pts = float(npts)
+
+    # live per-kernel timing of the conv launches (separate pass: event pairs perturb the pipeline)
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        step(); torch.cuda.synchronize()
+        ops.PROFILE = []
+        reps = 3
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        recs = ops.PROFILE; ops.PROFILE = None
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / reps
+        per = len(recs) // reps
+        flops = byts = 0.0
+        for _, _, m in recs[:per]:
+            f, b, _ = conv_work(m); flops += f; byts += b
+        avg_ms = tot_ms / per
+        if args.dtype == "fp32":
+            ach = flops / (tot_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=ach, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_MFMA_F32_TFLOPS, traffic=None)
+        else:
+            ach = byts / (tot_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                        mfma_tflops=flops / (tot_ms * 1e-3) / 1e12)
+        roof.update(kernel="k_conv_mfma (tl_conv_fwd)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
+                    algorithmic_gflop_per_step=flops / 1e9, algorithmic_gb_per_step=byts / 1e9)
+
+    if rank == 0:
+        res = dict(metric="Mpoints/sec through sparse U-Net fwd (0.1 m voxel, 40x40 m tile)",
+                   value=total_pts * args.steps / dt / 1e6, unit="Mpoints/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=args.dtype, data="synthetic",
+                   config=dict(workload=f"{args.workload}: single {cfg['extent']:.0f}x{cfg['extent']:.0f} m tile, voxel {cfg['voxel']} m, "
+                                        f"{n_pts} points/tile, 7-level 32-ch sparse U-Net fwd (30.1 M params, random init), 1 tile per GPU",
+                               points_per_tile=n_pts, tiles_per_step=world),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,10 @@ import torch
 
 from . import _hip
 
+# When set to a list, every conv_fwd launch is bracketed by HIP events on the launch stream and
+# (start, end, meta) is appended -- bench.py's live per-kernel timing.  None = no overhead.
+PROFILE = None
+
 
 def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Reference conv weight [Cout,k,k,k,Cin] (spconv layout) -> kernel layout [K,Cout,Cin] in `dtype`."""
@@ -52,6 +56,14 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.out_shift = out_shift.data_ptr() if out_shift is not None else None
     a.out = out.data_ptr(); a.out_ld = out.stride(0)
     a.stats = None
+    if PROFILE is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
+        e1.record()
+        PROFILE.append((e0, e1, dict(K=K, Cin=Cin, Cout=Cout, n_out=n_out, n_in=x.shape[0], table=table,
+                                     residual=residual is not None, esize=x.element_size())))
+        return out
     _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
     return out
 
