@@ -95,13 +95,16 @@ def test_reach_zero_raises():
         _geom(t, np.zeros(len(t), np.int64), 1, 0.5, 4, None)
 
 
-@pytest.mark.parametrize("cin,cout,K", [(32, 32, 27), (64, 32, 27), (96, 96, 27), (32, 64, 8), (64, 32, 8), (384, 192, 1),
-                                          (224, 224, 27), (4, 32, 27), (16, 8, 27), (24, 40, 8)])
-def test_conv_fwd_vs_oracle(cin, cout, K):
+@pytest.mark.parametrize("cin,cout,K,n_out", [
+    (32, 32, 27, 333), (64, 32, 27, 333), (96, 96, 27, 333), (32, 64, 8, 333), (64, 32, 8, 333), (384, 192, 1, 700),
+    (224, 224, 27, 333), (4, 32, 27, 333), (16, 8, 27, 333), (24, 40, 8, 333), (4, 16, 27, 5000),
+    # > 16384 rows: the 128-row output-stationary MFMA kernels (smaller sizes take the split-tap small-level kernel)
+    (32, 32, 27, 17001), (64, 64, 27, 16500), (128, 64, 27, 16400), (96, 96, 8, 16390), (64, 32, 1, 20000), (224, 224, 8, 16385)])
+def test_conv_fwd_vs_oracle(cin, cout, K, n_out):
     from treelearn_amd import ops
     rng = np.random.default_rng(cin * 1000 + cout + K)
     d = _dev()
-    n_in, n_out = 700, 333
+    n_in = 700 if n_out < 1000 else n_out + 77
     x = rng.normal(size=(n_in, cin)).astype(np.float32)
     k = round(K ** (1 / 3))
     w = (rng.normal(size=(cout, k, k, k, cin)) / np.sqrt(cin * K)).astype(np.float32)
@@ -109,7 +112,7 @@ def test_conv_fwd_vs_oracle(cin, cout, K):
     table[rng.uniform(size=table.shape) < 0.5] = -1
     table[:, K // 2][:50] = -1
     if K == 1:
-        table = np.arange(n_in, dtype=np.int32)[:, None]; n_out = n_in
+        n_in = n_out; x = x[:n_in]; table = np.arange(n_in, dtype=np.int32)[:, None]
     sc = rng.uniform(0.5, 1.5, cin).astype(np.float32); sh = rng.normal(0, 0.3, cin).astype(np.float32)
     osc = rng.uniform(0.5, 1.5, cout).astype(np.float32); osh = rng.normal(0, 0.3, cout).astype(np.float32)
     res = rng.normal(size=(n_out, cout)).astype(np.float32)
@@ -201,3 +204,53 @@ def test_tile_loop_golden_g9(golden_dir):
     res = get_pointwise_preds(Fake(), tiles, dict(voxel_size=0.2))
     for i, r in enumerate(res):
         np.testing.assert_allclose(r, g[f"out{i}"], rtol=1e-6, atol=1e-6)
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out", [
+    (32, 32, 27, 401), (64, 64, 27, 401), (96, 96, 27, 401), (128, 64, 27, 401), (64, 32, 8, 401), (384, 192, 1, 900), (224, 224, 27, 401),
+    (16, 8, 27, 401), (4, 32, 27, 3000),
+    (32, 32, 27, 17001), (64, 64, 27, 16500), (96, 96, 27, 16400), (128, 64, 8, 16390), (64, 32, 1, 20000), (224, 224, 8, 16385), (160, 160, 8, 16385)])
+def test_conv_fwd_bf16_vs_oracle(cin, cout, K, n_out):
+    """bf16 storage + bf16 MFMA, fp32 accumulate: compare with the oracle fed the same bf16-rounded operands."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin * 7 + cout + K)
+    d = _dev()
+    n_in = 900 if n_out < 1000 else n_out + 77
+    x = _bf16_round(rng.normal(size=(n_in, cin)).astype(np.float32))
+    k = round(K ** (1 / 3))
+    w = _bf16_round((rng.normal(size=(cout, k, k, k, cin)) / np.sqrt(cin * K)).astype(np.float32))
+    table = rng.integers(-1, n_in, size=(n_out, K)).astype(np.int32)
+    table[rng.uniform(size=table.shape) < 0.4] = -1
+    if K == 1:
+        n_in = n_out; x = x[:n_in]; table = np.arange(n_in, dtype=np.int32)[:, None]
+    sc = rng.uniform(0.5, 1.5, cin).astype(np.float32); sh = rng.normal(0, 0.3, cin).astype(np.float32)
+    res = _bf16_round(rng.normal(size=(n_out, cout)).astype(np.float32))
+    xin = _bf16_round(np.maximum(x * sc + sh, 0).astype(np.float32))
+    ref = osp.conv_table(torch.from_numpy(xin), torch.from_numpy(w), table, n_out).numpy() + res
+    T = lambda a, dt=torch.float32: torch.from_numpy(a).to(d).to(dt)
+    wp = ops.pack_weight(T(w), torch.bfloat16)
+    tab = None if K == 1 else torch.from_numpy(np.ascontiguousarray(table.T)).to(d)
+    out = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, in_scale=T(sc), in_shift=T(sh), in_relu=True, residual=T(res, torch.bfloat16))
+    assert out.dtype == torch.bfloat16
+    assert rel_err(out.float().cpu().numpy(), ref) < 8e-3          # one bf16 rounding of the output (2^-8)
+
+
+def test_forward_bf16_close_to_fp32():
+    """Throughput mode (bf16 features/weights, fp32 accumulate) stays close to the fp32 parity path."""
+    from treelearn_amd.model import TreeLearn
+    t = make_tile(**CONFIGS["config1"], seed=0)
+    batch = make_batch([t])
+    sd = om.random_state_dict(7, channels=32, num_blocks=7)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.2, compute_dtype=dt)
+        model.load_state_dict(sd, strict=True)
+        model = model.cuda().eval()
+        with torch.no_grad():
+            outs[dt] = {k: v.float().cpu().numpy() for k, v in model(batch, return_loss=False).items()}
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(outs[torch.bfloat16][k], outs[torch.float32][k]) < 5e-2, k

@@ -1,0 +1,49 @@
+// Internal declarations shared by the conv translation units.
+#pragma once
+#include "tl_common.h"
+#include <hip/hip_bf16.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvP {
+  const void* in; int64_t in_ld;
+  const void* w;
+  const int32_t* table;
+  int64_t n_out, n_in;
+  int K, Cin, Cout;
+  const float* in_scale; const float* in_shift; int in_relu, out_relu;
+  const void* res; int64_t res_ld;
+  const float* out_scale; const float* out_shift;
+  void* out; int64_t out_ld;
+  int nblk;
+};
+
+static __device__ __forceinline__ float ld_elem(const float* p) { return *p; }
+static __device__ __forceinline__ float ld_elem(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+static __device__ __forceinline__ void st_elem(float* p, float v) { *p = v; }
+static __device__ __forceinline__ void st_elem(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+// XCD-aware tile order: block b runs on XCD b % 8 (observed, speed only); give each XCD a contiguous
+// range of tiles so neighbouring tiles -- which gather overlapping input rows -- share one L2.
+static __device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // round-to-nearest-even
+  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+  a += 0x7FFFu + ((a >> 16) & 1u);
+  b += 0x7FFFu + ((b >> 16) & 1u);
+  return (a >> 16) | (b & 0xFFFF0000u);
+}
+static __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+static __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// tl_conv_small.hip
+int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves
+int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s);   // Cin <= 8 (the 4-channel input conv)

@@ -1,0 +1,217 @@
+// Sparse conv variants for the two shapes the 128-row output-stationary tiling serves badly.
+//
+// k_conv_small  -- deep U-Net levels (a few hundred .. 16 k voxels, up to 224 channels): a 128-row tile
+//   leaves most of the 256 CUs idle and serialises 27 taps x Cin/32 chunks in one workgroup.  Here a
+//   workgroup owns 32 rows x (<=64) output channels and its 4 waves split the (tap, chunk) steps between
+//   them; MFMA operands are loaded straight from global/L2 into fragment registers (the whole level
+//   lives in L2), there is no LDS staging and no barrier in the main loop; the four partial
+//   accumulators are reduced through LDS once at the end.  Deterministic (fixed reduction order).
+//
+// k_conv_tinycin -- the 4-channel input conv (reference tree_learn.py:37-39): HBM-bound on reading the
+//   27-tap table and writing [N,32]; weights sit in LDS, one thread = one row x 8 output channels.
+#include "tl_conv_internal.h"
+
+namespace {
+
+template <bool BF16, int NBB>
+__global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
+  __shared__ float red[4][NBB][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rt = blockIdx.x / ncolblk, cb = blockIdx.x % ncolblk;
+  const int64_t row = (int64_t)rt * 32 + (lane & 31);
+  const int fh = lane >> 5;
+  const int col0 = cb * NBB * 32;
+  const int nchunk = p.Cin / 32;
+  const int nsteps = p.K * nchunk;
+
+  f32x16 acc[NBB];
+#pragma unroll
+  for (int nb = 0; nb < NBB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  for (int s = wv; s < nsteps; s += 4) {
+    const int k = s / nchunk, ch = s % nchunk;
+    int idx = -1;
+    if (row < p.n_out) idx = p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row;
+    if (!__any(idx >= 0)) continue;
+    if constexpr (BF16) {
+      const uint16_t* in = (const uint16_t*)p.in; const uint16_t* W = (const uint16_t*)p.w;
+      uint4 a[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+      if (idx >= 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a[j] = *reinterpret_cast<const uint4*>(in + (int64_t)idx * p.in_ld + ch * 32 + j * 16 + fh * 8);
+        if (p.in_scale || p.in_relu) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c0 = ch * 32 + j * 16 + fh * 8;
+            uint32_t u[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float lo = bf16_lo(u[q]), hi = bf16_hi(u[q]);
+              if (p.in_scale) { lo = fmaf(lo, p.in_scale[c0 + 2 * q], p.in_shift[c0 + 2 * q]); hi = fmaf(hi, p.in_scale[c0 + 2 * q + 1], p.in_shift[c0 + 2 * q + 1]); }
+              if (p.in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+              u[q] = pack_bf16x2(lo, hi);
+            }
+            a[j] = make_uint4(u[0], u[1], u[2], u[3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBB; ++nb) {
+        const uint16_t* wr = W + ((int64_t)k * p.Cout + col0 + nb * 32 + (lane & 31)) * p.Cin + ch * 32 + fh * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 b = *reinterpret_cast<const uint4*>(wr + j * 16);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b), acc[nb], 0, 0, 0);
+        }
+      }
+    } else {
+      const float* in = (const float*)p.in; const float* W = (const float*)p.w;
+      float4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c0 = ch * 32 + fh * 4 + 8 * j;
+          float4 v = *reinterpret_cast<const float4*>(in + (int64_t)idx * p.in_ld + c0);
+          if (p.in_scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + c0), sh = *reinterpret_cast<const float4*>(p.in_shift + c0);
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+          }
+          if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          a[j] = v;
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBB; ++nb) {
+        const float* wr = W + ((int64_t)k * p.Cout + col0 + nb * 32 + (lane & 31)) * p.Cin + ch * 32 + fh * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 b = *reinterpret_cast<const float4*>(wr + 8 * j);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b.x, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b.y, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b.z, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b.w, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < NBB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][nb][r][lane] = acc[nb][r];
+  __syncthreads();
+  // wave w finishes registers r = 4w..4w+3 of every column block (fixed summation order => deterministic)
+  const int col = lane & 31;
+#pragma unroll
+  for (int nb = 0; nb < NBB; ++nb) {
+    const int j = col0 + nb * 32 + col;
+    float osc = 1.f, osh = 0.f;
+    if (p.out_scale) { osc = p.out_scale[j]; osh = p.out_shift[j]; }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wv * 4 + rr;
+      const int64_t orow = (int64_t)rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (orow >= p.n_out) continue;
+      float v = ((red[0][nb][r][lane] + red[1][nb][r][lane]) + red[2][nb][r][lane]) + red[3][nb][r][lane];
+      if constexpr (BF16) {
+        if (p.res) v += __uint_as_float((uint32_t)((const uint16_t*)p.res)[orow * p.res_ld + j] << 16);
+      } else {
+        if (p.res) v += ((const float*)p.res)[orow * p.res_ld + j];
+      }
+      if (p.out_scale) v = fmaf(v, osc, osh);
+      if (p.out_relu) v = fmaxf(v, 0.f);
+      if constexpr (BF16) ((uint16_t*)p.out)[orow * p.out_ld + j] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu);
+      else ((float*)p.out)[orow * p.out_ld + j] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Cin <= 8
+template <typename T, int CIN>
+__global__ void __launch_bounds__(256) k_conv_tinycin(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float wsh[];        // [K][CIN][Cout]
+  const T* w = (const T*)p.w; const T* in = (const T*)p.in; T* out = (T*)p.out; const T* res = (const T*)p.res;
+  for (int e = threadIdx.x; e < p.K * CIN * p.Cout; e += 256) {
+    const int j = e % p.Cout, c = (e / p.Cout) % CIN, k = e / (p.Cout * CIN);
+    wsh[e] = ld_elem(w + ((int64_t)k * p.Cout + j) * p.Cin + c);
+  }
+  __syncthreads();
+  const int ngrp = p.Cout / 8;                                         // 8 output channels per thread
+  const int64_t total = p.n_out * ngrp;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t o = t / ngrp; const int j0 = (int)(t % ngrp) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.K; ++k) {
+      const int64_t idx = p.table ? (int64_t)p.table[(int64_t)k * p.n_out + o] : o;
+      if (idx < 0) continue;
+      float x[CIN];
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) x[c] = ld_elem(in + idx * p.in_ld + c);
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        const float4 w0 = *reinterpret_cast<const float4*>(&wsh[(k * CIN + c) * p.Cout + j0]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&wsh[(k * CIN + c) * p.Cout + j0 + 4]);
+        acc[0] = fmaf(x[c], w0.x, acc[0]); acc[1] = fmaf(x[c], w0.y, acc[1]); acc[2] = fmaf(x[c], w0.z, acc[2]); acc[3] = fmaf(x[c], w0.w, acc[3]);
+        acc[4] = fmaf(x[c], w1.x, acc[4]); acc[5] = fmaf(x[c], w1.y, acc[5]); acc[6] = fmaf(x[c], w1.z, acc[6]); acc[7] = fmaf(x[c], w1.w, acc[7]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = acc[q];
+      if (res) v += ld_elem(res + o * p.res_ld + j0 + q);
+      if (p.out_scale) v = fmaf(v, p.out_scale[j0 + q], p.out_shift[j0 + q]);
+      if (p.out_relu) v = fmaxf(v, 0.f);
+      acc[q] = v;
+    }
+    if constexpr (sizeof(T) == 4) {
+      float4* dst = reinterpret_cast<float4*>((float*)out + o * p.out_ld + j0);
+      dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]); dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+      *reinterpret_cast<uint4*>((uint16_t*)out + o * p.out_ld + j0) =
+          make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+    }
+  }
+}
+
+template <typename T>
+int launch_tiny(const ConvP& p, hipStream_t s) {
+  const size_t lds = (size_t)p.K * p.Cin * p.Cout * 4;
+  const unsigned g = tl_grid(p.n_out * (p.Cout / 8), 256);
+  switch (p.Cin) {
+    case 1: k_conv_tinycin<T, 1><<<g, 256, lds, s>>>(p); break;
+    case 2: k_conv_tinycin<T, 2><<<g, 256, lds, s>>>(p); break;
+    case 3: k_conv_tinycin<T, 3><<<g, 256, lds, s>>>(p); break;
+    case 4: k_conv_tinycin<T, 4><<<g, 256, lds, s>>>(p); break;
+    case 5: k_conv_tinycin<T, 5><<<g, 256, lds, s>>>(p); break;
+    case 6: k_conv_tinycin<T, 6><<<g, 256, lds, s>>>(p); break;
+    case 7: k_conv_tinycin<T, 7><<<g, 256, lds, s>>>(p); break;
+    case 8: k_conv_tinycin<T, 8><<<g, 256, lds, s>>>(p); break;
+    default: return TL_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+}  // namespace
+
+int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
+  const int nrt = (int)tl_cdiv(p.n_out, 32);
+  const bool two = (p.Cout % 64 == 0);
+  const int ncb = p.Cout / (two ? 64 : 32);
+  const unsigned g = (unsigned)(nrt * ncb);
+  if (dtype == TL_BF16) {
+    if (two) k_conv_small<true, 2><<<g, 256, 0, s>>>(p, ncb); else k_conv_small<true, 1><<<g, 256, 0, s>>>(p, ncb);
+  } else {
+    if (two) k_conv_small<false, 2><<<g, 256, 0, s>>>(p, ncb); else k_conv_small<false, 1><<<g, 256, 0, s>>>(p, ncb);
+  }
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s) {
+  const bool out_ok = (dtype == TL_F32) ? (p.out_ld % 4 == 0 && ((uintptr_t)p.out) % 16 == 0) : (p.out_ld % 8 == 0 && ((uintptr_t)p.out) % 16 == 0);
+  if (!out_ok) return TL_ERR_ARG;
+  return dtype == TL_F32 ? launch_tiny<float>(p, s) : launch_tiny<__hip_bfloat16>(p, s);
+}

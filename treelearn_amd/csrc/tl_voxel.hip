@@ -26,31 +26,35 @@ __global__ void k_init_minmax(uint32_t* __restrict__ mm, int B, int32_t* __restr
   if (i < 4) maxc[i] = 0;
 }
 
-// per-batch-element min / max of xyz  (tree_learn.py:134-135)
+// per-batch-element min / max of xyz  (tree_learn.py:134-135).  Thread-local accumulation over a
+// grid-stride range, one wave-reduced set of atomics per wave at the end (6 atomics x ~2 k waves).
 __global__ void __launch_bounds__(kBlock) k_minmax(const float* __restrict__ xyz, const int64_t* __restrict__ bid,
                                                    int64_t N, int B, uint32_t* __restrict__ mm) {
-  const int64_t nround = (N + 63) & ~(int64_t)63;            // whole waves iterate together
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += (int64_t)gridDim.x * blockDim.x) {
-    const bool live = i < N;
-    int b = -1;
-    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-    if (live) {
-      b = (int)bid[i];
-      for (int j = 0; j < 3; ++j) lo[j] = hi[j] = enc_f32(xyz[i * 3 + j]);
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  int cb = -1;
+  auto flush = [&]() {
+    if (cb >= 0 && cb < B)
+      for (int j = 0; j < 3; ++j) { atomicMin(&mm[cb * 6 + j], lo[j]); atomicMax(&mm[cb * 6 + 3 + j], hi[j]); }
+  };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)bid[i];
+    if (b != cb) {
+      flush();
+      cb = b;
+      for (int j = 0; j < 3; ++j) { lo[j] = 0xFFFFFFFFu; hi[j] = 0u; }
     }
-    const int b0 = __shfl(b, 0);                               // lane 0 is live whenever any lane is
-    const bool uniform = __all(!live || b == b0) && b0 >= 0;
-    if (uniform) {
-      for (int j = 0; j < 3; ++j)
-        for (int off = 32; off > 0; off >>= 1) {
-          lo[j] = min(lo[j], (uint32_t)__shfl_xor((int)lo[j], off));
-          hi[j] = max(hi[j], (uint32_t)__shfl_xor((int)hi[j], off));
-        }
-      if ((threadIdx.x & 63) == 0 && b0 < B)
-        for (int j = 0; j < 3; ++j) { atomicMin(&mm[b0 * 6 + j], lo[j]); atomicMax(&mm[b0 * 6 + 3 + j], hi[j]); }
-    } else if (live && b >= 0 && b < B) {
-      for (int j = 0; j < 3; ++j) { atomicMin(&mm[b * 6 + j], lo[j]); atomicMax(&mm[b * 6 + 3 + j], hi[j]); }
-    }
+    for (int j = 0; j < 3; ++j) { const uint32_t e = enc_f32(xyz[i * 3 + j]); lo[j] = min(lo[j], e); hi[j] = max(hi[j], e); }
+  }
+  const int b0 = __shfl(cb, 0);
+  if (__all(cb == b0)) {                                         // whole wave on one batch element: reduce first
+    for (int j = 0; j < 3; ++j)
+      for (int off = 32; off > 0; off >>= 1) {
+        lo[j] = min(lo[j], (uint32_t)__shfl_xor((int)lo[j], off));
+        hi[j] = max(hi[j], (uint32_t)__shfl_xor((int)hi[j], off));
+      }
+    if ((threadIdx.x & 63) == 0) flush();
+  } else {
+    flush();
   }
 }
 
@@ -325,7 +329,7 @@ int tl_voxel_point_coords(const float* xyz, const int64_t* batch_ids, int64_t N,
   if (!xyz || !batch_ids || !ws_minmax || !pcoords || !maxc || N <= 0 || B <= 0 || !(voxel_size > 0.f)) return TL_ERR_ARG;
   hipStream_t s = tl_s(stream);
   k_init_minmax<<<tl_cdiv(B * 6 > 4 ? B * 6 : 4, 64), 64, 0, s>>>(ws_minmax, B, maxc);
-  k_minmax<<<tl_grid(N, kBlock), kBlock, 0, s>>>(xyz, batch_ids, N, B, ws_minmax);
+  k_minmax<<<tl_grid(N, kBlock * 8) < 512 ? tl_grid(N, kBlock * 8) : 512, kBlock, 0, s>>>(xyz, batch_ids, N, B, ws_minmax);
   k_point_coords<<<tl_grid(N, kBlock), kBlock, 0, s>>>(xyz, batch_ids, N, B, voxel_size, ws_minmax, pcoords, maxc);
   TL_CHECK_LAUNCH();
   return TL_OK;
