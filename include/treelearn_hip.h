@@ -34,6 +34,9 @@ enum {
 enum { TL_F32 = 0, TL_BF16 = 1 };
 
 int tl_version(void);
+/* Developer tuning knobs ("bf16_depth": register prefetch depth 1..4; "small_rows": row threshold of the
+ * split-tap small-level kernel).  Not needed for correct results. */
+int tl_set_tuning(const char* key, int64_t value);
 const char* tl_error_string(int code);
 
 /* ------------------------------------------------------------------ voxel hashing

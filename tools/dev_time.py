@@ -8,6 +8,11 @@ from treelearn_amd.model import TreeLearn
 from treelearn_amd.geometry import build_geometry
 from treelearn_amd.synth import CONFIGS, make_batch, make_tile
 
+from treelearn_amd import _hip
+for key in ("bf16_depth", "bf16_units", "small_rows", "dbg"):
+    if os.environ.get("TL_" + key.upper()):
+        _hip.check(_hip.lib().tl_set_tuning(key.encode(), int(os.environ["TL_" + key.upper()])), key)
+        print("tuning", key, os.environ["TL_" + key.upper()])
 name = sys.argv[1] if len(sys.argv) > 1 else "config2"
 dtype = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 cfg = CONFIGS[name]

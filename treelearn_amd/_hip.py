@@ -33,6 +33,7 @@ _I3 = _i32 * 3
 PROTOTYPES = {
     "tl_version": (_i32, []),
     "tl_error_string": (_c.c_char_p, [_i32]),
+    "tl_set_tuning": (_i32, [_c.c_char_p, _i64]),
     "tl_voxel_point_coords": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "tl_bitmap_from_points": (_i32, [_vp, _i64, _I4, _vp, _vp]),
     "tl_bitmap_down": (_i32, [_vp, _I4, _I3, _vp, _I4, _vp]),

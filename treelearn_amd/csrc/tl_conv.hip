@@ -14,6 +14,7 @@
 // lands on 16 different 16-B slots (36*r mod 64 is a permutation of multiples of 4 for r mod 16),
 // i.e. conflict-free for the b128 lane groups of MI355X_MICROARCH.md §LDS.
 #include "tl_conv_internal.h"
+#include <string.h>
 
 namespace {
 
@@ -87,10 +88,11 @@ __global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
 
   const int nchunk = p.Cin / KC;
   const int lrow = tid >> 3, c4 = (tid & 7) * 4;
-  float4 ra[4], rb[NB];
+  float4 ra[4];
+  f32x4 rb[NB];                      // native vector type: HIP's float4 struct copies lower to memcpy and pin the array in scratch
   bool va[4];
 
-  auto issue = [&](int k, int ch) {
+  auto issue = [&](int k, int ch) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = idx_s[k * TM + lrow + 32 * i];
@@ -99,9 +101,9 @@ __global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      rb[i] = *reinterpret_cast<const float4*>(W + ((int64_t)k * p.Cout + lrow + 32 * i) * p.Cin + ch * KC + c4);
+      rb[i] = *reinterpret_cast<const f32x4*>(W + ((int64_t)k * p.Cout + lrow + 32 * i) * p.Cin + ch * KC + c4);
   };
-  auto stage = [&](int buf, int ch) {
+  auto stage = [&](int buf, int ch) __attribute__((always_inline)) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.in_scale) {
       sc = *reinterpret_cast<const float4*>(p.in_scale + ch * KC + c4);
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
       *reinterpret_cast<float4*>(a + (lrow + 32 * i) * LDA + c4) = v;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDA + c4) = rb[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(b + (lrow + 32 * i) * LDA + c4) = rb[i];
   };
 
   if (mask) {
@@ -196,183 +198,6 @@ int launch_mfma_f32(const ConvP& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
-// ------------------------------------------------------------------ bf16 MFMA kernel
-// KCB input channels per step (32 or 64); LDS pitch = KCB*2 + 16 bytes (conflict-free ds_read_b128, see header)
-template <int NB, int KCB>
-__global__ void __launch_bounds__(256) k_conv_mfma_bf16(ConvP p) {
-  constexpr int PITCH = KCB * 2 + 16;             // bytes
-  constexpr int VPR = KCB / 8;                    // 16-B vectors per row
-  constexpr int RPP = 256 / VPR;                  // rows staged per pass
-  constexpr int APASS = TM / RPP;                 // passes for the A tile
-  constexpr int BPASS = (NB * 32 + RPP - 1) / RPP;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* idx_s = reinterpret_cast<int*>(smem);
-  unsigned* mask_s = reinterpret_cast<unsigned*>(idx_s + p.K * TM);
-  char* As = reinterpret_cast<char*>(mask_s + 4);              // [2][TM][PITCH]
-  char* Bs = As + 2 * TM * PITCH;                              // [2][NB*32][PITCH]
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int tile = xcd_tile(blockIdx.x, p.nblk);
-  const int64_t r0 = (int64_t)tile * TM;
-  const uint16_t* in = (const uint16_t*)p.in; const uint16_t* W = (const uint16_t*)p.w;
-
-  if (tid == 0) mask_s[0] = 0;
-  __syncthreads();
-  unsigned local = 0;
-  for (int e = tid; e < p.K * TM; e += 256) {
-    const int k = e >> 7, r = e & (TM - 1);
-    const int64_t row = r0 + r;
-    int idx = -1;
-    if (row < p.n_out) idx = p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row;
-    idx_s[e] = idx;
-    if (idx >= 0) local |= 1u << k;
-  }
-  if (local) atomicOr(&mask_s[0], local);
-  __syncthreads();
-  unsigned mask = __builtin_amdgcn_readfirstlane(mask_s[0]);
-
-  f32x16 acc[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-
-  const int nchunk = p.Cin / KCB;
-  const int lrow = tid / VPR, c8 = (tid % VPR) * 8;
-  uint4 ra[APASS], rb[BPASS];
-  bool va[APASS];
-
-  auto issue = [&](int k, int ch) {
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const int idx = idx_s[k * TM + lrow + RPP * i];
-      va[i] = idx >= 0;
-      ra[i] = va[i] ? *reinterpret_cast<const uint4*>(in + (int64_t)idx * p.in_ld + ch * KCB + c8) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      const int n = lrow + RPP * i;
-      if (n < NB * 32) rb[i] = *reinterpret_cast<const uint4*>(W + ((int64_t)k * p.Cout + n) * p.Cin + ch * KCB + c8);
-    }
-  };
-  auto stage = [&](int buf, int ch) {
-    char* a = As + buf * TM * PITCH;
-    char* b = Bs + buf * NB * 32 * PITCH;
-    if (p.in_scale || p.in_relu) {
-      float sc[8], sh[8];
-      if (p.in_scale) {
-        const float4 s0 = *reinterpret_cast<const float4*>(p.in_scale + ch * KCB + c8), s1 = *reinterpret_cast<const float4*>(p.in_scale + ch * KCB + c8 + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(p.in_shift + ch * KCB + c8), h1 = *reinterpret_cast<const float4*>(p.in_shift + ch * KCB + c8 + 4);
-        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { sc[q] = 1.f; sh[q] = 0.f; }
-      }
-#pragma unroll
-      for (int i = 0; i < APASS; ++i) {
-        if (!va[i]) continue;
-        uint32_t u[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float lo = fmaf(bf16_lo(u[q]), sc[2 * q], sh[2 * q]), hi = fmaf(bf16_hi(u[q]), sc[2 * q + 1], sh[2 * q + 1]);
-          if (p.in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-          u[q] = pack_bf16x2(lo, hi);
-        }
-        ra[i] = make_uint4(u[0], u[1], u[2], u[3]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) *reinterpret_cast<uint4*>(a + (lrow + RPP * i) * PITCH + c8 * 2) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      const int n = lrow + RPP * i;
-      if (n < NB * 32) *reinterpret_cast<uint4*>(b + n * PITCH + c8 * 2) = rb[i];
-    }
-  };
-
-  if (mask) {
-    int k = __builtin_ctz(mask), ch = 0;
-    issue(k, ch);
-    stage(0, ch);
-    __syncthreads();
-    int buf = 0;
-    const int fi = lane & 31, fh = lane >> 5;
-    while (true) {
-      int nk = k, nch = ch + 1;
-      unsigned nmask = mask;
-      if (nch == nchunk) { nch = 0; nmask = mask & (mask - 1); nk = nmask ? __builtin_ctz(nmask) : -1; }
-      const bool more = nk >= 0;
-      if (more) issue(nk, nch);
-
-      const char* a = As + buf * TM * PITCH + (wv * 32 + fi) * PITCH + fh * 16;
-      bf16x8 af[KCB / 16];
-#pragma unroll
-      for (int j = 0; j < KCB / 16; ++j) af[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + 32 * j));
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const char* b = Bs + buf * NB * 32 * PITCH + (nb * 32 + fi) * PITCH + fh * 16;
-#pragma unroll
-        for (int j = 0; j < KCB / 16; ++j) {
-          const bf16x8 bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + 32 * j));
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf, acc[nb], 0, 0, 0);
-        }
-      }
-      if (!more) break;
-      stage(buf ^ 1, nch);
-      __syncthreads();
-      buf ^= 1; k = nk; ch = nch; mask = nmask;
-    }
-  }
-
-  const uint16_t* res = (const uint16_t*)p.res; uint16_t* out = (uint16_t*)p.out;
-  const int col = lane & 31;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int j = nb * 32 + col;
-    float osc = 1.f, osh = 0.f;
-    if (p.out_scale) { osc = p.out_scale[j]; osh = p.out_shift[j]; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = r0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= p.n_out) continue;
-      float v = acc[nb][r];
-      if (res) v += __uint_as_float((uint32_t)res[row * p.res_ld + j] << 16);
-      if (p.out_scale) v = fmaf(v, osc, osh);
-      if (p.out_relu) v = fmaxf(v, 0.f);
-      out[row * p.out_ld + j] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu);
-    }
-  }
-}
-
-template <int NB, int KCB>
-int launch_mfma_bf16(const ConvP& p, hipStream_t s) {
-  constexpr int PITCH = KCB * 2 + 16;
-  const size_t lds = (size_t)p.K * TM * 4 + 16 + 2 * (size_t)TM * PITCH + 2 * (size_t)NB * 32 * PITCH;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma_bf16<NB, KCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
-  k_conv_mfma_bf16<NB, KCB><<<p.nblk, 256, lds, s>>>(p);
-  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
-}
-
-template <int KCB>
-int dispatch_bf16(const ConvP& p, hipStream_t s) {
-  switch (p.Cout / 32) {
-    case 1: return launch_mfma_bf16<1, KCB>(p, s);
-    case 2: return launch_mfma_bf16<2, KCB>(p, s);
-    case 3: return launch_mfma_bf16<3, KCB>(p, s);
-    case 4: return launch_mfma_bf16<4, KCB>(p, s);
-    case 5: return launch_mfma_bf16<5, KCB>(p, s);
-    case 6: return launch_mfma_bf16<6, KCB>(p, s);
-    case 7: return launch_mfma_bf16<7, KCB>(p, s);
-  }
-  return TL_ERR_UNSUPPORTED;
-}
-
 __global__ void k_pack_weight(const float* __restrict__ w, int Cout, int K, int Cin, void* __restrict__ o, int dtype) {
   const int64_t total = (int64_t)Cout * K * Cin;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -398,7 +223,20 @@ __global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __rest
 
 }  // namespace
 
+static int64_t g_small_rows = kSmallRows;
+static int g_dbg = 0;
+static int g_bf16_depth = 0, g_bf16_units = 0;   // 0 = kernel default
+
 extern "C" {
+
+int tl_set_tuning(const char* key, int64_t value) {
+  if (!key) return TL_ERR_ARG;
+  if (!strcmp(key, "bf16_depth")) { g_bf16_depth = (int)value; return TL_OK; }
+  if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
+  if (!strcmp(key, "small_rows")) { g_small_rows = value; return TL_OK; }
+  if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
+  return TL_ERR_ARG;
+}
 
 int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (!a || !a->in || !a->weight || !a->out || a->n_out <= 0 || a->K <= 0 || a->K > 27 || a->Cin <= 0 || a->Cout <= 0) return TL_ERR_ARG;
@@ -413,11 +251,12 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   p.in_relu = a->in_relu; p.out_relu = a->out_relu; p.res = a->residual; p.res_ld = a->res_ld;
   p.out_scale = a->out_scale; p.out_shift = a->out_shift; p.out = a->out; p.out_ld = a->out_ld;
   p.nblk = (int)tl_cdiv(a->n_out, TM);
+  p.dbg = g_dbg;
   hipStream_t s = tl_s(stream);
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0);
   if (a->Cin <= 8 && a->Cout % 8 == 0 && a->Cout <= 64 && !a->in_scale && !a->in_relu && out_vec) return tl_launch_conv_tinycin(p, a->dtype, s);
-  if (vec_ok && a->n_out <= kSmallRows && a->Cin % 32 == 0 && a->Cout % 32 == 0) return tl_launch_conv_small(p, a->dtype, s);
+  if (vec_ok && a->n_out <= g_small_rows && a->Cin % 32 == 0 && a->Cout % 32 == 0) return tl_launch_conv_small(p, a->dtype, s);
   const bool aligned = (a->in_ld % 4 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0) &&
                        (!a->in_scale || (((uintptr_t)a->in_scale) % 16 == 0 && ((uintptr_t)a->in_shift) % 16 == 0));
   if (a->dtype == TL_F32 && aligned && a->Cin % KC == 0 && a->Cout % 32 == 0 && a->Cout <= 224) {
@@ -431,8 +270,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       case 7: return launch_mfma_f32<7>(p, s);
     }
   }
-  if (a->dtype == TL_BF16 && aligned && a->in_ld % 8 == 0 && a->Cin % 32 == 0 && a->Cout % 32 == 0 && a->Cout <= 224)
-    return (a->Cin % 64 == 0) ? dispatch_bf16<64>(p, s) : dispatch_bf16<32>(p, s);
+  if (a->dtype == TL_BF16 && aligned && vec_ok && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && a->Cout <= 224 &&
+      (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
+      (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
+    return tl_launch_conv_bf16(p, g_bf16_depth, g_bf16_units, s);
   const unsigned g = tl_grid(a->n_out * a->Cout, 256);
   if (a->dtype == TL_F32) k_conv_generic<float><<<g, 256, 0, s>>>(p);
   else k_conv_generic<__hip_bfloat16><<<g, 256, 0, s>>>(p);

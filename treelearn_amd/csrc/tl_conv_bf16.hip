@@ -1,0 +1,282 @@
+// bf16 sparse-conv forward, large levels: output-stationary gather-GEMM on v_mfma_f32_32x32x16_bf16.
+//
+// Design notes (gfx950):
+//  * Workgroup = 256 threads = 4 waves, owns TM = 128 consecutive output rows; wave w owns rows
+//    32w..32w+31 and all Cout columns (NB = Cout/32 accumulators of 32x32 fp32).
+//  * The reduction runs over "units" = (active tap, 32-channel chunk).  A step contracts U units
+//    (U*32 channels, U*64 B per gathered row): with Cin = 32 two/four different taps share a step,
+//    with Cin = 64 a step is one tap, so the per-step fixed cost (barrier, waits) is amortised over
+//    at least 128 B per row.
+//  * Gathers are UNCONDITIONAL straight-line 16-B loads (absent neighbours load row 0 and are zeroed
+//    while staging): no exec-masked branches, so hipcc's s_waitcnt insertion keeps counted vmcnt(N)
+//    and the D-deep register prefetch really stays in flight across the per-step barrier.
+//  * BatchNorm scale/shift of the prologue are staged once in LDS (ds_read => lgkmcnt, not vmcnt).
+//  * Operands go through padded LDS tiles (pitch = U*64+16 B: conflict-free ds_read_b128 for the b128
+//    lane groups); LDS is double-buffered, one barrier per step.
+//  * Epilogue: accumulators are transposed through LDS (fp32) so that residual loads and output stores
+//    are full 16-B vectors along the row; one rounding to bf16.
+#include "tl_conv_internal.h"
+
+namespace {
+
+constexpr int TM = 128;
+
+template <int NB, int U, int D>
+__global__ void __launch_bounds__(256) k_conv_bf16(ConvP p) {
+  constexpr int KCB = 32 * U;
+  constexpr int PITCH = KCB * 2 + 16;              // bytes
+  constexpr int VPR = KCB / 8;                     // 16-B vectors per staged row (= 4U)
+  constexpr int RPP = 256 / VPR;                   // rows staged per pass
+  constexpr int APASS = TM / RPP;
+  constexpr int BROWS = NB * 32;
+  constexpr int BPASS = (BROWS + RPP - 1) / RPP;
+  constexpr int EP = NB * 32 + 4;                  // epilogue pitch in floats
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* idx_s = reinterpret_cast<int*>(smem);                           // [K][TM]
+  int* taps_s = idx_s + p.K * TM;                                      // [32]: [0..26] active taps, [31] count
+  float* scale_s = reinterpret_cast<float*>(taps_s + 32);              // [Cin] (+ shift_s [Cin])
+  float* shift_s = scale_s + p.Cin;
+  char* As = reinterpret_cast<char*>(shift_s + p.Cin);                 // [2][TM][PITCH]   (Cin % 32 == 0 keeps 16-B alignment)
+  char* Bs = As + 2 * TM * PITCH;                                      // [2][BROWS][PITCH]
+  float* Es = reinterpret_cast<float*>(As);                            // epilogue alias: [4 waves][32][EP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tile = xcd_tile(blockIdx.x, p.nblk);
+  const int64_t r0 = (int64_t)tile * TM;
+  const char* in = (const char*)p.in; const char* W = (const char*)p.w;
+  const bool pro = p.in_scale != nullptr;
+
+  // ---- phase 0: rulebook rows of this tile -> LDS, active-tap list, BN affine -> LDS
+  if (tid < 32) taps_s[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < p.K * TM; e += 256) {
+    const int k = e >> 7, r = e & (TM - 1);                 // a wave covers 64 rows of ONE tap
+    const int64_t row = r0 + r;
+    int idx = -1;
+    if (row < p.n_out) idx = p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row;
+    idx_s[e] = idx;
+    if (__any(idx >= 0) && lane == 0) atomicOr(&taps_s[30], 1 << k);
+  }
+  if (pro) for (int c = tid; c < p.Cin; c += 256) { scale_s[c] = p.in_scale[c]; shift_s[c] = p.in_shift[c]; }
+  __syncthreads();
+  const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(taps_s[30]);
+  if (tid == 0) {
+    int n = 0;
+    for (unsigned m = mask; m; m &= m - 1) taps_s[n++] = __builtin_ctz(m);
+  }
+  __syncthreads();
+  const int upc = p.Cin >> 5;                               // units per tap
+  const int nunits = __builtin_popcount(mask) * upc;
+  const int nsteps = (nunits + U - 1) / U;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  // ---- per-thread staging role: row lrow (+RPP*i), unit uh of the step, 8 channels at c8
+  const int lrow = tid / VPR, cv = tid % VPR;
+  const int uh = cv >> 2, c8 = (cv & 3) * 8;
+  const int in_ld_b = (int)(p.in_ld * 2);
+  const int64_t w_tap_b = (int64_t)p.Cout * p.Cin * 2;      // bytes per tap
+  const int w_row_b = p.Cin * 2;
+
+  u32x4 ra[D][APASS], rb[D][BPASS];
+  unsigned vmask[D];                                        // bit i: row pass i has a present neighbour
+  int chs[D];                                               // chunk of the unit (for the prologue's channel offset)
+  int it_tap = 0, it_ch = uh;                               // issue stream: (tap ordinal, chunk) of this thread's unit
+#pragma unroll
+  for (int r = 0; r < U; ++r) { const bool w = it_ch >= upc; it_ch -= w ? upc : 0; it_tap += w ? 1 : 0; }   // branch-free wrap
+
+  auto issue = [&](u32x4 (&a)[APASS], u32x4 (&b)[BPASS], unsigned& vm, int& chv) __attribute__((always_inline)) {
+    const bool uvalid = it_tap * upc + it_ch < nunits;
+    const int tapo = uvalid ? it_tap : 0, ch = uvalid ? it_ch : 0;
+    const int tap = taps_s[tapo];
+    chv = ch;
+    unsigned m = 0;
+    const char* src = in + ch * 64 + c8 * 2;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int idx = idx_s[tap * TM + lrow + RPP * i];
+      if (idx >= 0 && uvalid) m |= 1u << i;
+      a[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)max(idx, 0) * in_ld_b);
+    }
+    vm = m;
+    const char* wsrc = W + tap * w_tap_b + ch * 64 + c8 * 2;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int n = min(lrow + RPP * i, BROWS - 1);
+      b[i] = *reinterpret_cast<const u32x4*>(wsrc + n * w_row_b);
+    }
+    it_ch += U;
+#pragma unroll
+    for (int r = 0; r < U; ++r) { const bool w = it_ch >= upc; it_ch -= w ? upc : 0; it_tap += w ? 1 : 0; }
+  };
+
+  auto stage = [&](int buf, u32x4 (&a)[APASS], u32x4 (&b)[BPASS], unsigned vm, int chv) __attribute__((always_inline)) {
+    char* ad = As + buf * TM * PITCH + lrow * PITCH + cv * 16;
+    char* bd = Bs + buf * BROWS * PITCH + lrow * PITCH + cv * 16;
+    if (pro) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale_s + chv * 32 + c8), s1 = *reinterpret_cast<const f32x4*>(scale_s + chv * 32 + c8 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift_s + chv * 32 + c8), h1 = *reinterpret_cast<const f32x4*>(shift_s + chv * 32 + c8 + 4);
+      const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        u32x4 u = a[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float lo = fmaf(bf16_lo(u[q]), sc[2 * q], sh[2 * q]), hi = fmaf(bf16_hi(u[q]), sc[2 * q + 1], sh[2 * q + 1]);
+          if (p.in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+          u[q] = pack_bf16x2(lo, hi);
+        }
+        a[i] = u;
+      }
+    } else if (p.in_relu) {
+#pragma unroll
+      for (int i = 0; i < APASS; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                         // relu on packed bf16: clear negative halves
+          const uint32_t u = a[i][q];
+          a[i][q] = u & (((u & 0x8000u) ? 0u : 0xFFFFu) | ((u & 0x80000000u) ? 0u : 0xFFFF0000u));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const bool v = (vm >> i) & 1u;
+      u32x4 z = a[i];
+      z[0] = v ? z[0] : 0u; z[1] = v ? z[1] : 0u; z[2] = v ? z[2] : 0u; z[3] = v ? z[3] : 0u;
+      *reinterpret_cast<u32x4*>(ad + RPP * i * PITCH) = z;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i)
+      if (BROWS % RPP == 0 || lrow + RPP * i < BROWS) *reinterpret_cast<u32x4*>(bd + RPP * i * PITCH) = b[i];
+  };
+
+  const int fi = lane & 31, fh = lane >> 5;
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* a = As + buf * TM * PITCH + (wv * 32 + fi) * PITCH + fh * 16;
+    bf16x8 af[KCB / 16];
+#pragma unroll
+    for (int j = 0; j < KCB / 16; ++j) af[j] = *reinterpret_cast<const bf16x8*>(a + 32 * j);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const char* b = Bs + buf * BROWS * PITCH + (nb * 32 + fi) * PITCH + fh * 16;
+#pragma unroll
+      for (int j = 0; j < KCB / 16; ++j) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b + 32 * j);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf, acc[nb], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- software pipeline: loads of steps s+1..s+D in flight while step s is contracted.
+  // Every issue() is unconditional (units past the end load a valid dummy row and contribute zero):
+  // any branch around the loads makes hipcc's waitcnt pass merge paths with fewer outstanding loads and
+  // fall back to vmcnt(0), which drains the whole prefetch queue every step.
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(ra[d], rb[d], vmask[d], chs[d]);
+  int buf = 0, s = 0;
+  for (; s + D <= nsteps; s += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      stage(buf, ra[d], rb[d], vmask[d], chs[d]);
+      __syncthreads();
+      issue(ra[d], rb[d], vmask[d], chs[d]);
+      compute(buf);
+      buf ^= 1;
+    }
+  }
+  const int rem = nsteps - s;                                // < D steps left, already in flight
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+    if (d < rem) {
+      stage(buf, ra[d], rb[d], vmask[d], chs[d]);
+      __syncthreads();
+      compute(buf);
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue: acc -> LDS (fp32, wave-private 32 x EP) -> 16-B vector residual loads / output stores
+  __syncthreads();                                           // all waves done reading As/Bs
+  float* ew = Es + wv * 32 * EP;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + nb * 32 + fi] = acc[nb][r];
+  __syncthreads();
+  constexpr int VROW = NB * 4;                               // 16-B output vectors per row (8 bf16 each)
+  const char* res = (const char*)p.res; char* out = (char*)p.out;
+  for (int e = lane; e < 32 * VROW; e += 64) {
+    const int rr = e / VROW, cvv = e % VROW;
+    const int64_t row = r0 + wv * 32 + rr;
+    if (row >= p.n_out) continue;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (res) {
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (row * p.res_ld + cvv * 8) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
+    }
+    if (p.out_scale) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.out_scale + cvv * 8), a1 = *reinterpret_cast<const f32x4*>(p.out_scale + cvv * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.out_shift + cvv * 8), b1 = *reinterpret_cast<const f32x4*>(p.out_shift + cvv * 8 + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] = fmaf(v[q], a0[q], b0[q]); v[q + 4] = fmaf(v[q + 4], a1[q], b1[q]); }
+    }
+    if (p.out_relu) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+    *reinterpret_cast<u32x4*>(out + (row * p.out_ld + cvv * 8) * 2) = o;
+  }
+}
+
+template <int NB, int U, int D>
+int launch(const ConvP& p, hipStream_t s) {
+  constexpr int PITCH = 32 * U * 2 + 16;
+  const size_t main_b = 2 * (size_t)TM * PITCH + 2 * (size_t)NB * 32 * PITCH;
+  const size_t epi_b = 4 * (size_t)32 * (NB * 32 + 4) * 4;
+  const size_t lds = (size_t)p.K * TM * 4 + 128 + (size_t)p.Cin * 8 + (main_b > epi_b ? main_b : epi_b);
+  if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<NB, U, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return TL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  k_conv_bf16<NB, U, D><<<p.nblk, 256, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// Requirements (checked by the caller): Cin % 32 == 0, Cout % 32 == 0, Cout <= 224, 16-B aligned rows
+// (in_ld, out_ld, res_ld multiples of 8; base pointers 16-B aligned).
+int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s) {
+  const int nb = p.Cout / 32;
+  const int D = depth > 0 ? depth : 2;                      // measured: 2 >= 3 (occupancy) >= 1 on the config-2 levels
+  int U = units > 0 ? units : 2;
+  if (U == 4) {                                             // 4-unit steps need 2x the LDS: fall back when they do not fit
+    const size_t pitch = 32 * 4 * 2 + 16;
+    const size_t need = (size_t)p.K * TM * 4 + 128 + (size_t)p.Cin * 8 + 2 * TM * pitch + 2 * (size_t)nb * 32 * pitch;
+    if (need > 160 * 1024) U = 2;
+  }
+#define TL_CASE(NB_)                                                                       \
+  case NB_:                                                                                \
+    if (U == 4) return D >= 3 && NB_ <= 3 ? launch<NB_, 4, 3>(p, s) : launch<NB_, 4, 2>(p, s); \
+    if (D >= 3 && NB_ <= 3) return launch<NB_, 2, 3>(p, s);                                \
+    if (D == 1) return launch<NB_, 2, 1>(p, s);                                            \
+    return launch<NB_, 2, 2>(p, s);
+  switch (nb) {
+    TL_CASE(1) TL_CASE(2) TL_CASE(3) TL_CASE(4) TL_CASE(5) TL_CASE(6) TL_CASE(7)
+  }
+#undef TL_CASE
+  return TL_ERR_UNSUPPORTED;
+}

@@ -5,6 +5,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvP {
@@ -18,6 +19,7 @@ struct ConvP {
   const float* out_scale; const float* out_shift;
   void* out; int64_t out_ld;
   int nblk;
+  int dbg;     // developer ablation bits (tl_set_tuning "dbg"): 1 no A loads, 2 no B loads, 4 no MFMA, 8 no stores
 };
 
 static __device__ __forceinline__ float ld_elem(const float* p) { return *p; }
@@ -43,6 +45,9 @@ static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {    
 }
 static __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 static __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// tl_conv_bf16.hip
+int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   // large levels, bf16 MFMA
 
 // tl_conv_small.hip
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves
