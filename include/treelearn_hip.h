@@ -160,7 +160,7 @@ int tl_compact_rows(const float* in, int C, const uint8_t* mask, int64_t n, floa
  * xy f32[n,2]; labels i32[n] out; n_clusters i32[1] device out;
  * ws: tl_cluster_ws_bytes(n) bytes. */
 int64_t tl_cluster_ws_bytes(int64_t n);
-int tl_cluster_grid(const float* xy, int64_t n, float eps, int32_t* labels, int32_t* n_clusters,
+int tl_cluster_grid(const float* xy, int64_t n, double eps, int32_t* labels, int32_t* n_clusters,
                     void* ws, tl_stream_t stream);
 
 #ifdef __cplusplus

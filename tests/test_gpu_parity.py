@@ -254,3 +254,25 @@ def test_forward_bf16_close_to_fp32():
             outs[dt] = {k: v.float().cpu().numpy() for k, v in model(batch, return_loss=False).items()}
     for k in ("semantic_prediction_logits", "offset_predictions"):
         assert rel_err(outs[torch.bfloat16][k], outs[torch.float32][k]) < 5e-2, k
+
+
+def test_dbscan_grid_vs_golden(golden_dir):
+    """GPU eps-graph components == sklearn DBSCAN(min_samples=2) incl. numbering (golden from the reference)."""
+    from treelearn_amd.util.pipeline import group_dbscan, get_instances
+    g = np.load(os.path.join(golden_dir, "g5_clustering.npz"))
+    np.testing.assert_array_equal(group_dbscan(g["gd_xy"], 0.15, 50, -1, 1), g["gd_pred"])
+    cfg = dict(tree_conf_thresh=0.5, tau_vert=0.6, tau_off=4, tau_group=0.15, tau_min=50, use_hdbscan=False)
+    for case in "ab":
+        pred = get_instances(g[f"{case}_coords"], g[f"{case}_offsets"], g[f"{case}_logits"], cfg, g[f"{case}_vert"], 0, 0, -1, 1)
+        np.testing.assert_array_equal(pred, g[f"{case}_dbscan_pred"])
+
+
+def test_dbscan_grid_vs_sklearn_random():
+    from sklearn.cluster import DBSCAN
+    from treelearn_amd.cluster import dbscan_min2
+    rng = np.random.default_rng(0)
+    for n, spread in ((1, 1.0), (2, 0.05), (5000, 3.0), (60000, 12.0)):
+        xy = (rng.normal(size=(n, 2)) * spread).astype(np.float32)
+        xy[: n // 3] = (rng.integers(-20, 20, size=(n // 3, 2)) * 0.5 + rng.normal(size=(n // 3, 2)) * 0.03).astype(np.float32)
+        ref = DBSCAN(eps=0.15, min_samples=2).fit(xy).labels_
+        np.testing.assert_array_equal(dbscan_min2(xy, 0.15), ref)

@@ -52,7 +52,7 @@ PROTOTYPES = {
     "tl_compact_ws_words": (_i64, [_i64]),
     "tl_compact_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tl_cluster_ws_bytes": (_i64, [_i64]),
-    "tl_cluster_grid": (_i32, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+    "tl_cluster_grid": (_i32, [_vp, _i64, _c.c_double, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -17,6 +17,3 @@ const char* tl_error_string(int code) {
 
 }  // extern "C"
 
-// TEMPORARY until tl_cluster.hip lands
-extern "C" int64_t tl_cluster_ws_bytes(int64_t n) { return 0; }
-extern "C" int tl_cluster_grid(const float*, int64_t, float, int32_t*, int32_t*, void*, tl_stream_t) { return TL_ERR_UNSUPPORTED; }

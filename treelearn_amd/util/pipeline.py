@@ -36,6 +36,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             outs[2].append(off); outs[3].append(batch['offset_labels'][m])
             outs[4].append(coords[m]); outs[5].append(batch['instance_labels'][m])
             outs[6].append(bb); outs[7].append(batch['input_feats'][m])
+    if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
+        return tuple(np.zeros((0,), np.float32) for _ in outs)
     return tuple(torch.cat(o, 0).numpy() for o in outs)
 
 
