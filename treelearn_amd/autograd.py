@@ -25,24 +25,24 @@ def _packed(weight, dtype):
 
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, table, n_out):
+    def forward(ctx, feats, weight, ref):
         x = feats.contiguous()
-        out = ops.conv_fwd(x, _packed(weight, x.dtype), table, n_out)
+        out = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out)
         ctx.save_for_backward(x, weight)
-        ctx.table = table
+        ctx.ref = ref
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        from . import backward as bw                       # HIP dgrad / wgrad
+        from . import backward as bw
         x, weight = ctx.saved_tensors
-        gx, gw = bw.conv_backward(x, weight, ctx.table, grad_out.contiguous(),
-                                  ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gw, None, None
+        gx, gw = bw.conv_backward(x, weight, ctx.ref, grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, None
 
 
-def sparse_conv(feats, weight, table, n_out):
+def sparse_conv(feats, weight, ref):
+    """`ref`: treelearn_amd.backward.TableRef (rulebook + its transpose)."""
     if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad):
-        return _SparseConvFn.apply(feats, weight, table, n_out)
+        return _SparseConvFn.apply(feats, weight, ref)
     x = feats.contiguous()
-    return ops.conv_fwd(x, _packed(weight, x.dtype), table, n_out)
+    return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out)

@@ -40,7 +40,9 @@ class Custom1x1Subm3d(spconv.SparseConv3d):
     """1x1 'conv' = dense GEMM on the feature matrix (blocks.py:29-39)."""
     def forward(self, input):
         from ..autograd import sparse_conv
-        feats = sparse_conv(input.features, self.weight, None, input.features.shape[0])
+        from ..backward import TableRef
+        n = input.features.shape[0]
+        feats = sparse_conv(input.features, self.weight, TableRef(None, n, None, n, False))
         if self.bias is not None:
             feats = feats + self.bias
         return input.replace_feature(feats)

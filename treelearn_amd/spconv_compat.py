@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .backward import TableRef
 
 
 class SparseConvTensor:
@@ -95,8 +96,8 @@ class SparseConvolution(SparseModule):
 
     def forward(self, x):
         from .autograd import sparse_conv                  # late import (autograd depends on ops)
-        table, n_out, out_level = self._table(x)
-        feats = sparse_conv(x.features, self.weight, table, n_out)
+        ref, out_level = self._table(x)
+        feats = sparse_conv(x.features, self.weight, ref)
         if self.bias is not None:
             feats = feats + self.bias
         lv = x.geometry.levels[out_level]
@@ -114,9 +115,9 @@ class SubMConv3d(SparseConvolution):
     def _table(self, x):
         lv = x.geometry.levels[x.level]
         if int(self.kernel_size) == 1:
-            return None, lv.n, x.level
+            return TableRef(None, lv.n, None, lv.n, False), x.level
         assert int(self.kernel_size) == 3, "rulebooks are built for kernel_size 3 (reference configs/_modular/model.yaml:2)"
-        return lv.nbr, lv.n, x.level
+        return TableRef(lv.nbr, lv.n, lv.nbr, lv.n, True), x.level
 
 
 class SparseConv3d(SparseConvolution):
@@ -125,13 +126,13 @@ class SparseConv3d(SparseConvolution):
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, indice_key)
 
     def _table(self, x):
-        if int(self.kernel_size) == 1 and int(self.stride) == 1:
-            return None, x.geometry.levels[x.level].n, x.level
-        assert int(self.kernel_size) == 2 and int(self.stride) == 2
         lv = x.geometry.levels[x.level]
+        if int(self.kernel_size) == 1 and int(self.stride) == 1:
+            return TableRef(None, lv.n, None, lv.n, False), x.level
+        assert int(self.kernel_size) == 2 and int(self.stride) == 2
         if lv.child is None:
             raise ValueError("geometry was built with too few levels for this SparseConv3d")
-        return lv.child, x.geometry.levels[x.level + 1].n, x.level + 1
+        return TableRef(lv.child, x.geometry.levels[x.level + 1].n, lv.inv, lv.n, False), x.level + 1
 
 
 class SparseInverseConv3d(SparseConvolution):
@@ -141,4 +142,4 @@ class SparseInverseConv3d(SparseConvolution):
     def _table(self, x):
         assert int(self.kernel_size) == 2 and x.level > 0
         lv = x.geometry.levels[x.level - 1]
-        return lv.inv, lv.n, x.level - 1
+        return TableRef(lv.inv, lv.n, lv.child, x.geometry.levels[x.level].n, False), x.level - 1
