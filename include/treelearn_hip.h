@@ -163,6 +163,18 @@ int64_t tl_cluster_ws_bytes(int64_t n);
 int tl_cluster_grid(const float* xy, int64_t n, double eps, int32_t* labels, int32_t* n_clusters,
                     void* ws, tl_stream_t stream);
 
+/* HDBSCAN(min_cluster_size = m) of group_hdbscan (tree_learn/util/pipeline.py:184-191; sklearn: min_samples = m,
+ * euclidean, Prim MST on mutual reachability, EOM).  Device stage: core distances (k-th neighbour incl. self) and
+ * Prim's MST with sklearn's tie-breaking, fp64 on the fp32 points.  xy f32[n,2]; e_src/e_dst i32[n-1], e_w f64[n-1]
+ * (edges in insertion order); core f64[n] or NULL; ws tl_hdbscan_ws_bytes(n). */
+int64_t tl_hdbscan_ws_bytes(int64_t n);
+int tl_hdbscan_mst(const float* xy, int64_t n, int min_samples, int32_t* e_src, int32_t* e_dst, double* e_w,
+                   double* core, void* ws, tl_stream_t stream);
+/* HOST stage (host pointers, no GPU work): edges -> single linkage -> condensed tree -> EOM -> labels i32[n]
+ * (-1 noise, clusters numbered by ascending condensed-tree id like sklearn). */
+int tl_hdbscan_labels_host(const int32_t* e_src, const int32_t* e_dst, const double* e_w, int64_t n,
+                           int min_cluster_size, int32_t* labels);
+
 #ifdef __cplusplus
 }
 #endif

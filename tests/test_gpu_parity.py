@@ -310,3 +310,43 @@ def test_training_step_vs_golden(golden_dir, name):
     np.testing.assert_allclose(ours, ref, rtol=5e-3, atol=1e-6 * ref.max())
     assert rel_err(model.input_conv[0].weight.grad.cpu().numpy(), g[f"{name}_grad_input_conv"]) < 5e-3
     assert rel_err(model.semantic_linear[3].weight.grad.cpu().numpy(), g[f"{name}_grad_sem3"]) < 5e-3
+
+
+def _same_partition(a, b):
+    """labels equal up to renaming of the non-noise clusters (noise = -1 must coincide)."""
+    a = np.asarray(a); b = np.asarray(b)
+    if not np.array_equal(a == -1, b == -1):
+        return False
+    pairs = set(zip(a[a != -1].tolist(), b[b != -1].tolist()))
+    return len(pairs) == len(set(p[0] for p in pairs)) == len(set(p[1] for p in pairs))
+
+
+def test_hdbscan_vs_golden_and_sklearn(golden_dir):
+    from sklearn.cluster import HDBSCAN
+    from treelearn_amd.cluster import hdbscan
+    from treelearn_amd.util.pipeline import get_instances
+    g = np.load(os.path.join(golden_dir, "g5_clustering.npz"))
+    cfg = dict(tree_conf_thresh=0.5, tau_vert=0.6, tau_off=4, tau_group=0.15, tau_min=50, use_hdbscan=True)
+    for case in "ab":
+        pred = get_instances(g[f"{case}_coords"], g[f"{case}_offsets"], g[f"{case}_logits"], cfg, g[f"{case}_vert"], 0, 0, -1, 1)
+        ref = g[f"{case}_hdbscan_pred"]
+        np.testing.assert_array_equal(pred <= 0, ref <= 0)              # non-tree (0) / unassigned (-1) coincide
+        np.testing.assert_array_equal(pred == 0, ref == 0)
+        assert _same_partition(np.where(pred > 0, pred, -1), np.where(ref > 0, ref, -1))
+        np.testing.assert_array_equal(pred, ref)                        # and, on this data, the numbering too
+    rng = np.random.default_rng(5)
+    for n, k in ((400, 10), (3000, 50), (12000, 50)):
+        centers = rng.uniform(-20, 20, size=(9, 2))
+        xy = np.concatenate([c + rng.normal(size=(n // 10, 2)) * rng.uniform(0.05, 0.6) for c in centers] + [rng.uniform(-25, 25, size=(n // 10, 2))]).astype(np.float32)
+        ref = HDBSCAN(min_cluster_size=k).fit(xy).labels_
+        ours = hdbscan(xy, k)
+        # Mutual-reachability MSTs are full of equal-weight edges; sklearn orders them with numpy's unstable
+        # (and CPU-dependent) quicksort, so individual boundary points may fall on either side of a split born
+        # at the same lambda.  Same clusters, >= 99 % identical point assignments.
+        assert len(set(ours[ours >= 0])) == len(set(ref[ref >= 0])), (n, k)
+        agree = 0
+        for c in set(ours.tolist()):
+            m = ours == c
+            vals, cnts = np.unique(ref[m], return_counts=True)
+            agree += cnts.max() if c != -1 else int((ref[m] == -1).sum())
+        assert agree / len(ours) >= 0.99, (n, k, agree / len(ours))

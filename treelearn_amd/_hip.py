@@ -53,6 +53,9 @@ PROTOTYPES = {
     "tl_compact_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tl_cluster_ws_bytes": (_i64, [_i64]),
     "tl_cluster_grid": (_i32, [_vp, _i64, _c.c_double, _vp, _vp, _vp, _vp]),
+    "tl_hdbscan_ws_bytes": (_i64, [_i64]),
+    "tl_hdbscan_mst": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tl_hdbscan_labels_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
 }
 
 _lib = None

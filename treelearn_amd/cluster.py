@@ -21,6 +21,22 @@ def dbscan_min2(xy, eps, device="cuda"):
     return labels.cpu().numpy().astype(np.int64)
 
 
-def hdbscan(xy, min_cluster_size):
-    raise NotImplementedError("HDBSCAN grouping is not built yet on the HIP path (use grouping.use_hdbscan=False: "
-                              "DBSCAN(eps=tau_group, min_samples=2)); there is deliberately no CPU fallback")
+def hdbscan(xy, min_cluster_size, device="cuda"):
+    """sklearn HDBSCAN(min_cluster_size=m).fit(xy).labels_ (min_samples = m, EOM): core distances + Prim MST
+    on the GPU (tl_hdbscan_mst), hierarchy condensation on the host (tl_hdbscan_labels_host)."""
+    L = _hip.lib()
+    t = torch.as_tensor(np.ascontiguousarray(xy, dtype=np.float32)) if not torch.is_tensor(xy) else xy.float().contiguous()
+    n = t.shape[0]
+    m = int(min_cluster_size)
+    if n < m:
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {m}, n_samples_fit = {n}")   # as sklearn
+    t = t.to(device)
+    e_src = torch.empty(n - 1, dtype=torch.int32, device=t.device)
+    e_dst = torch.empty(n - 1, dtype=torch.int32, device=t.device)
+    e_w = torch.empty(n - 1, dtype=torch.float64, device=t.device)
+    ws = torch.empty(int(L.tl_hdbscan_ws_bytes(n)), dtype=torch.uint8, device=t.device)
+    _hip.check(L.tl_hdbscan_mst(_hip.ptr(t), n, m, _hip.ptr(e_src), _hip.ptr(e_dst), _hip.ptr(e_w), None, _hip.ptr(ws), _hip.stream()), "tl_hdbscan_mst")
+    hs, hd, hw = e_src.cpu().numpy(), e_dst.cpu().numpy(), e_w.cpu().numpy()
+    labels = np.empty(n, np.int32)
+    _hip.check(L.tl_hdbscan_labels_host(hs.ctypes.data, hd.ctypes.data, hw.ctypes.data, n, m, labels.ctypes.data), "tl_hdbscan_labels_host")
+    return labels.astype(np.int64)
