@@ -109,6 +109,7 @@ int tl_table_tapmask(const int32_t* table, int K, int64_t n_out, uint32_t* tapma
  *
  *   out[o, :] = epi( sum_k  W[k] . pro(in[table[k][o], :]) )        (absent rows contribute 0)
  *   pro(x) = relu?(x * in_scale + in_shift)       epi(y) = relu?((y + residual[o]) * out_scale + out_shift)
+ *   out2 / out3 (optional) = relu?((y + residual[o]) * out{2,3}_scale + out{2,3}_shift)
  */
 typedef struct tl_conv_args {
   const void* in;        int64_t in_ld;   /* row stride in elements (>= Cin) */
@@ -122,6 +123,10 @@ typedef struct tl_conv_args {
   const float* out_scale; const float* out_shift;
   void* out;             int64_t out_ld;
   float* stats;                           /* optional f32[2*Cout]: += sum, sumsq of (acc+residual) per channel */
+  /* up to two extra views of y = acc + residual, each with its own affine/ReLU -- lets a producer store the
+   * raw tensor (for the residual branch) AND relu(bn_next(y)) (for the next conv's gathers) in one pass: */
+  void* out2; int64_t out2_ld; const float* out2_scale; const float* out2_shift; int32_t out2_relu;
+  void* out3; int64_t out3_ld; const float* out3_scale; const float* out3_shift; int32_t out3_relu;
 } tl_conv_args;
 
 int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);

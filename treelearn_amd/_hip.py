@@ -23,6 +23,8 @@ class ConvArgs(_c.Structure):
         ("in_scale", _vp), ("in_shift", _vp), ("in_relu", _i32), ("out_relu", _i32),
         ("residual", _vp), ("res_ld", _i64), ("out_scale", _vp), ("out_shift", _vp),
         ("out", _vp), ("out_ld", _i64), ("stats", _vp),
+        ("out2", _vp), ("out2_ld", _i64), ("out2_scale", _vp), ("out2_shift", _vp), ("out2_relu", _i32),
+        ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
     ]
 
 

@@ -21,7 +21,7 @@ namespace {
 // ------------------------------------------------------------------ generic fallback (any Cin/Cout)
 template <typename T>
 __global__ void __launch_bounds__(256) k_conv_generic(ConvP p) {
-  const T* in = (const T*)p.in; const T* w = (const T*)p.w; const T* res = (const T*)p.res; T* out = (T*)p.out;
+  const T* in = (const T*)p.in; const T* w = (const T*)p.w; const T* res = (const T*)p.res;
   const int64_t total = p.n_out * p.Cout;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t o = t / p.Cout; const int j = (int)(t % p.Cout);
@@ -40,9 +40,10 @@ __global__ void __launch_bounds__(256) k_conv_generic(ConvP p) {
       }
     }
     if (res) acc += ld_elem(res + o * p.res_ld + j);
-    if (p.out_scale) acc = fmaf(acc, p.out_scale[j], p.out_shift[j]);
-    if (p.out_relu) acc = fmaxf(acc, 0.f);
-    st_elem(out + o * p.out_ld + j, acc);
+    constexpr bool BF = sizeof(T) == 2;
+    epi_store1<BF>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, o, j, acc);
+    if (p.out2) epi_store1<BF>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, o, j, acc);
+    if (p.out3) epi_store1<BF>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, o, j, acc);
   }
 }
 
@@ -165,22 +166,20 @@ __global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float* res = (const float*)p.res; float* out = (float*)p.out;
+  const float* res = (const float*)p.res;
   const int col = lane & 31;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int j = nb * 32 + col;
-    float osc = 1.f, osh = 0.f;
-    if (p.out_scale) { osc = p.out_scale[j]; osh = p.out_shift[j]; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = r0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row >= p.n_out) continue;
       float v = acc[nb][r];
       if (res) v += res[row * p.res_ld + j];
-      if (p.out_scale) v = fmaf(v, osc, osh);
-      if (p.out_relu) v = fmaxf(v, 0.f);
-      out[row * p.out_ld + j] = v;
+      epi_store1<false>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, row, j, v);
+      if (p.out2) epi_store1<false>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, row, j, v);
+      if (p.out3) epi_store1<false>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, row, j, v);
     }
   }
 }
@@ -250,11 +249,15 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   p.K = a->K; p.Cin = a->Cin; p.Cout = a->Cout; p.in_scale = a->in_scale; p.in_shift = a->in_shift;
   p.in_relu = a->in_relu; p.out_relu = a->out_relu; p.res = a->residual; p.res_ld = a->res_ld;
   p.out_scale = a->out_scale; p.out_shift = a->out_shift; p.out = a->out; p.out_ld = a->out_ld;
+  p.out2 = a->out2; p.out2_ld = a->out2_ld; p.out2_scale = a->out2_scale; p.out2_shift = a->out2_shift; p.out2_relu = a->out2_relu;
+  p.out3 = a->out3; p.out3_ld = a->out3_ld; p.out3_scale = a->out3_scale; p.out3_shift = a->out3_shift; p.out3_relu = a->out3_relu;
+  if ((a->out2_scale == nullptr) != (a->out2_shift == nullptr) || (a->out3_scale == nullptr) != (a->out3_shift == nullptr)) return TL_ERR_ARG;
   p.nblk = (int)tl_cdiv(a->n_out, TM);
   p.dbg = g_dbg;
   hipStream_t s = tl_s(stream);
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
-  const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0);
+  const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
+                       (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));
   if (a->Cin <= 8 && a->Cout % 8 == 0 && a->Cout <= 64 && !a->in_scale && !a->in_relu && out_vec) return tl_launch_conv_tinycin(p, a->dtype, s);
   if (vec_ok && a->n_out <= g_small_rows && a->Cin % 32 == 0 && a->Cout % 32 == 0) return tl_launch_conv_small(p, a->dtype, s);
   const bool aligned = (a->in_ld % 4 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0) &&

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_conv_bf16(ConvP p) {
     for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + nb * 32 + fi] = acc[nb][r];
   __syncthreads();
   constexpr int VROW = NB * 4;                               // 16-B output vectors per row (8 bf16 each)
-  const char* res = (const char*)p.res; char* out = (char*)p.out;
+  const char* res = (const char*)p.res;
   for (int e = lane; e < 32 * VROW; e += 64) {
     const int rr = e / VROW, cvv = e % VROW;
     const int64_t row = r0 + wv * 32 + rr;
@@ -221,20 +221,9 @@ __global__ void __launch_bounds__(256) k_conv_bf16(ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
     }
-    if (p.out_scale) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.out_scale + cvv * 8), a1 = *reinterpret_cast<const f32x4*>(p.out_scale + cvv * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.out_shift + cvv * 8), b1 = *reinterpret_cast<const f32x4*>(p.out_shift + cvv * 8 + 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { v[q] = fmaf(v[q], a0[q], b0[q]); v[q + 4] = fmaf(v[q + 4], a1[q], b1[q]); }
-    }
-    if (p.out_relu) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-    }
-    u32x4 o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
-    *reinterpret_cast<u32x4*>(out + (row * p.out_ld + cvv * 8) * 2) = o;
+    epi_store8<true>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, row, cvv * 8, v);
+    if (p.out2) epi_store8<true>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, row, cvv * 8, v);
+    if (p.out3) epi_store8<true>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, row, cvv * 8, v);
   }
 }
 

@@ -18,6 +18,9 @@ struct ConvP {
   const void* res; int64_t res_ld;
   const float* out_scale; const float* out_shift;
   void* out; int64_t out_ld;
+  // optional extra views of the same result y = acc (+ residual), each with its own BN affine / ReLU:
+  void* out2; int64_t out2_ld; const float* out2_scale; const float* out2_shift; int out2_relu;
+  void* out3; int64_t out3_ld; const float* out3_scale; const float* out3_shift; int out3_relu;
   int nblk;
   int dbg;     // developer ablation bits (tl_set_tuning "dbg"): 1 no A loads, 2 no B loads, 4 no MFMA, 8 no stores
 };
@@ -45,6 +48,41 @@ static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {    
 }
 static __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 static __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+// ---- epilogue helpers: write y (fp32) through one output view
+template <bool BF16>
+static __device__ __forceinline__ void epi_store1(void* base, int64_t ld, const float* sc, const float* sh, int relu, int64_t row, int j, float y) {
+  if (sc) y = fmaf(y, sc[j], sh[j]);
+  if (relu) y = fmaxf(y, 0.f);
+  if constexpr (BF16) ((uint16_t*)base)[row * ld + j] = (uint16_t)(pack_bf16x2(y, 0.f) & 0xFFFFu);
+  else ((float*)base)[row * ld + j] = y;
+}
+// 8 consecutive channels c0..c0+7 (c0 % 8 == 0), 16-B (bf16) / 2x16-B (f32) vector stores
+template <bool BF16>
+static __device__ __forceinline__ void epi_store8(void* base, int64_t ld, const float* sc, const float* sh, int relu, int64_t row, int c0, const float (&y)[8]) {
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = y[q];
+  if (sc) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sc + c0), a1 = *reinterpret_cast<const f32x4*>(sc + c0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh + c0), b1 = *reinterpret_cast<const f32x4*>(sh + c0 + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = fmaf(v[q], a0[q], b0[q]); v[q + 4] = fmaf(v[q + 4], a1[q], b1[q]); }
+  }
+  if (relu) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+  }
+  if constexpr (BF16) {
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+    *reinterpret_cast<u32x4*>((uint16_t*)base + row * ld + c0) = o;
+  } else {
+    f32x4* d = reinterpret_cast<f32x4*>((float*)base + row * ld + c0);
+    d[0] = f32x4{v[0], v[1], v[2], v[3]}; d[1] = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
 
 // tl_conv_bf16.hip
 int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   // large levels, bf16 MFMA

@@ -109,8 +109,6 @@ __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
   for (int nb = 0; nb < NBB; ++nb) {
     const int j = col0 + nb * 32 + col;
-    float osc = 1.f, osh = 0.f;
-    if (p.out_scale) { osc = p.out_scale[j]; osh = p.out_shift[j]; }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int r = wv * 4 + rr;
@@ -122,10 +120,9 @@ __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
       } else {
         if (p.res) v += ((const float*)p.res)[orow * p.res_ld + j];
       }
-      if (p.out_scale) v = fmaf(v, osc, osh);
-      if (p.out_relu) v = fmaxf(v, 0.f);
-      if constexpr (BF16) ((uint16_t*)p.out)[orow * p.out_ld + j] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu);
-      else ((float*)p.out)[orow * p.out_ld + j] = v;
+      epi_store1<BF16>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, orow, j, v);
+      if (p.out2) epi_store1<BF16>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, orow, j, v);
+      if (p.out3) epi_store1<BF16>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, orow, j, v);
     }
   }
 }
@@ -134,7 +131,7 @@ __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
 template <typename T, int CIN>
 __global__ void __launch_bounds__(256) k_conv_tinycin(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float wsh[];        // [K][CIN][Cout]
-  const T* w = (const T*)p.w; const T* in = (const T*)p.in; T* out = (T*)p.out; const T* res = (const T*)p.res;
+  const T* w = (const T*)p.w; const T* in = (const T*)p.in; const T* res = (const T*)p.res;
   for (int e = threadIdx.x; e < p.K * CIN * p.Cout; e += 256) {
     const int j = e % p.Cout, c = (e / p.Cout) % CIN, k = e / (p.Cout * CIN);
     wsh[e] = ld_elem(w + ((int64_t)k * p.Cout + j) * p.Cin + c);
@@ -160,20 +157,11 @@ __global__ void __launch_bounds__(256) k_conv_tinycin(ConvP p) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = acc[q];
-      if (res) v += ld_elem(res + o * p.res_ld + j0 + q);
-      if (p.out_scale) v = fmaf(v, p.out_scale[j0 + q], p.out_shift[j0 + q]);
-      if (p.out_relu) v = fmaxf(v, 0.f);
-      acc[q] = v;
-    }
-    if constexpr (sizeof(T) == 4) {
-      float4* dst = reinterpret_cast<float4*>((float*)out + o * p.out_ld + j0);
-      dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]); dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    } else {
-      *reinterpret_cast<uint4*>((uint16_t*)out + o * p.out_ld + j0) =
-          make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
-    }
+    for (int q = 0; q < 8; ++q) if (res) acc[q] += ld_elem(res + o * p.res_ld + j0 + q);
+    constexpr bool BF = sizeof(T) == 2;
+    epi_store8<BF>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, o, j0, acc);
+    if (p.out2) epi_store8<BF>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, o, j0, acc);
+    if (p.out3) epi_store8<BF>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, o, j0, acc);
   }
 }
 

@@ -1,13 +1,21 @@
-"""Fused inference engine: walks the TreeLearn module tree and issues HIP calls with
-BatchNorm(eval)+ReLU folded into conv prologues/epilogues, the residual add folded into the
-second conv's epilogue and the skip concat realised as column views of one [N, 2C] buffer.
+"""Fused inference engine: walks the TreeLearn module tree and issues HIP calls with eval-mode
+BatchNorm+ReLU, residual adds and the skip concat folded into the sparse-conv kernels.
 
-Per ResidualBlock (reference blocks.py:55-79):
-    t   = conv1( relu(bn0(x)) )            prologue bn0+relu ; epilogue bn3+relu  (t is only ever read through bn3)
-    out = conv2( t ) + i_branch(x)          epilogue residual add (x itself, or the 1x1 GEMM of x)
-Per UBlock (blocks.py:137-149): the last block of `blocks` writes straight into cat[:, :C]; the inverse
-conv writes cat[:, C:]; `blocks_tail.block0` reads cat as a [N, 2C] input.
+Dataflow ("pre-activated" form, default).  BatchNorm1d+ReLU always sits in FRONT of a conv in the
+reference (blocks.py:55-70,102-123), i.e. it would have to be applied to every gathered row -- up to 27x
+per voxel.  Instead the PRODUCER of a tensor writes, in its epilogue, every view its consumers need:
+    raw y                      (residual branch, blocks.py:76; 1x1 i_branch input; skip concat, blocks.py:146)
+    relu(bn_next(y))           (gather source of the next conv -- gathers become pure copies)
+through tl_conv_fwd's out / out2 / out3.  The skip concat is two column views of one [N, 2C] buffer
+(raw and activated variants), written by the encoder's last block and by the inverse conv.
+
+Per ResidualBlock (blocks.py:55-79):   t = conv1(x_act) [epilogue bn3+relu];  y = conv2(t) + i_branch(x_raw)
+Per UBlock (blocks.py:137-149):        blocks -> down conv -> child UBlock -> inverse conv -> tail blocks
+
+`TL_ENGINE=prologue` selects the older form (BN+ReLU applied as a gather-side prologue) for A/B runs.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -22,7 +30,83 @@ def _bn_affine(bn: nn.BatchNorm1d):
     return scale.contiguous(), shift.contiguous()
 
 
-class _ResPlan:
+class View:
+    """One requested view of a conv result: optional destination (column view), affine, relu."""
+    __slots__ = ("buf", "scale", "shift", "relu")
+
+    def __init__(self, scale=None, shift=None, relu=False, buf=None):
+        self.buf, self.scale, self.shift, self.relu = buf, scale, shift, relu
+
+
+RAW = lambda buf=None: View(buf=buf)                                   # noqa: E731
+ACT = lambda aff, buf=None: View(aff[0], aff[1], True, buf)            # noqa: E731
+
+
+def _conv_views(x, w, table, n, views, residual=None):
+    """Run one conv producing up to three views; returns the list of result tensors (same order)."""
+    outs = [v.buf if v.buf is not None else torch.empty((n, w.shape[1]), dtype=x.dtype, device=x.device) for v in views]
+    v0 = views[0]
+    extra = [(o, v.scale, v.shift, v.relu) for o, v in zip(outs[1:], views[1:])]
+    ops.conv_fwd(x, w, table, n, out=outs[0], residual=residual, out_scale=v0.scale, out_shift=v0.shift, out_relu=v0.relu,
+                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None)
+    return outs
+
+
+# ------------------------------------------------------------------------------------------- pre-activated form
+class _Res:
+    def __init__(self, block, dtype):
+        cb = block.conv_branch
+        self.bn0 = _bn_affine(cb[0])                                   # applied by the PRODUCER of this block's input
+        self.w1 = ops.pack_weight(cb[2].weight, dtype)
+        self.bn3 = _bn_affine(cb[3])
+        self.w2 = ops.pack_weight(cb[5].weight, dtype)
+        ib = block.i_branch[0]
+        self.w1x1 = None if isinstance(ib, nn.Identity) else ops.pack_weight(ib.weight, dtype)
+
+    def run(self, x_raw, x_act, nbr, n, views):
+        t = ops.conv_fwd(x_act, self.w1, nbr, n, out_scale=self.bn3[0], out_shift=self.bn3[1], out_relu=True)
+        res = x_raw if self.w1x1 is None else ops.conv_fwd(x_raw, self.w1x1, None, n)
+        return _conv_views(t, self.w2, nbr, n, views, residual=res)
+
+
+class _U:
+    def __init__(self, ub, dtype):
+        self.C = ub.nPlanes[0]
+        self.blocks = [_Res(b, dtype) for b in ub.blocks._modules.values()]
+        self.deeper = len(ub.nPlanes) > 1
+        if self.deeper:
+            C = self.C
+            self.bn_down = _bn_affine(ub.conv[0]); self.wd = ops.pack_weight(ub.conv[2].weight, dtype)
+            self.u = _U(ub.u, dtype)
+            self.bn_up = _bn_affine(ub.deconv[0]); self.wu = ops.pack_weight(ub.deconv[2].weight, dtype)
+            self.tail = [_Res(b, dtype) for b in ub.blocks_tail._modules.values()]
+            s, h = self.tail[0].bn0                                    # BN over the 2C concat: split per half
+            self.bn_cat_l = (s[:C].contiguous(), h[:C].contiguous())
+            self.bn_cat_r = (s[C:].contiguous(), h[C:].contiguous())
+
+    def run(self, x_raw, x_act, geom: TileGeometry, li, views):
+        """`views`: what the caller needs of this UBlock's output."""
+        lv = geom.levels[li]
+        n, C = lv.n, self.C
+        nb = len(self.blocks)
+        for i, b in enumerate(self.blocks[:-1]):
+            x_raw, x_act = b.run(x_raw, x_act, lv.nbr, n, [RAW(), ACT(self.blocks[i + 1].bn0)])
+        if not self.deeper:
+            return self.blocks[-1].run(x_raw, x_act, lv.nbr, n, views)
+        cat_raw = torch.empty((n, 2 * C), dtype=x_raw.dtype, device=x_raw.device)
+        cat_act = torch.empty((n, 2 * C), dtype=x_raw.dtype, device=x_raw.device)
+        _, _, xd = self.blocks[-1].run(x_raw, x_act, lv.nbr, n,
+                                       [RAW(cat_raw[:, :C]), ACT(self.bn_cat_l, cat_act[:, :C]), ACT(self.bn_down)])
+        nxt = geom.levels[li + 1]
+        d_raw, d_act = _conv_views(xd, self.wd, lv.child, nxt.n, [RAW(), ACT(self.u.blocks[0].bn0)])
+        (e_act,) = self.u.run(d_raw, d_act, geom, li + 1, [ACT(self.bn_up)])
+        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:]), ACT(self.bn_cat_r, cat_act[:, C:])])
+        y_raw, y_act = self.tail[0].run(cat_raw, cat_act, lv.nbr, n, [RAW(), ACT(self.tail[1].bn0)])
+        return self.tail[1].run(y_raw, y_act, lv.nbr, n, views)
+
+
+# ------------------------------------------------------------------------------------------- prologue form (A/B)
+class _ResPro:
     def __init__(self, block, dtype):
         cb = block.conv_branch
         self.s0, self.h0 = _bn_affine(cb[0])
@@ -39,18 +123,18 @@ class _ResPlan:
         return ops.conv_fwd(t, self.w2, nbr, n, out=out, residual=res)
 
 
-class _UPlan:
+class _UPro:
     def __init__(self, ub, dtype):
         self.C = ub.nPlanes[0]
-        self.blocks = [_ResPlan(b, dtype) for b in ub.blocks._modules.values()]
+        self.blocks = [_ResPro(b, dtype) for b in ub.blocks._modules.values()]
         self.deeper = len(ub.nPlanes) > 1
         if self.deeper:
             self.sd, self.hd = _bn_affine(ub.conv[0]); self.wd = ops.pack_weight(ub.conv[2].weight, dtype)
-            self.u = _UPlan(ub.u, dtype)
+            self.u = _UPro(ub.u, dtype)
             self.su, self.hu = _bn_affine(ub.deconv[0]); self.wu = ops.pack_weight(ub.deconv[2].weight, dtype)
-            self.tail = [_ResPlan(b, dtype) for b in ub.blocks_tail._modules.values()]
+            self.tail = [_ResPro(b, dtype) for b in ub.blocks_tail._modules.values()]
 
-    def run(self, x, geom: TileGeometry, li):
+    def run(self, x, geom, li):
         lv = geom.levels[li]
         n, C = lv.n, self.C
         if not self.deeper:
@@ -59,8 +143,7 @@ class _UPlan:
             return x
         cat = torch.empty((n, 2 * C), dtype=x.dtype, device=x.device)
         for i, b in enumerate(self.blocks):
-            last = i == len(self.blocks) - 1
-            x = b.run(x, lv.nbr, n, out=cat[:, :C] if last else None)          # identity -> left half
+            x = b.run(x, lv.nbr, n, out=cat[:, :C] if i == len(self.blocks) - 1 else None)
         nxt = geom.levels[li + 1]
         d = ops.conv_fwd(x, self.wd, lv.child, nxt.n, in_scale=self.sd, in_shift=self.hd, in_relu=True)
         d = self.u.run(d, geom, li + 1)
@@ -75,8 +158,9 @@ class InferencePlan:
     """Folded BatchNorms + packed weights of one TreeLearn module, for one compute dtype."""
     def __init__(self, model, dtype):
         self.dtype = dtype
+        self.preact = os.environ.get("TL_ENGINE", "preact") != "prologue"
         self.w_in = ops.pack_weight(model.input_conv[0].weight, dtype)
-        self.unet = _UPlan(model.unet, dtype)
+        self.unet = (_U if self.preact else _UPro)(model.unet, dtype)
         self.so, self.ho = _bn_affine(model.output_layer[0])
         w1, b1 = [], []
         for mlp in (model.semantic_linear, model.offset_linear):
@@ -90,6 +174,11 @@ class InferencePlan:
 
     def run(self, voxel_feats, geom: TileGeometry, want_backbone=True):
         lv = geom.levels[0]
-        x = ops.conv_fwd(voxel_feats.to(self.dtype).contiguous(), self.w_in, lv.nbr, lv.n)
-        x = self.unet.run(x, geom, 0)
+        vf = voxel_feats.to(self.dtype).contiguous()
+        if self.preact:
+            x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)])
+            (x,) = self.unet.run(x_raw, x_act, geom, 0, [RAW()])
+        else:
+            x = ops.conv_fwd(vf, self.w_in, lv.nbr, lv.n)
+            x = self.unet.run(x, geom, 0)
         return ops.head_mlp(x, geom.v2p, self.so, self.ho, self.w1, self.b1, self.w2, self.b2, want_backbone)

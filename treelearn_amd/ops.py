@@ -23,7 +23,8 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
-             in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False):
+             in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False,
+             out2=None, out3=None):
     """out[o] = epi(sum_k W[k] . pro(x[table[k][o]])); x / out / residual may be column views of wider
     row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused."""
     L = _hip.lib()
@@ -56,6 +57,18 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.out_shift = out_shift.data_ptr() if out_shift is not None else None
     a.out = out.data_ptr(); a.out_ld = out.stride(0)
     a.stats = None
+    # extra views: (tensor [n_out, Cout] (may be a column view), scale or None, shift or None, relu)
+    for name, spec in (("out2", out2), ("out3", out3)):
+        if spec is None:
+            setattr(a, name, None); setattr(a, name + "_ld", 0); setattr(a, name + "_scale", None); setattr(a, name + "_shift", None); setattr(a, name + "_relu", 0)
+            continue
+        t, sc, sh, relu = spec
+        if t.dtype != x.dtype or t.stride(1) != 1 or t.shape[0] != n_out or t.shape[1] != Cout:
+            raise ValueError(f"bad {name} view")
+        setattr(a, name, t.data_ptr()); setattr(a, name + "_ld", t.stride(0))
+        setattr(a, name + "_scale", sc.data_ptr() if sc is not None else None)
+        setattr(a, name + "_shift", sh.data_ptr() if sh is not None else None)
+        setattr(a, name + "_relu", int(bool(relu)))
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
