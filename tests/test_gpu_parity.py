@@ -350,3 +350,36 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
             vals, cnts = np.unique(ref[m], return_counts=True)
             agree += cnts.max() if c != -1 else int((ref[m] == -1).sum())
         assert agree / len(ours) >= 0.99, (n, k, agree / len(ours))
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 17001), (64, 32, 27, 16500), (32, 64, 8, 16400), (64, 32, 8, 20000), (64, 96, 8, 16390),
+                                               (96, 64, 8, 16385), (64, 32, 1, 20000), (64, 64, 27, 16500), (32, 32, 27, 300)])
+def test_conv_bf16_no_prologue_multi_output(cin, cout, K, n_out):
+    """Pre-activated form: no gather-side prologue, residual, three output views (raw, bn+relu, bn+relu) --
+    exercises the weights-in-LDS direct kernel (level-1 shapes), the tile kernel and the small-level kernel."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin + 3 * cout + K)
+    d = _dev()
+    n_in = n_out + 77 if K != 1 else n_out
+    x = _bf16_round(rng.normal(size=(n_in, cin)).astype(np.float32))
+    k = round(K ** (1 / 3))
+    w = _bf16_round((rng.normal(size=(cout, k, k, k, cin)) / np.sqrt(cin * K)).astype(np.float32))
+    table = rng.integers(-1, n_in, size=(n_out, K)).astype(np.int32)
+    table[rng.uniform(size=table.shape) < 0.6] = -1
+    if K == 1:
+        table = np.arange(n_in, dtype=np.int32)[:, None]
+    res = _bf16_round(rng.normal(size=(n_out, cout)).astype(np.float32))
+    s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32); h2 = rng.normal(0, 0.3, cout).astype(np.float32)
+    s3 = rng.uniform(0.5, 1.5, cout).astype(np.float32); h3 = rng.normal(0, 0.3, cout).astype(np.float32)
+    y = osp.conv_table(torch.from_numpy(x), torch.from_numpy(w), table, n_out).numpy() + res
+    T = lambda a, dt=torch.float32: torch.from_numpy(a).to(d).to(dt)
+    wp = ops.pack_weight(T(w), torch.bfloat16)
+    tab = None if K == 1 else torch.from_numpy(np.ascontiguousarray(table.T)).to(d)
+    wide = torch.zeros((n_out, 2 * cout), dtype=torch.bfloat16, device=d)               # out2 lands in the right half of a concat buffer
+    o3 = torch.empty((n_out, cout), dtype=torch.bfloat16, device=d)
+    out = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, residual=T(res, torch.bfloat16),
+                       out2=(wide[:, cout:], T(s2), T(h2), True), out3=(o3, T(s3), T(h3), True))
+    assert rel_err(out.float().cpu().numpy(), y) < 8e-3
+    assert rel_err(wide[:, cout:].float().cpu().numpy(), np.maximum(y * s2 + h2, 0)) < 8e-3
+    assert rel_err(o3.float().cpu().numpy(), np.maximum(y * s3 + h3, 0)) < 8e-3
+    assert float(wide[:, :cout].abs().max()) == 0.0

@@ -225,6 +225,7 @@ __global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __rest
 static int64_t g_small_rows = kSmallRows;
 static int g_dbg = 0;
 static int g_bf16_depth = 0, g_bf16_units = 0;   // 0 = kernel default
+static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
 
 extern "C" {
 
@@ -232,6 +233,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!key) return TL_ERR_ARG;
   if (!strcmp(key, "bf16_depth")) { g_bf16_depth = (int)value; return TL_OK; }
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
+  if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
   if (!strcmp(key, "small_rows")) { g_small_rows = value; return TL_OK; }
   if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
   return TL_ERR_ARG;
@@ -276,7 +278,13 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (a->dtype == TL_BF16 && aligned && vec_ok && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && a->Cout <= 224 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
+  {
+    if (g_direct) {
+      const int rc = tl_launch_conv_direct(p, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
     return tl_launch_conv_bf16(p, g_bf16_depth, g_bf16_units, s);
+  }
   const unsigned g = tl_grid(a->n_out * a->Cout, 256);
   if (a->dtype == TL_F32) k_conv_generic<float><<<g, 256, 0, s>>>(p);
   else k_conv_generic<__hip_bfloat16><<<g, 256, 0, s>>>(p);
