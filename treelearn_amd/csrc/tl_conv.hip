@@ -225,6 +225,7 @@ __global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __rest
 static int64_t g_small_rows = kSmallRows;
 static int g_dbg = 0;
 static int g_bf16_depth = 0, g_bf16_units = 0;   // 0 = kernel default
+static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
 
 extern "C" {
@@ -234,6 +235,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_depth")) { g_bf16_depth = (int)value; return TL_OK; }
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
+  if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
   if (!strcmp(key, "small_rows")) { g_small_rows = value; return TL_OK; }
   if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
   return TL_ERR_ARG;
@@ -281,6 +283,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   {
     if (g_direct) {
       const int rc = tl_launch_conv_direct(p, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
+    if (g_stream) {
+      const int rc = tl_launch_conv_stream(p, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     return tl_launch_conv_bf16(p, g_bf16_depth, g_bf16_units, s);

@@ -90,6 +90,9 @@ int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   
 // tl_conv_direct.hip
 int tl_launch_conv_direct(const ConvP& p, hipStream_t s);   // bf16, whole weight tensor resident in LDS, per-wave tiles
 
+// tl_conv_stream.hip
+int tl_launch_conv_stream(const ConvP& p, hipStream_t s);   // bf16, per-wave register gathers, weights streamed through LDS per tap
+
 // tl_conv_small.hip
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves
 int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s);   // Cin <= 8 (the 4-channel input conv)
