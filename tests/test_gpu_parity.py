@@ -353,7 +353,7 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
 
 
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 17001), (64, 32, 27, 16500), (32, 64, 8, 16400), (64, 32, 8, 20000), (64, 96, 8, 16390),
-                                               (96, 64, 8, 16385), (64, 32, 1, 20000), (64, 64, 27, 16500), (32, 32, 27, 300)])
+                                               (96, 64, 8, 16385), (64, 32, 1, 20000), (64, 64, 27, 16500), (32, 32, 27, 300), (4, 32, 27, 5000), (128, 64, 27, 16400), (96, 96, 27, 16390)])
 def test_conv_bf16_no_prologue_multi_output(cin, cout, K, n_out):
     """Pre-activated form: no gather-side prologue, residual, three output views (raw, bn+relu, bn+relu) --
     exercises the weights-in-LDS direct kernel (level-1 shapes), the tile kernel and the small-level kernel."""

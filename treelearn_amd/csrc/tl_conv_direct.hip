@@ -129,6 +129,81 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
   }
 }
 
+
+// ------------------------------------------------------------------ the 4-channel input conv on the matrix cores
+// Cin = 4, Cout = 32, K <= 28 (reference tree_learn.py:37-39, `input_conv`).  The reduction index is (tap, channel):
+// 27 x 4 = 108 -> seven 32x32x16 MFMA steps.  Lane (i, h) of step s holds channels 0..3 of taps 4s+2h and 4s+2h+1 of
+// row i: two 8-byte bounds-checked gathers; the weight fragments (7 x 16 B per lane) live in registers for the whole
+// kernel.  HBM-bound on the 108 B/voxel rulebook read and the output writes.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
+  constexpr int EP = 36;
+  __shared__ float Es[WAVES][32][EP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  // B fragments: W packed [K][32][4] bf16 = 8 B per (tap, column)
+  u32x4 bfrag[7];
+  const u32x2* w2 = reinterpret_cast<const u32x2*>(p.w);
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int t0 = 4 * s + 2 * fh, t1 = t0 + 1;
+    const u32x2 z = {0u, 0u};
+    const u32x2 b0 = t0 < p.K ? w2[t0 * 32 + fi] : z, b1 = t1 < p.K ? w2[t1 * 32 + fi] : z;
+    bfrag[s] = u32x4{b0[0], b0[1], b1[0], b1[1]};
+  }
+  const int in_ld_b = (int)(p.in_ld * 2);
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + 8;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
+  float* ew = &Es[wv][0][0];
+  for (int tile = blockIdx.x * WAVES + wv; tile < ntiles; tile += gridDim.x * WAVES) {
+    const int64_t row = (int64_t)tile * 32 + fi;
+    const bool rvalid = row < p.n_out;
+    int idx[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+      const int t = 4 * (q >> 1) + 2 * fh + (q & 1);
+      idx[q] = (rvalid && t < p.K) ? p.table[(int64_t)t * p.n_out + row] : -1;
+    }
+    u32x2 g[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q)
+      g[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((unsigned)idx[q] * (unsigned)in_ld_b), 0, 0));
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const u32x4 af = {g[2 * s][0], g[2 * s][1], g[2 * s + 1][0], g[2 * s + 1][1]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfrag[s]), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const char* res = (const char*)p.res;
+#pragma unroll
+    for (int e0 = 0; e0 < 2; ++e0) {
+      const int e = lane + e0 * 64, rr = e >> 2, cvv = e & 3;
+      const int64_t orow = (int64_t)tile * 32 + rr;
+      if (orow < p.n_out) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (res) {
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (orow * p.res_ld + cvv * 8) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
+        }
+        epi_store8<true>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, orow, cvv * 8, v);
+        if (p.out2) epi_store8<true>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, orow, cvv * 8, v);
+        if (p.out3) epi_store8<true>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, orow, cvv * 8, v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int K, int NB, int UN, int G, int WAVES>
 int launch(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)K * UN * NB * 32 * 64 + (size_t)WAVES * 32 * (NB * 32 + 4) * 4;
@@ -165,6 +240,13 @@ int dispatch(const ConvP& p, hipStream_t s) {
 // scratch within LDS, input view below 4 GB.  Returns TL_ERR_UNSUPPORTED when the shape is not covered.
 int tl_launch_conv_direct(const ConvP& p, hipStream_t s) {
   if (p.in_scale || p.in_relu) return TL_ERR_UNSUPPORTED;
+  if (p.Cin == 4 && p.Cout == 32 && p.K <= 28 && p.table && p.in_ld % 4 == 0 && (int64_t)p.n_in * p.in_ld * 2 < 0xFFFF0000ll) {
+    const int ntiles = (int)tl_cdiv(p.n_out, 32);
+    int grid = (int)tl_cdiv(ntiles, 8);
+    if (grid > 2048) grid = 2048;
+    k_conv_in4<8><<<grid, 512, 0, s>>>(p, ntiles);
+    return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+  }
   const int64_t ld_b = p.in_ld * 2, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 2;
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll)) return TL_ERR_UNSUPPORTED;
   if ((size_t)p.K * p.Cout * p.Cin * 2 > 112 * 1024) return TL_ERR_UNSUPPORTED;

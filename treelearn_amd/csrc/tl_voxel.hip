@@ -81,13 +81,19 @@ __global__ void __launch_bounds__(kBlock) k_point_coords(const float* __restrict
     }
     reinterpret_cast<int4*>(pc)[i] = make_int4(b, c[0], c[1], c[2]);
   }
+  // block-level reduction, then ONE set of atomics per block (same-address atomics serialise at ~12 ns each)
+  __shared__ int smx[kBlock / 64][4];
   for (int j = 0; j < 3; ++j) {
     for (int off = 32; off > 0; off >>= 1) mx[j] = max(mx[j], __shfl_xor(mx[j], off));
   }
   err = __any(err);
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) { for (int j = 0; j < 3; ++j) smx[threadIdx.x >> 6][j] = mx[j]; smx[threadIdx.x >> 6][3] = err; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int e = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { for (int j = 0; j < 3; ++j) mx[j] = max(mx[j], smx[w][j]); e |= smx[w][3]; }
     for (int j = 0; j < 3; ++j) atomicMax(&maxc[j], mx[j]);
-    if (err) atomicMax(&maxc[3], 1);
+    if (e) atomicMax(&maxc[3], 1);
   }
 }
 
@@ -330,7 +336,7 @@ int tl_voxel_point_coords(const float* xyz, const int64_t* batch_ids, int64_t N,
   hipStream_t s = tl_s(stream);
   k_init_minmax<<<tl_cdiv(B * 6 > 4 ? B * 6 : 4, 64), 64, 0, s>>>(ws_minmax, B, maxc);
   k_minmax<<<tl_grid(N, kBlock * 8) < 512 ? tl_grid(N, kBlock * 8) : 512, kBlock, 0, s>>>(xyz, batch_ids, N, B, ws_minmax);
-  k_point_coords<<<tl_grid(N, kBlock), kBlock, 0, s>>>(xyz, batch_ids, N, B, voxel_size, ws_minmax, pcoords, maxc);
+  k_point_coords<<<tl_grid(N, kBlock) < 1024 ? tl_grid(N, kBlock) : 1024, kBlock, 0, s>>>(xyz, batch_ids, N, B, voxel_size, ws_minmax, pcoords, maxc);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
