@@ -16,14 +16,15 @@ for key in ("bf16_depth", "bf16_units", "small_rows", "dbg", "direct", "stream")
 name = sys.argv[1] if len(sys.argv) > 1 else "config2"
 dtype = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 cfg = CONFIGS[name]
+SS = [500, 500, 1000] if cfg["voxel"] >= 0.1 else None
 t0 = time.time(); tile = make_tile(**cfg, seed=0); batch = make_batch([tile]); print("tile", time.time() - t0, flush=True)
-model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=cfg["voxel"], compute_dtype=dtype)
+model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=SS, voxel_size=cfg["voxel"], compute_dtype=dtype)
 model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 torch.cuda.synchronize(); print("model ready", flush=True)
 for it in range(3):
     t0 = time.time()
-    geom = build_geometry(g["coords"], g["batch_ids"], 1, cfg["voxel"], 7, [500, 500, 1000])
+    geom = build_geometry(g["coords"], g["batch_ids"], 1, cfg["voxel"], 7, SS)
     torch.cuda.synchronize(); print("geometry", time.time() - t0, [l.n for l in geom.levels], flush=True)
 ops.PROFILE = []
 with torch.no_grad():

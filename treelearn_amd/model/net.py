@@ -76,7 +76,10 @@ class TreeLearn(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch, return_loss):
-        backbone_output, v2p_map = self.forward_backbone(**batch)
+        # only the tensors the backbone reads cross PCIe here (the reference's cuda_cast also ships every label /
+        # mask / centre tensor of the batch, ~80 MB per tile that inference never touches; util/train.py:28-43)
+        backbone_output, v2p_map = self.forward_backbone(coords=batch['coords'], input_feats=batch['input_feats'],
+                                                         batch_ids=batch['batch_ids'], batch_size=batch['batch_size'])
         output = self.forward_head(backbone_output, v2p_map)
         if return_loss:
             output = self.get_loss(model_output=output, **batch)

@@ -7,17 +7,46 @@ import torch
 from .. import ops
 
 
+_GPU_KEYS = ("coords", "input_feats", "batch_ids", "masks_inner")
+
+
+def _to_device_async(batch, stream):
+    """Start the H2D copies of the tensors the forward needs on `stream` (non-blocking when the batch is pinned,
+    as the reference DataLoader's pin_memory=True makes it; util/train.py:140)."""
+    out = dict(batch)
+    with torch.cuda.stream(stream):
+        for k in _GPU_KEYS:
+            v = batch.get(k)
+            if torch.is_tensor(v) and not v.is_cuda:
+                out[k] = v.cuda(non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(stream)
+    return out, ev
+
+
 def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True):
     """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one small D2H
     instead of the reference's three full-tile `.cpu()` copies), `coords += centers`, and skip tiles
-    whose forward raises "... reach zero!!! ..." (pipeline.py:91-97)."""
+    whose forward raises "... reach zero!!! ..." (pipeline.py:91-97).  The next tile's H2D copy runs on a
+    side stream while the current tile computes."""
     outs = [[] for _ in range(8)]
+    use_gpu = torch.cuda.is_available()
+    copy_stream = torch.cuda.Stream() if use_gpu else None
+    vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
     with torch.no_grad():
         model.eval()
-        for batch in dataloader:
-            batch['voxel_size'] = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
+        it = iter(dataloader)
+        nxt = next(it, None)
+        staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+        while nxt is not None:
+            batch, (gbatch, ev) = nxt, staged
+            nxt = next(it, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            if nxt is not None:
+                staged = _to_device_async(nxt, copy_stream) if use_gpu else (nxt, None)
+            gbatch['voxel_size'] = vs
             try:
-                output = model(batch, return_loss=False)
+                output = model(gbatch, return_loss=False)
             except Exception as e:                                     # noqa: BLE001
                 if "reach zero!!!" in str(e):
                     if logger:
@@ -25,17 +54,19 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                                     'If this does not happen too often, the results should not be influenced.')
                     continue
                 raise
-            m = batch['masks_inner']
-            m_dev = m.to(output['offset_predictions'].device, non_blocking=True)
-            off = output['offset_predictions'][m_dev].cpu()
-            sem = output['semantic_prediction_logits'][m_dev].cpu()
+            dev = output['offset_predictions'].device
+            m_dev = gbatch['masks_inner'].to(dev)
+            idx = torch.nonzero(m_dev).squeeze(1)                      # one small sync; 4-5 % of the rows survive
+            off = output['offset_predictions'].index_select(0, idx).cpu()
+            sem = output['semantic_prediction_logits'].index_select(0, idx).cpu()
             bb = output['backbone_feats']
-            bb = bb[m_dev].cpu() if bb is not None else torch.zeros((int(m.sum()), 0))
-            coords = batch['coords'] + batch['centers']
-            outs[0].append(sem); outs[1].append(batch['semantic_labels'][m])
-            outs[2].append(off); outs[3].append(batch['offset_labels'][m])
-            outs[4].append(coords[m]); outs[5].append(batch['instance_labels'][m])
-            outs[6].append(bb); outs[7].append(batch['input_feats'][m])
+            bb = bb.index_select(0, idx).cpu() if bb is not None else torch.zeros((idx.shape[0], 0))
+            ci = idx.cpu()
+            sel = lambda t: t.index_select(0, ci) if not t.is_cuda else t.index_select(0, idx).cpu()   # noqa: E731
+            outs[0].append(sem); outs[1].append(sel(batch['semantic_labels']))
+            outs[2].append(off); outs[3].append(sel(batch['offset_labels']))
+            outs[4].append(sel(batch['coords']) + sel(batch['centers'])); outs[5].append(sel(batch['instance_labels']))
+            outs[6].append(bb); outs[7].append(sel(batch['input_feats']))
     if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
         return tuple(np.zeros((0,), np.float32) for _ in outs)
     return tuple(torch.cat(o, 0).numpy() for o in outs)
