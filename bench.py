@@ -81,6 +81,21 @@ def cpu_baseline(timeout_s=240):
         return dict(value=None, unit="Mpoints/s", cores=host_cores(), kind="port", sample=f"failed: {type(e).__name__}")
 
 
+def pmc_traffic(dtype, workload):
+    """HBM bytes per step of the conv launches from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, KB units, gfx950 half-count correction) -- collected offline, not in this run."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:                                    # noqa: BLE001
+            continue
+        if d.get("dtype") == dtype and d.get("workload") == workload:
+            best = (d, f)
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +110,7 @@ def main():
         print(json.dumps(cpu_baseline_worker()), flush=True)
         return
 
+    torch.set_num_threads(host_cores())
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
@@ -168,7 +184,12 @@ def main():
             ach = byts / (tot_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
                         mfma_tflops=flops / (tot_ms * 1e-3) / 1e12)
-        roof.update(kernel="k_conv_mfma (tl_conv_fwd)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
+        tr = pmc_traffic(args.dtype, args.workload)
+        if tr is not None:
+            roof["traffic"] = tr[0]["hbm_gb_per_step"]
+            roof["traffic_unit"] = "GB per step (sum over the conv launches; PMC 2*FETCH_SIZE+WRITE_SIZE)"
+            roof["traffic_source"] = os.path.relpath(tr[1], REPO)
+        roof.update(kernel="tl_conv_fwd family (k_conv_stream / k_conv_direct / k_conv_bf16 / k_conv_small / k_conv_in4)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
                     algorithmic_gflop_per_step=flops / 1e9, algorithmic_gb_per_step=byts / 1e9)
 
     if rank == 0:
