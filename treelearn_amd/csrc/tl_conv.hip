@@ -264,13 +264,19 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
                        (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));
   if (a->dtype == TL_BF16 && a->Cin == 4 && a->Cout == 32 && g_direct && out_vec && ((uintptr_t)a->in) % 8 == 0 && ((uintptr_t)a->weight) % 16 == 0 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0))) {
-    const int rc = tl_launch_conv_direct(p, s);
+    const int rc = tl_launch_conv_direct(p, TL_BF16, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (a->Cin <= 8 && a->Cout % 8 == 0 && a->Cout <= 64 && !a->in_scale && !a->in_relu && out_vec) return tl_launch_conv_tinycin(p, a->dtype, s);
   if (vec_ok && a->n_out <= g_small_rows && a->Cin % 32 == 0 && a->Cout % 32 == 0) return tl_launch_conv_small(p, a->dtype, s);
   const bool aligned = (a->in_ld % 4 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0) &&
                        (!a->in_scale || (((uintptr_t)a->in_scale) % 16 == 0 && ((uintptr_t)a->in_shift) % 16 == 0));
+  if (a->dtype == TL_F32 && aligned && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && !a->in_scale && !a->in_relu &&
+      (!a->residual || (a->res_ld % 4 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
+      (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
+    if (g_direct) { const int rc = tl_launch_conv_direct(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
+    if (g_stream) { const int rc = tl_launch_conv_stream(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
+  }
   if (a->dtype == TL_F32 && aligned && a->Cin % KC == 0 && a->Cout % 32 == 0 && a->Cout <= 224) {
     switch (a->Cout / 32) {
       case 1: return launch_mfma_f32<1>(p, s);
@@ -287,11 +293,11 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
   {
     if (g_direct) {
-      const int rc = tl_launch_conv_direct(p, s);
+      const int rc = tl_launch_conv_direct(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (g_stream) {
-      const int rc = tl_launch_conv_stream(p, s);
+      const int rc = tl_launch_conv_stream(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     return tl_launch_conv_bf16(p, g_bf16_depth, g_bf16_units, s);

@@ -1,52 +1,55 @@
-// bf16 sparse conv, "direct" form: for layers whose whole weight tensor fits in LDS (K*Cout*Cin*2 <= ~100 KB:
-// every level-1 conv of the U-Net, the level-1/2 down/up convs and 1x1s).
+// Sparse conv, "direct" form: for layers whose whole weight tensor fits in LDS (K*Cout*Cin*sizeof <= ~110 KB:
+// every level-1 conv of the U-Net, the level-1/2 down/up convs and 1x1s).  bf16 and fp32.
 //
 // Measured on MI355X (tools/dev_gather.py): MFMA-fragment-shaped buffer gathers (32 rows x 32 B per instruction)
 // of 64-B rows run as fast as the 8-lanes-per-row staging pattern (all 27 taps of the level-1 rulebook in 0.13 ms),
 // while the LDS-staged tile kernel spends most of its time on LDS round trips and one barrier per step.  So here:
-//   * all K taps of the weights are staged ONCE per workgroup in LDS (XOR-swizzled 64-B rows, conflict-free
+//   * all K taps of the weights are staged ONCE per workgroup in LDS (XOR-swizzled rows, conflict-free
 //     ds_read_b128 B-fragments) and the workgroup walks many 32-row tiles (persistent waves);
 //   * each WAVE owns a 32-row output tile end to end: A fragments are gathered straight from global memory into
 //     MFMA operand registers with buffer loads (absent neighbour = index -1 = out-of-range offset = hardware
 //     returns zeros: no masks, no clamps, no branches), taps grouped G at a time and double-buffered in registers;
 //   * no barrier and no LDS traffic for A in the main loop; code is straight-line, so hipcc keeps counted vmcnt;
-//   * all K taps are contracted (no tap skipping): at 5.5 of 27 present neighbours the MFMA work is still < 10 %
-//     of the kernel time, and skipping would need divergent control flow around the loads.
-// Deterministic (fixed summation order).  Epilogue identical to the tile kernel (LDS transposition, 16-B stores,
-// residual, up to three output views).
+//   * all K taps are contracted (no tap skipping): at 5.5 of 27 present neighbours the bf16 MFMA work is still
+//     < 10 % of the kernel time, and skipping would need divergent control flow around the loads.
+// Deterministic (fixed summation order).  Epilogue: LDS transposition, 16-B stores, residual, up to three views.
 #include "tl_conv_internal.h"
 
 namespace {
 
-template <int K, int NB, int UN, int G, int WAVES>
+template <bool BF16, int K, int NB, int UN, int G, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles) {
+  constexpr int EB = BF16 ? 2 : 4;                   // bytes per element
+  constexpr int UB = 32 * EB;                        // bytes of one 32-channel unit of a row
+  constexpr int NJ = UB / 32;                        // 16-B fragment pairs per unit (lane half h takes bytes j*32 + h*16)
+  constexpr int SLOTS = UB / 16;
   constexpr int COUT = NB * 32;
   constexpr int NG = (K + G - 1) / G;
   constexpr int EP = COUT + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ws = smem;                                                          // [K][UN][COUT][64 B], slot-swizzled
-  float* Es = reinterpret_cast<float*>(smem + (size_t)K * UN * COUT * 64);  // [WAVES][32][EP]
+  char* Ws = smem;                                                          // [K][UN][COUT][UB], 16-B slots swizzled
+  float* Es = reinterpret_cast<float*>(smem + (size_t)K * UN * COUT * UB);  // [WAVES][32][EP]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fi = lane & 31, fh = lane >> 5;
-  const int cin = UN * 32;
+  auto swz_of = [](int n) { return BF16 ? ((n >> 2) & 3) : ((n >> 1) & 7); };   // conflict-free b128 reads for 64-B / 128-B rows
 
   {  // stage every tap of the weights (global layout [K][Cout][Cin]) into LDS
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
-    constexpr int NVEC = K * COUT * UN * 4;
+    constexpr int NVEC = K * COUT * UN * SLOTS;
     for (int v = tid; v < NVEC; v += WAVES * 64) {
-      const int s = v & 3, c = (v >> 2) % UN, n = (v / (4 * UN)) % COUT, k = v / (4 * UN * COUT);
-      *reinterpret_cast<u32x4*>(Ws + ((k * UN + c) * COUT + n) * 64 + ((s ^ ((n >> 2) & 3)) * 16)) = wsrc[v];
+      const int s = v % SLOTS, c = (v / SLOTS) % UN, n = (v / (SLOTS * UN)) % COUT, k = v / (SLOTS * UN * COUT);
+      *reinterpret_cast<u32x4*>(Ws + ((k * UN + c) * COUT + n) * UB + ((s ^ swz_of(n)) * 16)) = wsrc[v];
     }
   }
   __syncthreads();
 
-  const int in_ld_b = (int)(p.in_ld * 2);
-  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)cin * 2;
+  const int in_ld_b = (int)(p.in_ld * EB);
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)UN * UB;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)(fh * 16);
-  const int swz = (fi >> 2) & 3;
-  const char* wl = Ws + fi * 64;
+  const int swz = swz_of(fi);
+  const char* wl = Ws + fi * UB;
   float* ew = Es + wv * 32 * EP;
 
   for (int tile = blockIdx.x * WAVES + wv; tile < ntiles; tile += gridDim.x * WAVES) {
@@ -62,8 +65,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-    u32x4 a[2][G][UN][2];
-    auto issue = [&](int g, u32x4 (&dst)[G][UN][2]) __attribute__((always_inline)) {
+    u32x4 a[2][G][UN][NJ];
+    auto issue = [&](int g, u32x4 (&dst)[G][UN][NJ]) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < G; ++t) {
         const int k = g * G + t;
@@ -72,8 +75,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
 #pragma unroll
           for (int c = 0; c < UN; ++c)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              dst[t][c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * 64 + j * 32), 0, 0));
+            for (int j = 0; j < NJ; ++j)
+              dst[t][c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
         }
       }
     };
@@ -88,19 +91,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
 #pragma unroll
           for (int c = 0; c < UN; ++c)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const bf16x8 af = __builtin_bit_cast(bf16x8, a[g & 1][t][c][j]);
+            for (int j = 0; j < NJ; ++j) {
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wl + ((k * UN + c) * COUT + nb * 32) * 64 + (((2 * j + fh) ^ swz) * 16));
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[nb], 0, 0, 0);
+                const u32x4 bf = *reinterpret_cast<const u32x4*>(wl + ((k * UN + c) * COUT + nb * 32) * UB + (((2 * j + fh) ^ swz) * 16));
+                mma16<BF16>(acc[nb], a[g & 1][t][c][j], bf);
               }
             }
         }
       }
     }
 
-    // epilogue (wave-private): acc -> LDS fp32 -> rows as 16-B vectors
+    // epilogue (wave-private): acc -> LDS fp32 -> rows as 8-channel vectors
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -108,27 +110,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     constexpr int VROW = NB * 4;
-    const char* res = (const char*)p.res;
     for (int e = lane; e < 32 * VROW; e += 64) {
       const int rr = e / VROW, cvv = e % VROW;
       const int64_t orow = (int64_t)tile * 32 + rr;
       if (orow >= p.n_out) continue;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (res) {
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (orow * p.res_ld + cvv * 8) * 2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
-      }
-      epi_store8<true>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, orow, cvv * 8, v);
-      if (p.out2) epi_store8<true>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, orow, cvv * 8, v);
-      if (p.out3) epi_store8<true>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, orow, cvv * 8, v);
+      epi_views8<BF16>(p, orow, cvv * 8, v);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 }
-
 
 // ------------------------------------------------------------------ the 4-channel input conv on the matrix cores
 // Cin = 4, Cout = 32, K <= 28 (reference tree_learn.py:37-39, `input_conv`).  The reduction index is (tap, channel):
@@ -204,13 +197,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   }
 }
 
-template <int K, int NB, int UN, int G, int WAVES>
+template <bool BF16, int K, int NB, int UN, int G, int WAVES>
 int launch(const ConvP& p, hipStream_t s) {
-  const size_t lds = (size_t)K * UN * NB * 32 * 64 + (size_t)WAVES * 32 * (NB * 32 + 4) * 4;
+  constexpr int UB = BF16 ? 64 : 128;
+  const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<K, NB, UN, G, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
@@ -219,16 +213,20 @@ int launch(const ConvP& p, hipStream_t s) {
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_direct<K, NB, UN, G, WAVES><<<grid, WAVES * 64, lds, s>>>(p, ntiles);
+  k_conv_direct<BF16, K, NB, UN, G, WAVES><<<grid, WAVES * 64, lds, s>>>(p, ntiles);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
-template <int K, int G>
+template <bool BF16, int K, int G>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
-  const size_t wbytes = (size_t)K * p.Cout * p.Cin * 2;
-#define TL_D(NB_, UN_)                                                                   \
-  if (nb == NB_ && un == UN_) return wbytes <= 64 * 1024 ? launch<K, NB_, UN_, G, 16>(p, s) : launch<K, NB_, UN_, G, 8>(p, s);
+  const size_t wbytes = (size_t)K * p.Cout * p.Cin * (BF16 ? 2 : 4);
+  // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
+#define TL_D(NB_, UN_)                                                                                               \
+  if (nb == NB_ && un == UN_) {                                                                                      \
+    if constexpr (BF16) return wbytes <= 64 * 1024 ? launch<true, K, NB_, UN_, G, 16>(p, s) : launch<true, K, NB_, UN_, G, 8>(p, s); \
+    else return launch<false, K, NB_, UN_, (G > 2 ? 2 : G), 8>(p, s);                                                \
+  }
   TL_D(1, 1) TL_D(1, 2) TL_D(2, 1) TL_D(2, 2) TL_D(2, 3) TL_D(3, 2) TL_D(1, 3) TL_D(3, 1)
 #undef TL_D
   return TL_ERR_UNSUPPORTED;
@@ -238,22 +236,32 @@ int dispatch(const ConvP& p, hipStream_t s) {
 
 // Eligibility (beyond the tile kernel's alignment rules): no gather-side prologue, whole weight tensor + epilogue
 // scratch within LDS, input view below 4 GB.  Returns TL_ERR_UNSUPPORTED when the shape is not covered.
-int tl_launch_conv_direct(const ConvP& p, hipStream_t s) {
+int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s) {
   if (p.in_scale || p.in_relu) return TL_ERR_UNSUPPORTED;
-  if (p.Cin == 4 && p.Cout == 32 && p.K <= 28 && p.table && p.in_ld % 4 == 0 && (int64_t)p.n_in * p.in_ld * 2 < 0xFFFF0000ll) {
+  const int eb = dtype == TL_BF16 ? 2 : 4;
+  if (dtype == TL_BF16 && p.Cin == 4 && p.Cout == 32 && p.K <= 28 && p.table && p.in_ld % 4 == 0 && (int64_t)p.n_in * p.in_ld * 2 < 0xFFFF0000ll) {
     const int ntiles = (int)tl_cdiv(p.n_out, 32);
     int grid = (int)tl_cdiv(ntiles, 8);
     if (grid > 2048) grid = 2048;
     k_conv_in4<8><<<grid, 512, 0, s>>>(p, ntiles);
     return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
   }
-  const int64_t ld_b = p.in_ld * 2, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 2;
+  if (p.Cin % 32 || p.Cout % 32) return TL_ERR_UNSUPPORTED;
+  const int64_t ld_b = p.in_ld * eb, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * eb;
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll)) return TL_ERR_UNSUPPORTED;
-  if ((size_t)p.K * p.Cout * p.Cin * 2 > 112 * 1024) return TL_ERR_UNSUPPORTED;
-  switch (p.K) {
-    case 27: return dispatch<27, 3>(p, s);
-    case 8: return dispatch<8, 2>(p, s);
-    case 1: return dispatch<1, 1>(p, s);
+  if ((size_t)p.K * p.Cout * p.Cin * eb > 112 * 1024) return TL_ERR_UNSUPPORTED;
+  if (dtype == TL_BF16) {
+    switch (p.K) {
+      case 27: return dispatch<true, 27, 3>(p, s);
+      case 8: return dispatch<true, 8, 2>(p, s);
+      case 1: return dispatch<true, 1, 1>(p, s);
+    }
+  } else {
+    switch (p.K) {
+      case 27: return dispatch<false, 27, 3>(p, s);
+      case 8: return dispatch<false, 8, 2>(p, s);
+      case 1: return dispatch<false, 1, 1>(p, s);
+    }
   }
   return TL_ERR_UNSUPPORTED;
 }

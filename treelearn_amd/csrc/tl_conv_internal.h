@@ -84,14 +84,49 @@ static __device__ __forceinline__ void epi_store8(void* base, int64_t ld, const 
   }
 }
 
+// ---- dtype-generic MFMA step and residual helpers (bf16: one 32x32x16 MFMA per 16-B fragment pair;
+// fp32: the 16 B are 4 channels -> four exact-fp32 32x32x2 MFMAs)
+template <bool BF16>
+static __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (BF16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  } else {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
+  }
+}
+template <bool BF16>
+static __device__ __forceinline__ void res_add8(const void* res, int64_t elem, float (&v)[8]) {   // v += res[elem .. elem+7]
+  if constexpr (BF16) {
+    const u32x4 rv = *reinterpret_cast<const u32x4*>((const uint16_t*)res + elem);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
+  } else {
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>((const float*)res + elem), r1 = *reinterpret_cast<const f32x4*>((const float*)res + elem + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[q + 4] += r1[q]; }
+  }
+}
+// the shared row-vector epilogue: v[8] = acc (+ residual) of channels c0..c0+7 of row `row` -> up to three views
+template <bool BF16>
+static __device__ __forceinline__ void epi_views8(const ConvP& p, int64_t row, int c0, float (&v)[8]) {
+  if (p.res) res_add8<BF16>(p.res, row * p.res_ld + c0, v);
+  epi_store8<BF16>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, row, c0, v);
+  if (p.out2) epi_store8<BF16>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, row, c0, v);
+  if (p.out3) epi_store8<BF16>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, row, c0, v);
+}
+
 // tl_conv_bf16.hip
 int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   // large levels, bf16 MFMA
 
 // tl_conv_direct.hip
-int tl_launch_conv_direct(const ConvP& p, hipStream_t s);   // bf16, whole weight tensor resident in LDS, per-wave tiles
+int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s);   // whole weight tensor resident in LDS, per-wave tiles
 
 // tl_conv_stream.hip
-int tl_launch_conv_stream(const ConvP& p, hipStream_t s);   // bf16, per-wave register gathers, weights streamed through LDS per tap
+int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s);   // per-wave register gathers, weights streamed through LDS per tap
 
 // tl_conv_small.hip
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves

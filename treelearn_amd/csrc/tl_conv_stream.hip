@@ -1,4 +1,4 @@
-// bf16 sparse conv, "stream" form: mid levels (C = 64..128) whose weights do not fit in LDS as a whole.
+// Sparse conv, "stream" form (bf16 and fp32): mid levels (C = 64..128) whose weights do not fit in LDS as a whole.
 //
 // Same idea as tl_conv_direct.hip -- every wave owns a 32-row output tile and gathers its MFMA A-fragments
 // straight from global memory into registers with bounds-checked buffer loads (absent neighbour -> zeros), prefetched
@@ -14,18 +14,19 @@ namespace {
 constexpr int WAVES = 8;
 constexpr int NT = WAVES * 64;
 
-template <int K, int NB, int UN, int DA, int OCC>
+template <bool BF16, int K, int NB, int UN, int DA, int OCC>
 __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
+  constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32, SLOTS = UB / 16;
   constexpr int COUT = NB * 32, CIN = UN * 32;
-  constexpr int BROW = CIN * 2 + 16;                  // LDS pitch of a weight row (one output channel, one tap): +16 B pad =>
+  constexpr int BROW = CIN * EB + 16;                  // LDS pitch of a weight row (one output channel, one tap): +16 B pad =>
                                                       // ds_read_b128 of 16 different rows at one column is conflict-free
-  constexpr int BSLOTS = UN * 4;                      // 16-B vectors per weight row
+  constexpr int BSLOTS = UN * SLOTS;                  // 16-B vectors per weight row
   constexpr int BVEC = COUT * BSLOTS;                 // 16-B vectors per tap
   constexpr int BPT = (BVEC + NT - 1) / NT;           // vectors per thread per tap
   constexpr int EP = 32 + 4;                          // epilogue pitch (floats), one 32-column block at a time
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Bs = smem;                                                          // [2][COUT][BROW]
-  float* Es = reinterpret_cast<float*>(smem + 2 * (size_t)COUT * BROW);     // [WAVES][32][EP]
+  float* Es = reinterpret_cast<float*>(smem);                               // epilogue alias of Bs: [WAVES][32][EP]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fi = lane & 31, fh = lane >> 5;
@@ -38,8 +39,8 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
 #pragma unroll
   for (int k = 0; k < K; ++k) idx[k] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
 
-  const int in_ld_b = (int)(p.in_ld * 2);
-  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * 2;
+  const int in_ld_b = (int)(p.in_ld * EB);
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * EB;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)(fh * 16);
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
@@ -50,15 +51,15 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-  u32x4 a[DA][UN][2];
+  u32x4 a[DA][UN][NJ];
   u32x4 bw[BPT];
-  auto issue_a = [&](int k, u32x4 (&dst)[UN][2]) __attribute__((always_inline)) {
+  auto issue_a = [&](int k, u32x4 (&dst)[UN][NJ]) __attribute__((always_inline)) {
     const unsigned base = (unsigned)idx[k] * (unsigned)in_ld_b + lane_off;
 #pragma unroll
     for (int c = 0; c < UN; ++c)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        dst[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * 64 + j * 32), 0, 0));
+      for (int j = 0; j < NJ; ++j)
+        dst[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
   };
   auto load_b = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
@@ -92,22 +93,21 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
 #pragma unroll
     for (int c = 0; c < UN; ++c)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 af = __builtin_bit_cast(bf16x8, a[k % DA][c][j]);
+      for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const int slot = c * 4 + 2 * j + fh;
-          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bl + nb * 32 * BROW + slot * 16);
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[nb], 0, 0, 0);
+          const int slot = c * SLOTS + 2 * j + fh;
+          const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + slot * 16);
+          mma16<BF16>(acc[nb], a[k % DA][c][j], bf);
         }
       }
     if (k + DA < K) issue_a(k + DA, a[k % DA]);
     if (k + 1 < K) __syncthreads();
   }
 
-  // epilogue, one 32-column block at a time through a wave-private LDS transposition buffer
+  // epilogue, one 32-column block at a time through a wave-private LDS transposition buffer (aliases the weight tiles)
+  __syncthreads();
   float* ew = Es + wv * 32 * EP;
-  const char* res = (const char*)p.res;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -122,15 +122,7 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
       if (orow < p.n_out) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const int c0 = nb * 32 + cvv * 8;
-        if (res) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (orow * p.res_ld + c0) * 2);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
-        }
-        epi_store8<true>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, orow, c0, v);
-        if (p.out2) epi_store8<true>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, orow, c0, v);
-        if (p.out3) epi_store8<true>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, orow, c0, v);
+        epi_views8<BF16>(p, orow, nb * 32 + cvv * 8, v);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -138,39 +130,52 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   }
 }
 
-template <int K, int NB, int UN, int DA>
+template <bool BF16, int K, int NB, int UN, int DA>
 int launch(ConvP p, hipStream_t s) {
-  constexpr int OCC = (NB * 16 + DA * UN * 8 + 40 <= 118) ? 4 : 2;      // rough VGPR need -> waves per SIMD to ask for
-  const size_t lds = 2 * (size_t)NB * 32 * (UN * 64 + 16) + (size_t)WAVES * 32 * 36 * 4;
+  constexpr int EB = BF16 ? 2 : 4;
+  constexpr int OCC = (NB * 16 + DA * UN * (BF16 ? 8 : 16) + 40 <= 118) ? 4 : 2;     // rough VGPR need -> waves per SIMD to ask for
+  const size_t wt = 2 * (size_t)NB * 32 * (UN * 32 * EB + 16), ep = (size_t)WAVES * 32 * 36 * 4;
+  const size_t lds = wt > ep ? wt : ep;
+  if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<K, NB, UN, DA, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
   p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32);
-  k_conv_stream<K, NB, UN, DA, OCC><<<p.nblk, NT, lds, s>>>(p);
+  k_conv_stream<BF16, K, NB, UN, DA, OCC><<<p.nblk, NT, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
-template <int K>
+template <bool BF16, int K>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
-#define TL_S(NB_, UN_, DA_) if (nb == NB_ && un == UN_) return launch<K, NB_, UN_, DA_>(p, s);
-  TL_S(2, 2, 3) TL_S(2, 4, 2) TL_S(3, 3, 2) TL_S(3, 6, 1) TL_S(4, 4, 2) TL_S(2, 3, 3) TL_S(3, 2, 3) TL_S(3, 4, 2) TL_S(4, 3, 2) TL_S(1, 2, 3) TL_S(2, 1, 3)
+  // (NB, UN, prefetch depth bf16, prefetch depth fp32)
+#define TL_S(NB_, UN_, DB_, DF_) if (nb == NB_ && un == UN_) return launch<BF16, K, NB_, UN_, (BF16 ? DB_ : DF_)>(p, s);
+  TL_S(2, 2, 3, 2) TL_S(2, 4, 2, 1) TL_S(3, 3, 2, 1) TL_S(3, 6, 1, 1) TL_S(4, 4, 2, 1) TL_S(2, 3, 3, 1) TL_S(3, 2, 3, 2) TL_S(3, 4, 2, 1)
+  TL_S(4, 3, 2, 1) TL_S(1, 2, 3, 2) TL_S(2, 1, 3, 2) TL_S(1, 1, 3, 2)
 #undef TL_S
   return TL_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-int tl_launch_conv_stream(const ConvP& p, hipStream_t s) {
+int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s) {
   if (p.in_scale || p.in_relu) return TL_ERR_UNSUPPORTED;
-  const int64_t ld_b = p.in_ld * 2, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 2;
+  const int eb = dtype == TL_BF16 ? 2 : 4;
+  const int64_t ld_b = p.in_ld * eb, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * eb;
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll)) return TL_ERR_UNSUPPORTED;
-  switch (p.K) {
-    case 27: return dispatch<27>(p, s);
-    case 8: return dispatch<8>(p, s);
+  if (dtype == TL_BF16) {
+    switch (p.K) {
+      case 27: return dispatch<true, 27>(p, s);
+      case 8: return dispatch<true, 8>(p, s);
+    }
+  } else {
+    switch (p.K) {
+      case 27: return dispatch<false, 27>(p, s);
+      case 8: return dispatch<false, 8>(p, s);
+    }
   }
   return TL_ERR_UNSUPPORTED;
 }
