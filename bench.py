@@ -201,6 +201,17 @@ def main():
                                         f"{n_pts} points/tile, 7-level 32-ch sparse U-Net fwd (30.1 M params, random init), 1 tile per GPU",
                                points_per_tile=n_pts, tiles_per_step=world),
                    roofline=roof)
+        if world == 1 and args.dtype == "bf16":
+            # the fp32 parity mode (the precision the 1e-3 parity gate is checked in), same tile, for reference
+            m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype=torch.float32)
+            m32.load_state_dict(model.state_dict(), strict=True); m32 = m32.cuda().eval()
+            with torch.no_grad():
+                for _ in range(2): m32(gbatch, return_loss=False)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(5): m32(gbatch, return_loss=False)
+                torch.cuda.synchronize(); d32 = (time.perf_counter() - t1) / 5
+            res["fp32_parity_mode"] = dict(value=n_pts / d32 / 1e6, unit="Mpoints/s", ms_per_step=d32 * 1e3)
+            del m32
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

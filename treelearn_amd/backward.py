@@ -6,9 +6,9 @@ gather-GEMM over the TRANSPOSED table with transposed weights --
     down k2s2 : gin[i] = sum_k W[k]^T gout[inv[k][i]]
     inverse   : gin[q] = sum_k W[k]^T gout[child[k][q]]
     1x1       : gin    = gout . W
-all through `tl_conv_fwd`.  wgrad (gW[k] = sum_o gout[o] (x) x[table[k][o]]) is, in this round, a per-tap
-row gather followed by a library GEMM on the GPU (torch.mm -> rocBLAS/hipBLASLt): it is a plain dense
-[Cout x N] x [N x Cin] product once the rows are gathered.  A fused HIP wgrad is the next step.
+all through `tl_conv_fwd`.  wgrad (gW[k] = sum_o gout[o] (x) x[table[k][o]]) is, in this round, one gather of
+all (row, tap) neighbour rows followed by a single library GEMM on the GPU (torch.mm -> rocBLAS/hipBLASLt):
+[Cout x N] x [N x K*Cin].  A fused HIP wgrad (no materialised gather) is the next step.
 """
 import torch
 
@@ -35,15 +35,16 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
         gx = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in)
     if need_gw:
         g32 = grad_out.float()
-        xpad = torch.cat([x.float(), x.new_zeros((1, ci), dtype=torch.float32)], 0)
-        gw = torch.empty((co, K, ci), dtype=torch.float32, device=x.device)
         if ref.table is None:
-            gw[:, 0, :] = g32.t() @ xpad[:-1]
+            gw = (g32.t() @ x.float()).reshape(co, 1, ci)
         else:
+            # one gather of every (row, tap) neighbour row ([N, K, Cin]; absent -> the appended zero row), then ONE
+            # [Cout x N] x [N x K*Cin] GEMM: a tall reduction the library handles far better than K thin ones
             n = x.shape[0]
-            for k in range(K):
-                idx = ref.table[k].long()
-                idx = torch.where(idx < 0, torch.full_like(idx, n), idx)
-                gw[:, k, :] = g32.t() @ xpad[idx]
+            xpad = torch.cat([x.float(), x.new_zeros((1, ci), dtype=torch.float32)], 0)
+            idx = ref.table.t().long()                                         # [n_out, K]
+            idx = torch.where(idx < 0, torch.full_like(idx, n), idx)
+            xg = xpad[idx].reshape(idx.shape[0], K * ci)
+            gw = (g32.t() @ xg).reshape(co, K, ci)
         gw = gw.reshape(weight.shape).to(weight.dtype)
     return gx, gw
