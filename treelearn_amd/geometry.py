@@ -35,6 +35,16 @@ class TileGeometry:
     n_points: int
     batch_size: int
     pcoords: torch.Tensor = None
+    _backing: list = field(default_factory=list)         # pooled buffers the per-level views alias
+
+    def tensors(self):
+        """Every device tensor of this geometry (for Tensor.record_stream when built on a side stream)."""
+        out = [self.v2p] + list(self._backing)
+        if self.pcoords is not None:
+            out.append(self.pcoords)
+        for lv in self.levels:
+            out += [t for t in (lv.coords, lv.nbr, lv.child, lv.parent, lv.inv) if t is not None]
+        return out
 
 
 def _nwords(d):
@@ -124,7 +134,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     v2p = torch.empty(N, dtype=torch.int64, device=dev)
     _hip.check(L.tl_point_rank(_hip.ptr(pcoords), N, _hip.ptr(levels[0].bitmap), _hip.ptr(levels[0].prefix), _hip.dims4(levels[0].dims),
                                _hip.ptr(v2p), st), "tl_point_rank")
-    return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords)
+    return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[bm_all, pf_all])
 
 
 def voxel_mean_feats(point_feats: torch.Tensor, geom: TileGeometry, max_points: int) -> torch.Tensor:

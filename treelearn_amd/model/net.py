@@ -35,6 +35,7 @@ class TreeLearn(nn.Module):
         self.compute_dtype = compute_dtype          # torch.float32 (parity) | torch.bfloat16 (throughput)
         self.return_backbone_feats = True           # reference always returns them (tree_learn.py:100)
         self._plan = None
+        self._geom_stream = None
 
         norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
         self.input_conv = spconv.SparseSequential(
@@ -116,6 +117,36 @@ class TreeLearn(nn.Module):
         if self._plan is None or self._plan.dtype != self.compute_dtype:
             self._plan = InferencePlan(self, self.compute_dtype)
         return (vfeats, geom), geom.v2p
+
+    # ------------------------------------------------------------------ two-phase inference (software-pipelined tile loop)
+    def prepare(self, batch):
+        """Phase 1 of an inference forward: H2D (if needed) + voxel hashing + all rulebooks, issued on a side stream.
+        Returns a handle for `infer`.  Calling `prepare(next_tile)` right after `infer(this_tile)` lets the next tile's
+        geometry (small latency-bound kernels + two host syncs) run while this tile's convs occupy the main stream."""
+        assert not self.training, "prepare/infer is the eval-mode fused path"
+        if self._plan is None or self._plan.dtype != self.compute_dtype:
+            self._plan = InferencePlan(self, self.compute_dtype)
+        if self._geom_stream is None:
+            self._geom_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._geom_stream.wait_stream(main)                            # inputs produced on the main stream are visible
+        with torch.cuda.stream(self._geom_stream), torch.no_grad():
+            mv = lambda t: t.cuda(non_blocking=True) if not t.is_cuda else t                 # noqa: E731
+            vfeats, geom = self._voxelize(mv(batch['coords']).float(), mv(batch['input_feats']).float(),
+                                          mv(batch['batch_ids']).long(), batch['batch_size'])
+            ev = torch.cuda.Event(); ev.record(self._geom_stream)
+        return (vfeats, geom, ev)
+
+    def infer(self, handle):
+        """Phase 2: the fused U-Net + heads on the current stream."""
+        vfeats, geom, ev = handle
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        with torch.no_grad():
+            bb, logits, offsets = self._plan.run(vfeats, geom, want_backbone=self.return_backbone_feats)
+        for t in geom.tensors() + [vfeats]:                            # allocated on the side stream, consumed on this one
+            t.record_stream(main)
+        return dict(backbone_feats=bb, semantic_prediction_logits=logits, offset_predictions=offsets)
 
     def forward_head(self, backbone_output, v2p_map):
         output = dict()

@@ -34,26 +34,46 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
     with torch.no_grad():
         model.eval()
+        two_phase = use_gpu and hasattr(model, "prepare") and hasattr(model, "infer")
+
+        def stage(b):
+            """H2D on the copy stream, then (two-phase models) voxel hashing + rulebooks on the model's side stream;
+            a tile whose U-Net would collapse raises here and is reported as skipped."""
+            gb, ev = _to_device_async(b, copy_stream) if use_gpu else (b, None)
+            if not two_phase:
+                return gb, ev, None, None
+            try:
+                torch.cuda.current_stream().wait_event(ev)
+                return gb, None, model.prepare(gb), None
+            except Exception as e:                                     # noqa: BLE001
+                return gb, None, None, e
+
         it = iter(dataloader)
         nxt = next(it, None)
-        staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+        staged = stage(nxt) if nxt is not None else None
         while nxt is not None:
-            batch, (gbatch, ev) = nxt, staged
-            nxt = next(it, None)
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-            if nxt is not None:
-                staged = _to_device_async(nxt, copy_stream) if use_gpu else (nxt, None)
+            batch, (gbatch, ev, handle, err) = nxt, staged
             gbatch['voxel_size'] = vs
             try:
-                output = model(gbatch, return_loss=False)
+                if err is not None:
+                    raise err
+                if two_phase:
+                    output = model.infer(handle)                       # convs of this tile go on the main stream ...
+                else:
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                    output = model(gbatch, return_loss=False)
             except Exception as e:                                     # noqa: BLE001
                 if "reach zero!!!" in str(e):
                     if logger:
                         logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
                                     'If this does not happen too often, the results should not be influenced.')
+                    nxt = next(it, None)
+                    staged = stage(nxt) if nxt is not None else None
                     continue
                 raise
+            nxt = next(it, None)
+            staged = stage(nxt) if nxt is not None else None           # ... while the next tile's geometry is built
             dev = output['offset_predictions'].device
             m_dev = gbatch['masks_inner'].to(dev)
             idx = torch.nonzero(m_dev).squeeze(1)                      # one small sync; 4-5 % of the rows survive
