@@ -180,6 +180,13 @@ int tl_hdbscan_mst(const float* xy, int64_t n, int min_samples, int32_t* e_src, 
 int tl_hdbscan_labels_host(const int32_t* e_src, const int32_t* e_dst, const double* e_w, int64_t n,
                            int min_cluster_size, int32_t* labels);
 
+/* ------------------------------------------------------------------ next-row helpers
+ * k-NN majority vote: replaces KNeighborsClassifier(n_neighbors=k).fit(ref, labels).predict(query) in
+ * assign_remaining_points_nearest_neighbor (tree_learn/util/pipeline.py:287-296).  ref_xyz f32[nr,3], ref_label i64[nr],
+ * q_xyz f32[nq,3] -> out_label i64[nq]; k in {1,3,5}; ties -> smallest label; fp64 distances. */
+int tl_knn_vote(const float* ref_xyz, const int64_t* ref_label, int64_t nr, const float* q_xyz, int64_t nq, int k,
+                int64_t* out_label, tl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

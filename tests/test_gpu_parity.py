@@ -383,3 +383,28 @@ def test_conv_bf16_no_prologue_multi_output(cin, cout, K, n_out):
     assert rel_err(wide[:, cout:].float().cpu().numpy(), np.maximum(y * s2 + h2, 0)) < 8e-3
     assert rel_err(o3.float().cpu().numpy(), np.maximum(y * s3 + h3, 0)) < 8e-3
     assert float(wide[:, :cout].abs().max()) == 0.0
+
+
+def test_next_rows_ensemble_and_knn_fill_vs_golden(golden_dir):
+    """SURVEY.md §8f #1/#2 against the reference's own outputs (goldens G6/G7)."""
+    from treelearn_amd.util.postprocess import assign_remaining_points_nearest_neighbor, ensemble
+    g = np.load(os.path.join(golden_dir, "g6_g7_next.npz"))
+    res = ensemble(g["e_coords"], g["e_sem"], g["e_seml"], g["e_off"], g["e_offl"], g["e_inst"], g["e_feats"], g["e_inf"])
+    for i, r in enumerate(res):
+        ref = g[f"e_out{i}"]
+        assert r.shape == ref.shape and r.dtype == ref.dtype, i
+        if r.dtype == np.int64:
+            np.testing.assert_array_equal(r, ref)
+        else:
+            np.testing.assert_allclose(r, ref, rtol=1e-6, atol=1e-6)
+    out = assign_remaining_points_nearest_neighbor(g["k_coords"], g["k_pred"], -1)
+    np.testing.assert_array_equal(out, g["k_out"])
+    # bigger random case against sklearn directly
+    from sklearn.neighbors import KNeighborsClassifier
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(20000, 3)).astype(np.float32) * 3
+    pred = rng.integers(1, 30, 20000).astype(np.int64); pred[rng.uniform(size=20000) < 0.4] = -1
+    ours = assign_remaining_points_nearest_neighbor(pts, pred, -1)
+    knn = KNeighborsClassifier(n_neighbors=5).fit(pts[pred != -1], pred[pred != -1])
+    ref = pred.copy(); ref[pred == -1] = knn.predict(pts[pred == -1])
+    np.testing.assert_array_equal(ours, ref)

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "tl_hdbscan_ws_bytes": (_i64, [_i64]),
     "tl_hdbscan_mst": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_hdbscan_labels_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "tl_knn_vote": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
 }
 
 _lib = None
