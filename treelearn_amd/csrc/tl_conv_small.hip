@@ -15,14 +15,24 @@ namespace {
 
 template <bool BF16, int NBB>
 __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
+  constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
+  constexpr int PF = 4;                                       // steps in flight per wave (independent loads issued together)
   __shared__ float red[4][NBB][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rt = blockIdx.x / ncolblk, cb = blockIdx.x % ncolblk;
   const int64_t row = (int64_t)rt * 32 + (lane & 31);
-  const int fh = lane >> 5;
+  const int fi = lane & 31, fh = lane >> 5;
   const int col0 = cb * NBB * 32;
   const int nchunk = p.Cin / 32;
   const int nsteps = p.K * nchunk;
+  const bool rvalid = row < p.n_out;
+  const bool pro = p.in_scale != nullptr || p.in_relu;
+
+  const int in_ld_b = (int)(p.in_ld * EB);
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)p.Cin * EB;
+  const bool buf_ok = in_bytes > 0 && in_bytes + 2 * (int64_t)in_ld_b < 0xFFFFFFFFll;       // else: clamp + mask path
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, buf_ok ? (int)in_bytes : 0, 0x00020000);
+  const char* inb = (const char*)p.in; const char* Wb = (const char*)p.w;
 
   f32x16 acc[NBB];
 #pragma unroll
@@ -30,73 +40,69 @@ __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-  for (int s = wv; s < nsteps; s += 4) {
-    const int k = s / nchunk, ch = s % nchunk;
-    int idx = -1;
-    if (row < p.n_out) idx = p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row;
-    if (!__any(idx >= 0)) continue;
-    if constexpr (BF16) {
-      const uint16_t* in = (const uint16_t*)p.in; const uint16_t* W = (const uint16_t*)p.w;
-      uint4 a[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-      if (idx >= 0) {
+  // The wave's steps are s = wv, wv+4, ...; PF of them are processed per iteration with all their loads issued before
+  // the first MFMA (deep levels are latency-bound: a few hundred rows, 27 x Cin/32 dependent load->MFMA chains).
+  for (int s0 = wv; s0 < nsteps; s0 += 4 * PF) {
+    int idx[PF]; int kk[PF], ch[PF];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) a[j] = *reinterpret_cast<const uint4*>(in + (int64_t)idx * p.in_ld + ch * 32 + j * 16 + fh * 8);
-        if (p.in_scale || p.in_relu) {
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + 4 * u;
+      const bool sv = s < nsteps;
+      kk[u] = sv ? s / nchunk : 0; ch[u] = sv ? s % nchunk : 0;
+      idx[u] = (sv && rvalid) ? (p.table ? p.table[(int64_t)kk[u] * p.n_out + row] : (int)row) : -1;
+    }
+    u32x4 a[PF][NJ], b[PF][NBB][NJ];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int c0 = ch * 32 + j * 16 + fh * 8;
-            uint32_t u[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const unsigned off = (unsigned)(ch[u] * UB + j * 32 + fh * 16);
+        if (buf_ok) a[u][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((unsigned)idx[u] * (unsigned)in_ld_b + off), 0, 0));
+        else {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(inb + (int64_t)max(idx[u], 0) * in_ld_b + off);
+          a[u][j] = idx[u] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBB; ++nb)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk[u] * p.Cout + col0 + nb * 32 + fi) * p.Cin + ch[u] * 32) * EB + j * 32 + fh * 16);
+    }
+    if (pro) {                                                // gather-side BatchNorm+ReLU (module-by-module path only)
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (idx[u] < 0) continue;
+          const int c0 = ch[u] * 32 + (j * 32 + fh * 16) / EB;
+          if constexpr (BF16) {
+            u32x4 v = a[u][j];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              float lo = bf16_lo(u[q]), hi = bf16_hi(u[q]);
+              float lo = bf16_lo(v[q]), hi = bf16_hi(v[q]);
               if (p.in_scale) { lo = fmaf(lo, p.in_scale[c0 + 2 * q], p.in_shift[c0 + 2 * q]); hi = fmaf(hi, p.in_scale[c0 + 2 * q + 1], p.in_shift[c0 + 2 * q + 1]); }
               if (p.in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-              u[q] = pack_bf16x2(lo, hi);
+              v[q] = pack_bf16x2(lo, hi);
             }
-            a[j] = make_uint4(u[0], u[1], u[2], u[3]);
+            a[u][j] = v;
+          } else {
+            f32x4 v = __builtin_bit_cast(f32x4, a[u][j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (p.in_scale) v[q] = fmaf(v[q], p.in_scale[c0 + q], p.in_shift[c0 + q]);
+              if (p.in_relu) v[q] = fmaxf(v[q], 0.f);
+            }
+            a[u][j] = __builtin_bit_cast(u32x4, v);
           }
         }
-      }
-#pragma unroll
-      for (int nb = 0; nb < NBB; ++nb) {
-        const uint16_t* wr = W + ((int64_t)k * p.Cout + col0 + nb * 32 + (lane & 31)) * p.Cin + ch * 32 + fh * 8;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const uint4 b = *reinterpret_cast<const uint4*>(wr + j * 16);
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b), acc[nb], 0, 0, 0);
-        }
-      }
-    } else {
-      const float* in = (const float*)p.in; const float* W = (const float*)p.w;
-      float4 a[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx >= 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c0 = ch * 32 + fh * 4 + 8 * j;
-          float4 v = *reinterpret_cast<const float4*>(in + (int64_t)idx * p.in_ld + c0);
-          if (p.in_scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(p.in_scale + c0), sh = *reinterpret_cast<const float4*>(p.in_shift + c0);
-            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-          }
-          if (p.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          a[j] = v;
-        }
-      }
-#pragma unroll
-      for (int nb = 0; nb < NBB; ++nb) {
-        const float* wr = W + ((int64_t)k * p.Cout + col0 + nb * 32 + (lane & 31)) * p.Cin + ch * 32 + fh * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 b = *reinterpret_cast<const float4*>(wr + 8 * j);
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b.x, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b.y, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b.z, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b.w, acc[nb], 0, 0, 0);
-        }
-      }
     }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int nb = 0; nb < NBB; ++nb)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mma16<BF16>(acc[nb], a[u][j], b[u][nb][j]);   // steps past the end hold zero A fragments
   }
 
 #pragma unroll
