@@ -7,7 +7,7 @@ from treelearn_amd.geometry import build_geometry
 from treelearn_amd.synth import CONFIGS, make_tile
 L = _hip.lib()
 fns = {}
-for nm in ("tl_dev_gather_bench", "tl_dev_gather_frag"):
+for nm in ("tl_dev_gather_bench", "tl_dev_gather_frag", "tl_dev_gather_quad"):
     f = getattr(L, nm); f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     fns[nm] = f
@@ -23,6 +23,7 @@ for level in (0, 1, 2):
     for nm, tif in [(a, b) for a in fns for b in (1, 3, 9)]:
         fn = fns[nm]
         if C == 96 and tif == 9: continue
+        if nm.endswith("quad") and C != 64: continue
         for _ in range(2): fn(x.data_ptr(), C * 2, C * 2, lv.nbr.data_ptr(), 27, lv.n, tif, sink.data_ptr(), _hip.stream())
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

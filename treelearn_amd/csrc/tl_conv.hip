@@ -226,6 +226,7 @@ static int64_t g_small_rows = kSmallRows;
 static int g_dbg = 0;
 static int g_bf16_depth = 0, g_bf16_units = 0;   // 0 = kernel default
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
+static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
 
 extern "C" {
@@ -236,6 +237,8 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
   if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
+  if (!strcmp(key, "streamq")) { g_streamq = (int)value; return TL_OK; }
+  if (!strcmp(key, "stream_rb")) return tl_stream_set_rb((int)value);
   if (!strcmp(key, "small_rows")) { g_small_rows = value; return TL_OK; }
   if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
   return TL_ERR_ARG;
@@ -294,6 +297,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   {
     if (g_direct) {
       const int rc = tl_launch_conv_direct(p, TL_BF16, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
+    if (g_stream && g_streamq) {
+      const int rc = tl_launch_conv_streamq(p, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (g_stream) {

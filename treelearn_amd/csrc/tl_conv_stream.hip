@@ -1,12 +1,17 @@
 // Sparse conv, "stream" form (bf16 and fp32): mid levels (C = 64..128) whose weights do not fit in LDS as a whole.
 //
-// Same idea as tl_conv_direct.hip -- every wave owns a 32-row output tile and gathers its MFMA A-fragments
+// Same idea as tl_conv_direct.hip -- every wave owns its output rows end to end and gathers its MFMA A-fragments
 // straight from global memory into registers with bounds-checked buffer loads (absent neighbour -> zeros), prefetched
-// DA taps ahead -- but the weights are streamed: the workgroup (8 waves = 256 rows) stages ONE tap's [Cout x Cin]
-// slice per step in a double-buffered LDS tile (16 B per thread), so the per-step barrier only guards 8-32 KB
-// of weights; the A operand never touches LDS.  Compared with the tile kernel this removes two thirds of the LDS
-// traffic, all staging VALU work and the rulebook-in-LDS phase.  The tap loop is fully unrolled and branch-free
-// (counted vmcnt survives), all K taps are contracted.  Deterministic.
+// DA taps ahead -- but the weights are streamed: the workgroup (8 waves) stages ONE tap's [Cout x Cin] slice per step
+// in a double-buffered LDS tile (16 B per thread), so the per-step barrier only guards 8-32 KB of weights; the A
+// operand never touches LDS.  The tap loop is fully unrolled and branch-free (counted vmcnt survives), all K taps are
+// contracted.  Deterministic.
+//
+// RB = 32-row blocks per wave.  Ablations on the level-2 conv (C = 64, bf16): without gathers 0.28 of 0.43 ms remain,
+// without the barrier nothing changes, deeper prefetch changes nothing -- what remains is LDS read bandwidth: with one
+// row block per wave every 32x32x16 MFMA (32 cycles on one SIMD) needs its own 1 KB ds_read_b128 weight fragment, i.e.
+// 4 SIMDs x 1 KB / 32 clk = 128 B/clk = the whole LDS read rate of a CU.  With RB = 2 each weight fragment feeds two
+// MFMAs (two row blocks), halving the LDS traffic per flop.
 #include "tl_conv_internal.h"
 
 namespace {
@@ -14,7 +19,9 @@ namespace {
 constexpr int WAVES = 8;
 constexpr int NT = WAVES * 64;
 
-template <bool BF16, int K, int NB, int UN, int DA, int OCC>
+__device__ unsigned long long g_tm[8];   // developer timing mode (tl_dev_stream_tm): cycles summed over waves per step segment
+
+template <bool BF16, int K, int NB, int UN, int DA, int RB, int OCC, bool TM = false>
 __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32, SLOTS = UB / 16;
   constexpr int COUT = NB * 32, CIN = UN * 32;
@@ -23,7 +30,8 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   constexpr int BSLOTS = UN * SLOTS;                  // 16-B vectors per weight row
   constexpr int BVEC = COUT * BSLOTS;                 // 16-B vectors per tap
   constexpr int BPT = (BVEC + NT - 1) / NT;           // vectors per thread per tap
-  constexpr int EP = 32 + 4;                          // epilogue pitch (floats), one 32-column block at a time
+  constexpr int EP = 32 + 4;                          // epilogue pitch (floats), one 32x32 block at a time
+  constexpr int WROWS = 32 * RB;                      // rows per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Bs = smem;                                                          // [2][COUT][BROW]
   float* Es = reinterpret_cast<float*>(smem);                               // epilogue alias of Bs: [WAVES][32][EP]
@@ -31,13 +39,16 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fi = lane & 31, fh = lane >> 5;
   const int tile = xcd_tile(blockIdx.x, p.nblk);
-  const int64_t r0 = (int64_t)tile * (WAVES * 32) + wv * 32;
-  const int64_t row = r0 + fi;
-  const bool rvalid = row < p.n_out;
+  const int64_t r0 = (int64_t)tile * (WAVES * WROWS) + wv * WROWS;
 
-  int idx[K];
+  int idx[K][RB];
 #pragma unroll
-  for (int k = 0; k < K; ++k) idx[k] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+  for (int rb = 0; rb < RB; ++rb) {
+    const int64_t row = r0 + rb * 32 + fi;
+    const bool rvalid = row < p.n_out;
+#pragma unroll
+    for (int k = 0; k < K; ++k) idx[k][rb] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+  }
 
   const int in_ld_b = (int)(p.in_ld * EB);
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * EB;
@@ -45,50 +56,75 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   const unsigned lane_off = (unsigned)(fh * 16);
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
 
-  f32x16 acc[NB];
+  f32x16 acc[RB][NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][nb][i] = 0.f;
 
-  u32x4 a[DA][UN][NJ];
-  u32x4 bw[BPT];
-  auto issue_a = [&](int k, u32x4 (&dst)[UN][NJ]) __attribute__((always_inline)) {
-    const unsigned base = (unsigned)idx[k] * (unsigned)in_ld_b + lane_off;
+  // Weights of tap t are requested at step t - WA, *before* that step's gathers, and written to LDS at step t - 1.  With
+  // the in-order vmcnt this is the only placement where waiting for them does not also wait for younger gathers: the
+  // loads older than weights(t+1) at the top of step t are exactly gathers(<= t), which step t needs anyway.
+  constexpr int WA = DA > 2 ? DA : 2, RW = WA - 1;
+  u32x4 a[DA][RB][UN][NJ];
+  u32x4 bw[RW][BPT], bw0[BPT];
+  auto issue_a = [&](int k, u32x4 (&dst)[RB][UN][NJ]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < UN; ++c)
+    for (int rb = 0; rb < RB; ++rb) {
+      const unsigned base = (unsigned)idx[k][rb] * (unsigned)in_ld_b + lane_off;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        dst[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
+      for (int c = 0; c < UN; ++c)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          dst[rb][c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
+    }
   };
-  auto load_b = [&](int k) __attribute__((always_inline)) {
+  auto load_b = [&](int k, u32x4 (&dst)[BPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
       const int v = tid + q * NT;
-      bw[q] = wsrc[(int64_t)k * BVEC + (BVEC % NT == 0 ? v : min(v, BVEC - 1))];
+      dst[q] = wsrc[(int64_t)k * BVEC + (BVEC % NT == 0 ? v : min(v, BVEC - 1))];
     }
   };
-  auto store_b = [&](int buf) __attribute__((always_inline)) {
+  auto store_b = [&](int buf, const u32x4 (&src)[BPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
       const int v = tid + q * NT;
       const int n = v / BSLOTS, s = v % BSLOTS;
-      if (BVEC % NT == 0 || v < BVEC) *reinterpret_cast<u32x4*>(Bs + buf * COUT * BROW + n * BROW + s * 16) = bw[q];
+      if (BVEC % NT == 0 || v < BVEC) *reinterpret_cast<u32x4*>(Bs + buf * COUT * BROW + n * BROW + s * 16) = src[q];
     }
   };
 
-  // prologue: weights of tap 0 -> LDS, taps 0..DA-1 of A in flight, weights of tap 1 in registers
-  load_b(0);
+  // prologue: weights of tap 0 -> LDS; taps 1..WA-1 of the weights and 0..DA-1 of A in flight, interleaved in tap order
+  load_b(0, bw0);
 #pragma unroll
-  for (int d = 0; d < DA; ++d) if (d < K) issue_a(d, a[d]);
-  store_b(0);
-  if (K > 1) load_b(1);
+  for (int d = 0; d < WA; ++d) {
+    if (d >= 1 && d < K) load_b(d, bw[d % RW]);
+    if (d < DA && d < K) issue_a(d, a[d]);
+  }
+  store_b(0, bw0);
   __syncthreads();
 
+  [[maybe_unused]] unsigned long long tm[4] = {0, 0, 0, 0}, tprev = 0;
+  auto tick = [&](int seg) __attribute__((always_inline)) {
+    if constexpr (TM) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (seg >= 0) tm[seg] += t - tprev;
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  tick(-1);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (k + 1 < K) store_b((k + 1) & 1);                  // tap k+1's weights (loaded last step) -> other buffer
-    if (k + 2 < K) load_b(k + 2);
+    if (k + 1 < K) store_b((k + 1) & 1, bw[(k + 1) % RW]);     // tap k+1's weights -> the buffer step k-1 was reading
+    if (k + WA < K) load_b(k + WA, bw[(k + WA) % RW]);          // the slot just emptied
+    __builtin_amdgcn_sched_barrier(0);                         // keep the request up here (hipcc sinks it below the MFMAs)
+    if constexpr (TM) { if (k + DA < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (RB * UN * NJ + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
+    tick(0);
     const char* bl = Bs + (k & 1) * COUT * BROW + fi * BROW;
 #pragma unroll
     for (int c = 0; c < UN; ++c)
@@ -98,68 +134,114 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
         for (int nb = 0; nb < NB; ++nb) {
           const int slot = c * SLOTS + 2 * j + fh;
           const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + slot * 16);
-          mma16<BF16>(acc[nb], a[k % DA][c][j], bf);
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) mma16<BF16>(acc[rb][nb], a[k % DA][rb][c][j], bf);   // one weight fragment, RB MFMAs
         }
       }
+    tick(1);
     if (k + DA < K) issue_a(k + DA, a[k % DA]);
+    tick(2);
     if (k + 1 < K) __syncthreads();
+    tick(3);
+  }
+  if constexpr (TM) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(&g_tm[i], tm[i]);
+      atomicAdd(&g_tm[4], 1ull);
+    }
   }
 
-  // epilogue, one 32-column block at a time through a wave-private LDS transposition buffer (aliases the weight tiles)
+  // epilogue, one 32x32 block at a time through a wave-private LDS transposition buffer (aliases the weight tiles)
   __syncthreads();
   float* ew = Es + wv * 32 * EP;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[nb][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-    for (int e0 = 0; e0 < 2; ++e0) {
-      const int e = lane + e0 * 64;                        // 32 rows x 4 vectors
-      const int rr = e >> 2, cvv = e & 3;
-      const int64_t orow = r0 + rr;
-      if (orow < p.n_out) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        epi_views8<BF16>(p, orow, nb * 32 + cvv * 8, v);
+      for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[rb][nb][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e0 = 0; e0 < 2; ++e0) {
+        const int e = lane + e0 * 64;                        // 32 rows x 4 vectors of 8 channels
+        const int rr = e >> 2, cvv = e & 3;
+        const int64_t orow = r0 + rb * 32 + rr;
+        if (orow < p.n_out) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          epi_views8<BF16>(p, orow, nb * 32 + cvv * 8, v);
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
 }
 
-template <bool BF16, int K, int NB, int UN, int DA>
+template <bool BF16, int K, int NB, int UN, int DA, int RB, bool TM = false>
 int launch(ConvP p, hipStream_t s) {
   constexpr int EB = BF16 ? 2 : 4;
-  constexpr int OCC = (NB * 16 + DA * UN * (BF16 ? 8 : 16) + 40 <= 118) ? 4 : 2;     // rough VGPR need -> waves per SIMD to ask for
+  constexpr int BPTL = (NB * 32 * UN * (BF16 ? 4 : 8) + NT - 1) / NT;
+  constexpr int VG = RB * NB * 16 + DA * RB * UN * (BF16 ? 8 : 16) + (K <= 8 ? 8 : 27) * RB + 4 * BPTL * (DA > 2 ? DA - 1 : 1) + 20;   // rough VGPR need
+  constexpr int OCC = VG <= 120 ? 4 : 2;
   const size_t wt = 2 * (size_t)NB * 32 * (UN * 32 * EB + 16), ep = (size_t)WAVES * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
-  p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32);
-  k_conv_stream<BF16, K, NB, UN, DA, OCC><<<p.nblk, NT, lds, s>>>(p);
+  p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32 * RB);
+  k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM><<<p.nblk, NT, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
+
+int g_stream_da = 0;
+int g_stream_tm = 0;     // developer timing mode on the 64->64 bf16 shape
+int g_stream_rb = 0;     // bf16: 32-row blocks per wave (tl_set_tuning "stream_rb"): 1, 2, or 0 = measured best per shape (2 for 96->96)
 
 template <bool BF16, int K>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
-  // (NB, UN, prefetch depth bf16, prefetch depth fp32)
-#define TL_S(NB_, UN_, DB_, DF_) if (nb == NB_ && un == UN_) return launch<BF16, K, NB_, UN_, (BF16 ? DB_ : DF_)>(p, s);
-  TL_S(2, 2, 3, 2) TL_S(2, 4, 2, 1) TL_S(3, 3, 2, 1) TL_S(3, 6, 1, 1) TL_S(4, 4, 2, 1) TL_S(2, 3, 3, 1) TL_S(3, 2, 3, 2) TL_S(3, 4, 2, 1)
-  TL_S(4, 3, 2, 1) TL_S(1, 2, 3, 2) TL_S(2, 1, 3, 2) TL_S(1, 1, 3, 2)
+  if constexpr (BF16 && K == 27) {
+    if (g_stream_tm && nb == 2 && un == 2) return launch<true, 27, 2, 2, 3, 1, true>(p, s);
+    if (g_stream_da && nb == 2 && un == 2) {                  // developer A/B of the prefetch depth on the 64->64 shape
+      if (g_stream_da == 2) return launch<true, 27, 2, 2, 2, 1>(p, s);
+      if (g_stream_da == 4) return launch<true, 27, 2, 2, 4, 1>(p, s);
+      if (g_stream_da == 5) return launch<true, 27, 2, 2, 5, 1>(p, s);
+    }
+  }
+  // (NB, UN): bf16 with one row block per wave (prefetch depth DB1) or two (DB2, 0 = not offered); fp32: one (depth DF)
+#define TL_S(NB_, UN_, DB1_, DB2_, DF_)                                                              \
+  if (nb == NB_ && un == UN_) {                                                                      \
+    if constexpr (BF16) {                                                                            \
+      if (DB2_ > 0 && (g_stream_rb == 2 || (g_stream_rb == 0 && NB_ == 3 && UN_ == 3))) return launch<true, K, NB_, UN_, (DB2_ > 0 ? DB2_ : 1), 2>(p, s); \
+      return launch<true, K, NB_, UN_, DB1_, 1>(p, s);                                               \
+    } else return launch<false, K, NB_, UN_, DF_, 1>(p, s);                                          \
+  }
+  TL_S(2, 2, 3, 2, 2) TL_S(2, 4, 2, 1, 1) TL_S(3, 3, 2, 1, 1) TL_S(3, 6, 1, 0, 1) TL_S(4, 4, 2, 0, 1) TL_S(2, 3, 3, 1, 1) TL_S(3, 2, 3, 2, 2)
+  TL_S(3, 4, 2, 1, 1) TL_S(4, 3, 2, 1, 1) TL_S(1, 2, 3, 2, 2) TL_S(2, 1, 3, 2, 2) TL_S(1, 1, 3, 2, 2)
 #undef TL_S
   return TL_ERR_UNSUPPORTED;
 }
 
 }  // namespace
+
+int tl_stream_set_rb(int rb) { if (rb >= 100) g_stream_da = rb - 100; else g_stream_rb = rb; return TL_OK; }
+
+// Developer hook (not part of the C ABI): switch the per-segment cycle counters on/off, read and clear them.
+extern "C" int tl_dev_stream_tm(int enable, unsigned long long* out8) {
+  g_stream_tm = enable;
+  if (out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tm), sizeof(g_tm)) != hipSuccess) return TL_ERR_LAUNCH;
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tm), z, sizeof(z)) != hipSuccess) return TL_ERR_LAUNCH;
+  }
+  return TL_OK;
+}
 
 int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s) {
   if (p.in_scale || p.in_relu) return TL_ERR_UNSUPPORTED;

@@ -1,0 +1,271 @@
+// Sparse conv, "stream-q" form (bf16, Cin a multiple of 64): tl_conv_stream.hip with coalesced gathers.
+//
+// Why: a 32x32x16 MFMA wants its A operand as (lane & 31) = row, (lane >> 5) = which 16 B of the row -- loading that shape
+// straight from global memory makes every lane of a buffer_load_b128 its own 16-B request (32 rows x 2 pieces per
+// instruction).  Measured on the level-2 rulebook (tools/dev_gather.py): 27 taps of such gathers alone take 0.26 ms, while
+// the same bytes fetched with four ADJACENT lanes reading 64 contiguous bytes take 0.135 ms -- the texture-address path
+// works on quads.  And tools/dev_stream_tm.py showed the stream kernel's waves stalled a quarter of their time just
+// issuing the fragment-shaped loads (the request queue was full) and another third at the per-tap barrier behind them.
+//
+// So here a wave gathers its 32 rows quad-wise -- load i (0..3) of a 128-B part: lane l reads row ((l>>2)&7) + 8 i, bytes
+// 64 (l>>5) + 16 (l&3) .. +16, i.e. 8 whole rows per instruction -- and then turns (load index) x (lane & 3) around in
+// registers: two butterfly stages of v_cndmask + quad-permute DPP (lane bit 0 <-> load bit 0, lane bit 1 <-> load bit 1).
+// Afterwards register s (0..3) of lane l holds 16-B piece s + 4 (l>>5) of tile row rho(l & 31) = ((l>>2)&7) + 8 (l&3):
+// a valid A operand for k-step s if (1) the weight fragment of k-step s, half h is read from piece s + 4 h (free: the
+// order of the contraction index is ours) and (2) MFMA row m is written back as tile row rho(m) in the epilogue.
+// The VALU work (32 ops per 128-B part and tap) rides on the otherwise idle vector ALU next to the MFMAs.
+//
+// Row indices: each tap needs 4 per lane now (rows q + 8 i), so the wave's [K][32] slice of the rulebook is parked in LDS once
+// (as [K][8][4] -> one broadcast ds_read_b128 per tap) instead of 27 registers per lane.
+// Weight streaming, double buffering, request order (weights of tap t at step t - WA before that step's gathers) and the
+// epilogue are those of tl_conv_stream.hip.  Deterministic; all K taps contracted.
+#include "tl_conv_internal.h"
+
+namespace {
+
+constexpr int WAVES = 8;
+constexpr int NT = WAVES * 64;
+
+__device__ unsigned long long g_tmq[8];   // developer timing mode (tl_dev_streamq_tm)
+
+template <int CTRL>
+static __device__ __forceinline__ uint32_t qperm(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+
+// S[i] (i = load index) -> F[s]: see the header.  0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = [2,3,0,1] (lane ^ 2)
+static __device__ __forceinline__ void quad_transpose(const u32x4 (&S)[4], u32x4 (&F)[4], bool o0, bool o1) {
+  u32x4 T[4];                                      // (the permutes are computed unconditionally: DPP must see all lanes)
+#pragma unroll
+  for (int i1 = 0; i1 < 2; ++i1)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t P = S[2 * i1][d], Q = S[2 * i1 + 1][d];
+      const uint32_t Pn = qperm<0xB1>(P), Qn = qperm<0xB1>(Q);
+      T[2 * i1][d] = o0 ? Qn : P;
+      T[2 * i1 + 1][d] = o0 ? Q : Pn;
+    }
+#pragma unroll
+  for (int x0 = 0; x0 < 2; ++x0)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t Ta = T[x0][d], Tb = T[2 + x0][d];
+      const uint32_t An = qperm<0x4E>(Ta), Bn = qperm<0x4E>(Tb);
+      F[x0][d] = o1 ? Bn : Ta;
+      F[x0 + 2][d] = o1 ? Tb : An;
+    }
+}
+
+template <int K, int NB, int PN, int DA, int OCC, bool TM>
+__global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
+  constexpr int COUT = NB * 32, CIN = PN * 64;
+  constexpr int BROW = CIN * 2 + 16;                  // LDS pitch of a weight row (+16 B: conflict-free ds_read_b128 down a column)
+  constexpr int BSLOTS = PN * 8;                      // 16-B pieces per weight row
+  constexpr int BVEC = COUT * BSLOTS;
+  constexpr int BPT = (BVEC + NT - 1) / NT;
+  constexpr int EP = 32 + 4;
+  constexpr int WB = 2 * COUT * BROW;
+  constexpr int LA = 4 * PN;                          // gather instructions per tap
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Bs = smem;                                                          // [2][COUT][BROW]
+  int* Is = reinterpret_cast<int*>(smem + WB);                              // [WAVES][K][8][4] row indices
+  float* Es = reinterpret_cast<float*>(smem);                               // epilogue alias: [WAVES][32][EP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  const bool o0 = lane & 1, o1 = lane & 2;
+  const int tile = xcd_tile(blockIdx.x, p.nblk);
+  const int64_t r0 = (int64_t)tile * (WAVES * 32) + wv * 32;
+
+  // the wave's slice of the rulebook -> LDS, [k][row & 7][row >> 3]
+  int* iw = Is + wv * (K * 32);
+  {
+    const int64_t row = r0 + fi;
+    const bool rvalid = row < p.n_out;
+    int v[(K + 1) / 2];
+#pragma unroll
+    for (int t = 0; t < (K + 1) / 2; ++t) {
+      const int k = min(2 * t + fh, K - 1);
+      v[t] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < (K + 1) / 2; ++t) {
+      const int k = 2 * t + fh;
+      if (k < K) iw[(k * 8 + (fi & 7)) * 4 + (fi >> 3)] = v[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  const int in_ld_b = (int)(p.in_ld * 2);
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * 2;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
+  const unsigned qoff = (unsigned)(fh * 64 + (lane & 3) * 16);
+  const int* iq = iw + ((lane >> 2) & 7) * 4;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  constexpr int WA = DA > 2 ? DA : 2, RW = WA - 1;
+  u32x4 a[DA][PN][4];
+  u32x4 bw[RW][BPT], bw0[BPT];
+  u32x4 idn;                                           // row indices of the next tap to request
+  auto read_idx = [&](int k) __attribute__((always_inline)) { idn = *reinterpret_cast<const u32x4*>(iq + k * 32); };
+  auto issue_a = [&](u32x4 (&dst)[PN][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned base = idn[i] * (unsigned)in_ld_b + qoff;
+#pragma unroll
+      for (int pp = 0; pp < PN; ++pp)
+        dst[pp][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + pp * 128), 0, 0));
+    }
+  };
+  auto load_b = [&](int k, u32x4 (&dst)[BPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      const int v = tid + q * NT;
+      dst[q] = wsrc[(int64_t)k * BVEC + (BVEC % NT == 0 ? v : min(v, BVEC - 1))];
+    }
+  };
+  auto store_b = [&](int buf, const u32x4 (&src)[BPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      const int v = tid + q * NT;
+      const int n = v / BSLOTS, s = v % BSLOTS;
+      if (BVEC % NT == 0 || v < BVEC) *reinterpret_cast<u32x4*>(Bs + buf * COUT * BROW + n * BROW + s * 16) = src[q];
+    }
+  };
+
+  load_b(0, bw0);
+  read_idx(0);
+#pragma unroll
+  for (int d = 0; d < WA; ++d) {
+    if (d >= 1 && d < K) load_b(d, bw[d % RW]);
+    if (d < DA && d < K) { issue_a(a[d]); if (d + 1 < K) read_idx(d + 1); }
+  }
+  store_b(0, bw0);
+  __syncthreads();
+
+  [[maybe_unused]] unsigned long long tm[4] = {0, 0, 0, 0}, tprev = 0;
+  auto tick = [&](int seg) __attribute__((always_inline)) {
+    if constexpr (TM) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (seg >= 0) tm[seg] += t - tprev;
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  tick(-1);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (k + 1 < K) store_b((k + 1) & 1, bw[(k + 1) % RW]);
+    if (k + WA < K) load_b(k + WA, bw[(k + WA) % RW]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TM) { if (k + DA < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (LA + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
+    tick(0);
+    u32x4 F[PN][4];
+#pragma unroll
+    for (int pp = 0; pp < PN; ++pp) quad_transpose(a[k % DA][pp], F[pp], o0, o1);
+    const char* bl = Bs + (k & 1) * COUT * BROW + fi * BROW + fh * 64;
+#pragma unroll
+    for (int pp = 0; pp < PN; ++pp)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + (pp * 8 + s) * 16);
+          mma16<true>(acc[nb], F[pp][s], bf);
+        }
+    tick(1);
+    if (k + DA < K) { issue_a(a[k % DA]); if (k + DA + 1 < K) read_idx(k + DA + 1); }
+    tick(2);
+    if (k + 1 < K) __syncthreads();
+    tick(3);
+  }
+  if constexpr (TM) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(&g_tmq[i], tm[i]);
+      atomicAdd(&g_tmq[4], 1ull);
+    }
+  }
+
+  // epilogue: MFMA row m = (r & 3) + 8 (r >> 2) + 4 fh is tile row rho(m) = ((m >> 2) & 7) + 8 (m & 3) = 2 (r >> 2) + fh + 8 (r & 3)
+  __syncthreads();
+  float* ew = Es + wv * 32 * EP;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ew[(2 * (r >> 2) + fh + 8 * (r & 3)) * EP + fi] = acc[nb][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e0 = 0; e0 < 2; ++e0) {
+      const int e = lane + e0 * 64;
+      const int rr = e >> 2, cvv = e & 3;
+      const int64_t orow = r0 + rr;
+      if (orow < p.n_out) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        epi_views8<true>(p, orow, nb * 32 + cvv * 8, v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int K, int NB, int PN, int DA, bool TM = false>
+int launch(ConvP p, hipStream_t s) {
+  constexpr int OCC = 2;
+  const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)WAVES * K * 32 * 4, ep = (size_t)WAVES * 32 * 36 * 4;
+  const size_t lds = wt > ep ? wt : ep;
+  if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, OCC, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return TL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32);
+  k_conv_streamq<K, NB, PN, DA, OCC, TM><<<p.nblk, NT, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+int g_tm_on = 0;
+
+}  // namespace
+
+// Developer hook (not part of the C ABI): per-segment cycle counters of the 64->64 shape on/off, read and clear.
+extern "C" int tl_dev_streamq_tm(int enable, unsigned long long* out8) {
+  g_tm_on = enable;
+  if (out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tmq), sizeof(g_tmq)) != hipSuccess) return TL_ERR_LAUNCH;
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tmq), z, sizeof(z)) != hipSuccess) return TL_ERR_LAUNCH;
+  }
+  return TL_OK;
+}
+
+int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
+  if (p.in_scale || p.in_relu || p.Cin % 64 || p.Cout % 32) return TL_ERR_UNSUPPORTED;
+  const int64_t ld_b = p.in_ld * 2, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 2;
+  if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll)) return TL_ERR_UNSUPPORTED;
+  const int nb = p.Cout / 32, pn = p.Cin / 64;
+  if (p.K == 27) {
+    if (g_tm_on && nb == 2 && pn == 1) return launch<27, 2, 1, 2, true>(p, s);
+    if (nb == 2 && pn == 1) return launch<27, 2, 1, 2>(p, s);
+    if (nb == 2 && pn == 2) return launch<27, 2, 2, 2>(p, s);
+    if (nb == 1 && pn == 1) return launch<27, 1, 1, 2>(p, s);
+    if (nb == 4 && pn == 2) return launch<27, 4, 2, 2>(p, s);
+  } else if (p.K == 8) {
+    if (nb == 3 && pn == 1) return launch<8, 3, 1, 2>(p, s);
+    if (nb == 1 && pn == 1) return launch<8, 1, 1, 2>(p, s);
+  }
+  return TL_ERR_UNSUPPORTED;
+}

@@ -64,7 +64,49 @@ __global__ void __launch_bounds__(256) k_gather_frag(const char* __restrict__ in
   }
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
+// quad pattern: four adjacent lanes read 64 contiguous bytes of one row; lane (q = (lane >> 2) & 7, h = lane >> 5) reads row q + 8 i,
+// bytes 64 h + 16 (lane & 3): 8 rows x 128 B per instruction like the staging pattern, but only quads are contiguous
+template <int TAPS>
+__global__ void __launch_bounds__(256) k_gather_quad(const char* __restrict__ in, int ld_b, const int32_t* __restrict__ table, int K,
+                                                     int64_t n, uint32_t* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wv * 32 + ((lane >> 2) & 7);
+  const int64_t in_bytes = (n - 1) * (int64_t)ld_b + 128;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in), 0, (int)in_bytes, 0x00020000);
+  const int off = (lane >> 5) * 64 + (lane & 3) * 16;
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (int k0 = 0; k0 < K; k0 += TAPS) {
+    int idx[TAPS][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) idx[t][i] = (k0 + t < K && row0 + 8 * i < n) ? table[(int64_t)(k0 + t) * n + row0 + 8 * i] : -1;
+    u32x4 v[TAPS][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[t][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((unsigned)idx[t][i] * (unsigned)ld_b + off), 0, 0));
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc ^= v[t][i];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
 }  // namespace
+
+extern "C" int tl_dev_gather_quad(const void* in, int64_t ld_bytes, int row_bytes, const int32_t* table, int K, int64_t n, int taps_in_flight,
+                                  uint32_t* sink, tl_stream_t stream) {
+  if (row_bytes != 128) return TL_ERR_ARG;
+  const unsigned g = (unsigned)tl_cdiv(n, 128);
+  hipStream_t s = tl_s(stream);
+  if (taps_in_flight >= 9) k_gather_quad<9><<<g, 256, 0, s>>>((const char*)in, (int)ld_bytes, table, K, n, sink);
+  else if (taps_in_flight >= 3) k_gather_quad<3><<<g, 256, 0, s>>>((const char*)in, (int)ld_bytes, table, K, n, sink);
+  else k_gather_quad<1><<<g, 256, 0, s>>>((const char*)in, (int)ld_bytes, table, K, n, sink);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
 
 extern "C" int tl_dev_gather_frag(const void* in, int64_t ld_bytes, int row_bytes, const int32_t* table, int K, int64_t n, int taps_in_flight,
                                   uint32_t* sink, tl_stream_t stream) {
