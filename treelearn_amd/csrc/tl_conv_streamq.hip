@@ -23,9 +23,6 @@
 
 namespace {
 
-constexpr int WAVES = 8;
-constexpr int NT = WAVES * 64;
-
 __device__ unsigned long long g_tmq[8];   // developer timing mode (tl_dev_streamq_tm)
 
 template <int CTRL>
@@ -56,31 +53,37 @@ static __device__ __forceinline__ void quad_transpose(const u32x4 (&S)[4], u32x4
     }
 }
 
-template <int K, int NB, int PN, int DA, int OCC, bool TM>
-__global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
+// W waves per workgroup, each owning RB blocks of 32 rows (one weight fragment read from LDS feeds RB MFMAs).
+// ABL: developer ablation bits (1 no transposition, 2 no gathers, 4 no barrier, 8 no MFMA, 16 timers)
+template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL>
+__global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
+  constexpr bool TM = (ABL & 16) != 0;
+  constexpr int NTH = W * 64;
   constexpr int COUT = NB * 32, CIN = PN * 64;
   constexpr int BROW = CIN * 2 + 16;                  // LDS pitch of a weight row (+16 B: conflict-free ds_read_b128 down a column)
   constexpr int BSLOTS = PN * 8;                      // 16-B pieces per weight row
   constexpr int BVEC = COUT * BSLOTS;
-  constexpr int BPT = (BVEC + NT - 1) / NT;
+  constexpr int BPT = (BVEC + NTH - 1) / NTH;
   constexpr int EP = 32 + 4;
   constexpr int WB = 2 * COUT * BROW;
-  constexpr int LA = 4 * PN;                          // gather instructions per tap
+  constexpr int LA = 4 * PN * RB;                     // gather instructions per tap
+  constexpr int WROWS = 32 * RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Bs = smem;                                                          // [2][COUT][BROW]
-  int* Is = reinterpret_cast<int*>(smem + WB);                              // [WAVES][K][8][4] row indices
-  float* Es = reinterpret_cast<float*>(smem);                               // epilogue alias: [WAVES][32][EP]
+  int* Is = reinterpret_cast<int*>(smem + WB);                              // [W][K][RB][8][4] row indices
+  float* Es = reinterpret_cast<float*>(smem);                               // epilogue alias: [W][32][EP]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fi = lane & 31, fh = lane >> 5;
   const bool o0 = lane & 1, o1 = lane & 2;
   const int tile = xcd_tile(blockIdx.x, p.nblk);
-  const int64_t r0 = (int64_t)tile * (WAVES * 32) + wv * 32;
+  const int64_t r0 = (int64_t)tile * (W * WROWS) + wv * WROWS;
 
-  // the wave's slice of the rulebook -> LDS, [k][row & 7][row >> 3]
-  int* iw = Is + wv * (K * 32);
-  {
-    const int64_t row = r0 + fi;
+  // the wave's slice of the rulebook -> LDS, [k][rb][row & 7][row >> 3]
+  int* iw = Is + wv * (K * WROWS);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int64_t row = r0 + rb * 32 + fi;
     const bool rvalid = row < p.n_out;
     int v[(K + 1) / 2];
 #pragma unroll
@@ -91,11 +94,11 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
 #pragma unroll
     for (int t = 0; t < (K + 1) / 2; ++t) {
       const int k = 2 * t + fh;
-      if (k < K) iw[(k * 8 + (fi & 7)) * 4 + (fi >> 3)] = v[t];
+      if (k < K) iw[((k * RB + rb) * 8 + (fi & 7)) * 4 + (fi >> 3)] = v[t];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 
   const int in_ld_b = (int)(p.in_ld * 2);
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * 2;
@@ -104,39 +107,48 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
   const int* iq = iw + ((lane >> 2) & 7) * 4;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
 
-  f32x16 acc[NB];
+  f32x16 acc[RB][NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][nb][i] = 0.f;
 
   constexpr int WA = DA > 2 ? DA : 2, RW = WA - 1;
-  u32x4 a[DA][PN][4];
+  u32x4 a[DA][RB][PN][4];
   u32x4 bw[RW][BPT], bw0[BPT];
-  u32x4 idn;                                           // row indices of the next tap to request
-  auto read_idx = [&](int k) __attribute__((always_inline)) { idn = *reinterpret_cast<const u32x4*>(iq + k * 32); };
-  auto issue_a = [&](u32x4 (&dst)[PN][4]) __attribute__((always_inline)) {
+  u32x4 idn[RB];                                       // row indices of the next tap to request
+  auto read_idx = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned base = idn[i] * (unsigned)in_ld_b + qoff;
+    for (int rb = 0; rb < RB; ++rb) idn[rb] = *reinterpret_cast<const u32x4*>(iq + (k * RB + rb) * 32);
+  };
+  auto issue_a = [&](u32x4 (&dst)[RB][PN][4]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pp = 0; pp < PN; ++pp)
-        dst[pp][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + pp * 128), 0, 0));
-    }
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned base = idn[rb][i] * (unsigned)in_ld_b + qoff;
+#pragma unroll
+        for (int pp = 0; pp < PN; ++pp) {
+          if constexpr (ABL & 2) dst[rb][pp][i] = u32x4{base, base, base, base};
+          else dst[rb][pp][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + pp * 128), 0, 0));
+        }
+      }
   };
   auto load_b = [&](int k, u32x4 (&dst)[BPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
-      const int v = tid + q * NT;
-      dst[q] = wsrc[(int64_t)k * BVEC + (BVEC % NT == 0 ? v : min(v, BVEC - 1))];
+      const int v = tid + q * NTH;
+      dst[q] = wsrc[(int64_t)k * BVEC + (BVEC % NTH == 0 ? v : min(v, BVEC - 1))];
     }
   };
   auto store_b = [&](int buf, const u32x4 (&src)[BPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
-      const int v = tid + q * NT;
+      const int v = tid + q * NTH;
       const int n = v / BSLOTS, s = v % BSLOTS;
-      if (BVEC % NT == 0 || v < BVEC) *reinterpret_cast<u32x4*>(Bs + buf * COUT * BROW + n * BROW + s * 16) = src[q];
+      if (BVEC % NTH == 0 || v < BVEC) *reinterpret_cast<u32x4*>(Bs + buf * COUT * BROW + n * BROW + s * 16) = src[q];
     }
   };
 
@@ -168,9 +180,14 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TM) { if (k + DA < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (LA + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
     tick(0);
-    u32x4 F[PN][4];
+    u32x4 F[RB][PN][4];
 #pragma unroll
-    for (int pp = 0; pp < PN; ++pp) quad_transpose(a[k % DA][pp], F[pp], o0, o1);
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int pp = 0; pp < PN; ++pp) {
+        if constexpr (ABL & 1) { for (int i = 0; i < 4; ++i) F[rb][pp][i] = a[k % DA][rb][pp][i]; }
+        else quad_transpose(a[k % DA][rb][pp], F[rb][pp], o0, o1);
+      }
     const char* bl = Bs + (k & 1) * COUT * BROW + fi * BROW + fh * 64;
 #pragma unroll
     for (int pp = 0; pp < PN; ++pp)
@@ -179,12 +196,16 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + (pp * 8 + s) * 16);
-          mma16<true>(acc[nb], F[pp][s], bf);
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            if constexpr (ABL & 8) acc[rb][nb][0] += __uint_as_float(F[rb][pp][s][0] ^ bf[0]);
+            else mma16<true>(acc[rb][nb], F[rb][pp][s], bf);
+          }
         }
     tick(1);
     if (k + DA < K) { issue_a(a[k % DA]); if (k + DA + 1 < K) read_idx(k + DA + 1); }
     tick(2);
-    if (k + 1 < K) __syncthreads();
+    if constexpr ((ABL & 4) == 0) { if (k + 1 < K) __syncthreads(); }
     tick(3);
   }
   if constexpr (TM) {
@@ -199,41 +220,43 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_streamq(ConvP p) {
   __syncthreads();
   float* ew = Es + wv * 32 * EP;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ew[(2 * (r >> 2) + fh + 8 * (r & 3)) * EP + fi] = acc[nb][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-    for (int e0 = 0; e0 < 2; ++e0) {
-      const int e = lane + e0 * 64;
-      const int rr = e >> 2, cvv = e & 3;
-      const int64_t orow = r0 + rr;
-      if (orow < p.n_out) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        epi_views8<true>(p, orow, nb * 32 + cvv * 8, v);
+      for (int r = 0; r < 16; ++r) ew[(2 * (r >> 2) + fh + 8 * (r & 3)) * EP + fi] = acc[rb][nb][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e0 = 0; e0 < 2; ++e0) {
+        const int e = lane + e0 * 64;
+        const int rr = e >> 2, cvv = e & 3;
+        const int64_t orow = r0 + rb * 32 + rr;
+        if (orow < p.n_out) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          epi_views8<true>(p, orow, nb * 32 + cvv * 8, v);
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
 }
 
-template <int K, int NB, int PN, int DA, bool TM = false>
+template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0>
 int launch(ConvP p, hipStream_t s) {
   constexpr int OCC = 2;
-  const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)WAVES * K * 32 * 4, ep = (size_t)WAVES * 32 * 36 * 4;
+  const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)W * K * 32 * RB * 4, ep = (size_t)W * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, OCC, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
-  p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32);
-  k_conv_streamq<K, NB, PN, DA, OCC, TM><<<p.nblk, NT, lds, s>>>(p);
+  p.nblk = (int)tl_cdiv(p.n_out, W * 32 * RB);
+  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL><<<p.nblk, W * 64, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -258,14 +281,29 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll)) return TL_ERR_UNSUPPORTED;
   const int nb = p.Cout / 32, pn = p.Cin / 64;
   if (p.K == 27) {
-    if (g_tm_on && nb == 2 && pn == 1) return launch<27, 2, 1, 2, true>(p, s);
+    if (g_tm_on && nb == 2 && pn == 1) {
+      switch (g_tm_on) {
+        case 1: return launch<27, 2, 1, 2, 8, 1, 16>(p, s);
+        case 2: return launch<27, 2, 1, 2, 8, 1, 1>(p, s);
+        case 3: return launch<27, 2, 1, 2, 8, 1, 2>(p, s);
+        case 4: return launch<27, 2, 1, 2, 8, 1, 4>(p, s);
+        case 6: return launch<27, 2, 1, 2, 8, 1, 3>(p, s);
+        case 8: return launch<27, 2, 1, 3, 8, 1>(p, s);
+        case 9: return launch<27, 2, 1, 1, 8, 1>(p, s);
+        case 10: return launch<27, 2, 1, 2, 4, 1>(p, s);
+        case 11: return launch<27, 2, 1, 2, 4, 2>(p, s);
+        case 12: return launch<27, 2, 1, 2, 8, 2>(p, s);
+        case 13: return launch<27, 2, 1, 1, 4, 2>(p, s);
+        case 14: return launch<27, 2, 1, 3, 4, 2>(p, s);
+        case 15: return launch<27, 2, 1, 2, 4, 2, 2>(p, s);
+      }
+    }
     if (nb == 2 && pn == 1) return launch<27, 2, 1, 2>(p, s);
     if (nb == 2 && pn == 2) return launch<27, 2, 2, 2>(p, s);
-    if (nb == 1 && pn == 1) return launch<27, 1, 1, 2>(p, s);
     if (nb == 4 && pn == 2) return launch<27, 4, 2, 2>(p, s);
+    if (nb == 3 && pn == 3) return launch<27, 3, 3, 2>(p, s);
   } else if (p.K == 8) {
     if (nb == 3 && pn == 1) return launch<8, 3, 1, 2>(p, s);
-    if (nb == 1 && pn == 1) return launch<8, 1, 1, 2>(p, s);
   }
   return TL_ERR_UNSUPPORTED;
 }
