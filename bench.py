@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
@@ -201,7 +202,7 @@ def main():
             roof["traffic"] = tr[0]["hbm_gb_per_step"]
             roof["traffic_unit"] = "GB per step (sum over the conv launches; PMC 2*FETCH_SIZE+WRITE_SIZE)"
             roof["traffic_source"] = os.path.relpath(tr[1], REPO)
-        roof.update(kernel="tl_conv_fwd family (k_conv_stream / k_conv_direct / k_conv_bf16 / k_conv_small / k_conv_in4)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
+        roof.update(kernel="tl_conv_fwd family (k_conv_streamq / k_conv_stream / k_conv_direct / k_conv_small / k_conv_in4)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
                     algorithmic_gflop_per_step=flops / 1e9, algorithmic_gb_per_step=byts / 1e9)
 
     if rank == 0:
@@ -213,7 +214,7 @@ def main():
                                         f"{n_pts} points/tile, 7-level 32-ch sparse U-Net fwd (30.1 M params, random init), 1 tile per GPU",
                                points_per_tile=n_pts, tiles_per_step=world),
                    roofline=roof)
-        if world == 1 and args.dtype == "bf16":
+        if world == 1 and args.dtype == "bf16" and not args.no_fp32_mode:
             # the fp32 parity mode (the precision the 1e-3 parity gate is checked in), same tile, for reference
             m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype=torch.float32)
             m32.load_state_dict(model.state_dict(), strict=True); m32 = m32.cuda().eval()
