@@ -158,6 +158,29 @@ int64_t tl_compact_ws_words(int64_t n);
 int tl_compact_rows(const float* in, int C, const uint8_t* mask, int64_t n, float* out, int32_t* count,
                     int32_t* ws, tl_stream_t stream);
 
+/* ------------------------------------------------------------------ inference tiling
+ * Replaces, per tile, the box masks + `.cpu()` + np.savez / np.load round trip of
+ * SampleGenerator.tile_generate_and_save (tree_learn/util/data_preparation.py:393-441,456-476) and the
+ * bookkeeping of TreeDataset.__getitem__ (tree_learn/dataset/dataset.py:34-76,87-91), plot arrays resident in HBM.
+ *   xyz f32[n,3], label f32[n], feat f32[n,F] : the voxelised plot;
+ *   box (HOST struct): outer = (xmin,xmax,ymin,ymax) as float32 (closed box, compared in float32),
+ *       inner = the inner square in float64 (x in [x0,x1), y in (y0,y1], compared in float64),
+ *       center = tile centre subtracted in float64, half_inner = inner_square_edge_length / 2;
+ *   outputs, capacity n rows, rows kept in plot order: coords f32[.,3] (centred), out_feat f32[.,F],
+ *   instance_labels i64 (int32 truncation of label), semantic_labels i64 (label 0 -> 1, else 0),
+ *   mask_inner u8, mask_sem u8 (= inner & label != -1);
+ *   count i32[2] device out = {rows kept, rows inside the inner square};  ws i32[tl_tile_crop_ws_words(n)]. */
+typedef struct tl_tile_box {
+  float outer[4];
+  double inner[4];
+  double center[2];
+  float half_inner;
+} tl_tile_box;
+int64_t tl_tile_crop_ws_words(int64_t n);
+int tl_tile_crop(const float* xyz, const float* label, const float* feat, int64_t n, int F, const tl_tile_box* box,
+                 float* coords, float* out_feat, int64_t* instance_labels, int64_t* semantic_labels,
+                 uint8_t* mask_inner, uint8_t* mask_sem, int32_t* count, int32_t* ws, tl_stream_t stream);
+
 /* ------------------------------------------------------------------ clustering
  * Replaces sklearn DBSCAN(eps, min_samples=2) in group_dbscan (tree_learn/util/pipeline.py:173-180):
  * connected components of the eps-graph on 2-D points; isolated points = -1; component labels

@@ -12,7 +12,8 @@ What is real reference code and what is a stand-in
   Custom1x1Subm3d module wiring and state-dict layout, `voxelize` post-processing,
   `get_loss`, `point_wise_loss`, `get_pointwise_preds`, `get_instances`, `group_dbscan`,
   `group_hdbscan`, `make_labels_consecutive`, `ensemble`,
-  `assign_remaining_points_nearest_neighbor`, `TreeDataset.collate_fn`.
+  `assign_remaining_points_nearest_neighbor`, `TreeDataset.__getitem__/collate_fn`,
+  `SampleGenerator.tile_generate_and_save`.
 * Stand-in (defined in THIS file, because the third-party `spconv` wheel is neither in
   /root/reference nor installable here): `spconv.pytorch` = a *dense* implementation
   -- every sparse conv is torch.nn.functional.conv3d / conv_transpose3d on a dense grid,
@@ -421,10 +422,51 @@ def g10_forward():
     save("g10_forward.npz", **out)
 
 
+def g11_tiles(tmp="/tmp/tl_golden_plot"):
+    """the reference's inference tiling (SampleGenerator.tile_generate_and_save, plot_corners=None, no
+    denoising) followed by its own TreeDataset (test mode) + collate_fn with batch size 1, on a small synthetic plot.
+    Every tile's batch is pinned by per-array SHA-1 digests; four tiles are stored in full."""
+    import hashlib, logging, shutil
+    from tree_learn.util.data_preparation import SampleGenerator
+    shutil.rmtree(tmp, ignore_errors=True); os.makedirs(os.path.join(tmp, "forest")); os.makedirs(os.path.join(tmp, "features"))
+    t = make_tile(extent=14.0, voxel=0.25, n_trees=6, fill=0.08, seed=21)
+    rng = np.random.default_rng(5)
+    pts = np.round(t["points"].astype(np.float32) + np.array([103.2, -41.7, 2.0], np.float32), 2)
+    pts[:, 1] *= 0.8                                                    # non-square plot
+    pts = np.round(pts, 2).astype(np.float32)
+    labels = t["instance_label"].astype(np.float32)
+    labels[rng.uniform(size=len(labels)) < 0.05] = -1                   # some unlabeled points
+    feats = rng.uniform(size=(len(pts), 1)).astype(np.float32)
+    np.savez(os.path.join(tmp, "forest", "plot.npz"), points=pts, labels=labels)
+    np.savez(os.path.join(tmp, "features", "plot.npz"), features=feats)
+    inner_edge, outer_edge, stride, isel = 3.0, 2.5, 0.5, 3.0
+    gen = SampleGenerator(os.path.join(tmp, "forest", "plot.npz"), os.path.join(tmp, "features", "plot.npz"), os.path.join(tmp, "tiles"),
+                          None, None, None, None)
+    gen.tile_generate_and_save(inner_edge, outer_edge, stride, logger=logging.getLogger("golden"))
+    ds = TreeDataset(os.path.join(tmp, "tiles", "npz"), isel, False, logging.getLogger("golden"))
+    n_tiles = len(ds.data_paths)
+    ds.data_paths = [os.path.join(tmp, "tiles", "npz", f"plot_{i}.npz") for i in range(n_tiles)]
+    out = dict(points=pts, labels=labels, feats=feats, params=np.array([inner_edge, outer_edge, stride, isel]), n_tiles=n_tiles)
+    keys = ["coords", "input_feats", "batch_ids", "semantic_labels", "instance_labels", "masks_inner", "masks_off", "masks_sem", "offset_labels", "centers"]
+    digests, counts = [], []
+    full = sorted(set([0, n_tiles // 3, n_tiles // 2, n_tiles - 1]))
+    for i in range(n_tiles):
+        b = ds.collate_fn([ds[i]])
+        assert b["batch_size"] == 1
+        counts.append(len(b["coords"]))
+        digests.append([hashlib.sha1(np.ascontiguousarray(b[k].numpy()).tobytes()).hexdigest() for k in keys])
+        if i in full:
+            for k in keys:
+                out[f"tile{i}_{k}"] = b[k].numpy()
+    out["keys"] = np.array(keys); out["digests"] = np.array(digests); out["counts"] = np.array(counts); out["full_tiles"] = np.array(full)
+    print("g11: tiles", n_tiles, "points/tile", min(counts), max(counts))
+    save("g11_tiles.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
-    fns = dict(g1=g1_g2_loss, g3=g3_voxelize, g4=g4_collate, g5=g5_clustering, g6=g6_g7_next_rows, g8=g8_manifest, g9=g9_tile_loop, g10=g10_forward)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
+    fns = dict(g11=g11_tiles, g1=g1_g2_loss, g3=g3_voxelize, g4=g4_collate, g5=g5_clustering, g6=g6_g7_next_rows, g8=g8_manifest, g9=g9_tile_loop, g10=g10_forward)
     for w in which:
         fns[w]()

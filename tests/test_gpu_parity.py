@@ -410,3 +410,24 @@ def test_next_rows_ensemble_and_knn_fill_vs_golden(golden_dir):
     knn = KNeighborsClassifier(n_neighbors=5).fit(pts[pred != -1], pred[pred != -1])
     ref = pred.copy(); ref[pred == -1] = knn.predict(pts[pred == -1])
     np.testing.assert_array_equal(ours, ref)
+
+
+def test_next_rows_device_tiler_vs_golden(golden_dir):
+    """PlotTiler (tl_tile_crop + host label bookkeeping) reproduces every array of every tile of the
+    reference's tile_generate_and_save -> npz -> TreeDataset -> collate chain (golden G11), bit for bit."""
+    import hashlib
+    from treelearn_amd.util.tiles import PlotTiler
+    g = np.load(os.path.join(golden_dir, "g11_tiles.npz"))
+    ie, oe, st, isel = (float(v) for v in g["params"])
+    tiler = PlotTiler(g["points"], g["labels"], g["feats"])
+    keys = [str(k) for k in g["keys"]]
+    n = 0
+    for i, b in enumerate(tiler.tiles(ie, oe, st, isel)):
+        assert b["batch_size"] == 1 and len(b["coords"]) == int(g["counts"][i]), i
+        for j, k in enumerate(keys):
+            a = b[k].cpu().numpy()
+            assert hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest() == str(g["digests"][i][j]), (i, k, a.dtype)
+        n += 1
+    assert n == int(g["n_tiles"])
+    fast = list(tiler.tiles(ie, oe, st, isel, offset_labels="none"))
+    assert len(fast) == n and not bool(fast[0]["masks_off"].any()) and fast[0]["coords"].is_cuda

@@ -98,3 +98,23 @@ def test_g10_reach_zero(golden_dir):
     sd = om.random_state_dict(1, channels=8, num_blocks=4)
     with pytest.raises(ValueError, match="reach zero!!!"):
         om.forward(sd, g["rz_in_coords"], g["rz_in_input_feats"], g["rz_in_batch_ids"], 1, voxel_size=0.5, num_blocks=4)
+
+
+def test_g11_tiles_oracle_matches_reference(golden_dir):
+    """the numpy restatement of tile_generate_and_save + TreeDataset/collate (oracle/tiles.py) reproduces every
+    array of every tile the reference produced (SHA-1 over the raw bytes: dtype, order and values)."""
+    import hashlib
+    from oracle import tiles as ot
+    g = np.load(os.path.join(golden_dir, "g11_tiles.npz"))
+    ie, oe, st, isel = (float(v) for v in g["params"])
+    res = ot.plot_tiles(g["points"], g["labels"], g["feats"], ie, oe, st, isel)
+    assert len(res) == int(g["n_tiles"])
+    keys = [str(k) for k in g["keys"]]
+    for i, b in enumerate(res):
+        assert len(b["coords"]) == int(g["counts"][i])
+        for j, k in enumerate(keys):
+            assert hashlib.sha1(np.ascontiguousarray(b[k]).tobytes()).hexdigest() == str(g["digests"][i][j]), (i, k)
+    for i in g["full_tiles"]:
+        for k in keys:
+            ref = g[f"tile{i}_{k}"]
+            assert res[i][k].dtype == ref.dtype and np.array_equal(res[i][k], ref), (i, k)

@@ -28,6 +28,10 @@ class ConvArgs(_c.Structure):
     ]
 
 
+class TileBox(_c.Structure):               # tl_tile_box
+    _fields_ = [("outer", _c.c_float * 4), ("inner", _c.c_double * 4), ("center", _c.c_double * 2), ("half_inner", _c.c_float)]
+
+
 _I4 = _i32 * 4
 _I3 = _i32 * 3
 
@@ -53,6 +57,8 @@ PROTOTYPES = {
     "tl_affine_relu": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "tl_compact_ws_words": (_i64, [_i64]),
     "tl_compact_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tl_tile_crop_ws_words": (_i64, [_i64]),
+    "tl_tile_crop": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_cluster_ws_bytes": (_i64, [_i64]),
     "tl_cluster_grid": (_i32, [_vp, _i64, _c.c_double, _vp, _vp, _vp, _vp]),
     "tl_hdbscan_ws_bytes": (_i64, [_i64]),
