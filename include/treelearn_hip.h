@@ -181,6 +181,29 @@ int tl_tile_crop(const float* xyz, const float* label, const float* feat, int64_
                  float* coords, float* out_feat, int64_t* instance_labels, int64_t* semantic_labels,
                  uint8_t* mask_inner, uint8_t* mask_sem, int32_t* count, int32_t* ws, tl_stream_t stream);
 
+/* ------------------------------------------------------------------ plot preparation
+ * Global voxel down-sample and verticality feature, delegated by the reference to open3d 0.17.0
+ * (VoxelDownSampleAndTrace; tree_learn/util/data_preparation.py:60-79) and jakteristics 0.5.1
+ * (compute_features, data_preparation.py:82-88; called from generate_tiles, util/pipeline.py:40-65).
+ *
+ * tl_cell_keys: key[i] = pack(floor((p - min_bound) / cell) - base3), 21 bits per axis, z in the low bits;
+ *   round_input != 0 rounds the coordinates to 2 decimals first (np.round(points, 2), data_preparation.py:62);
+ *   base3 = HOST i64[3]; err i32[1] device out is set when a cell index leaves the 21-bit range.
+ * tl_downsample_reduce: keys sorted ascending with the stable permutation `perm` (host code: torch.sort);
+ *   per voxel, in input order and in double: mean of the 2-decimal-rounded points -> float32 -> rounded to 2
+ *   decimals (util/pipeline.py:44-45); first_idx = smallest original index of the voxel (`idx_keep`);
+ *   point2vox i64[n] = voxel row of every original point (the trace); n_voxels i64[1] device out.
+ * tl_verticality: xyz_sorted f64[n,3] and keys sorted by a `radius`-sized cell key (tl_cell_keys, round_input = 0);
+ *   extent2 = HOST i64[2] largest cell index in x and y; out f32[n] (sorted order) = 1 - |n_z| of the sample
+ *   covariance of all points within `radius` (inclusive, the point itself included); NaN when fewer than 3. */
+int tl_cell_keys(const double* xyz, int64_t n, double cell, double min_bound, const int64_t* base3, int round_input,
+                 int64_t* keys, int32_t* err, tl_stream_t stream);
+int64_t tl_downsample_ws_words(int64_t n);
+int tl_downsample_reduce(const double* xyz, const int64_t* sorted_keys, const int64_t* perm, int64_t n, float* out_xyz,
+                         int64_t* first_idx, int64_t* point2vox, int64_t* n_voxels, int32_t* ws, tl_stream_t stream);
+int tl_verticality(const double* xyz_sorted, const int64_t* sorted_keys, int64_t n, double radius, const int64_t* extent2,
+                   float* out, tl_stream_t stream);
+
 /* ------------------------------------------------------------------ clustering
  * Replaces sklearn DBSCAN(eps, min_samples=2) in group_dbscan (tree_learn/util/pipeline.py:173-180):
  * connected components of the eps-graph on 2-D points; isolated points = -1; component labels

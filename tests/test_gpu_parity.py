@@ -431,3 +431,44 @@ def test_next_rows_device_tiler_vs_golden(golden_dir):
     assert n == int(g["n_tiles"])
     fast = list(tiler.tiles(ie, oe, st, isel, offset_labels="none"))
     assert len(fast) == n and not bool(fast[0]["masks_off"].any()) and fast[0]["coords"].is_cuda
+
+
+def test_next_rows_voxel_downsample_vs_oracle():
+    """SURVEY.md 8f #4 (parity unpinned by the reference: open3d is absent): the device down-sample equals the numpy
+    restatement bit for bit -- voxel set, in-order double means -> float32 -> 2 decimals, first indices, trace."""
+    from oracle import prepare as op
+    from treelearn_amd.util.prepare import propagate_to_original, voxelize
+    rng = np.random.default_rng(4)
+    for n, scale, shift in ((5000, 3.0, 0.0), (20000, 12.0, 431.77)):
+        pts = rng.normal(size=(n, 3)) * scale + shift
+        pts[: n // 4] = np.round(pts[: n // 4], 1) + 0.05                     # points on voxel boundaries after rounding
+        lab = rng.integers(-1, 9, size=(n, 1)).astype(np.float64)
+        data = np.hstack([pts, lab])
+        ref, first, p2v = op.voxelize(data, 0.1)
+        out, trace = voxelize(data, 0.1)
+        assert out.shape == ref.shape
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        np.testing.assert_array_equal(trace["first_idx"].cpu().numpy(), first)
+        np.testing.assert_array_equal(trace["point2vox"].cpu().numpy(), p2v)
+        preds = rng.integers(0, 50, size=len(ref))
+        np.testing.assert_array_equal(propagate_to_original(preds, trace).cpu().numpy(), preds[p2v])
+
+
+def test_next_rows_verticality_vs_oracle():
+    """Verticality = 1 - |n_z| of the radius-neighbourhood covariance vs scipy cKDTree + numpy eigh (fp64), 1e-5 absolute
+    wherever the normal is well conditioned; same NaN set (fewer than 3 neighbours) and the same NaN replacement."""
+    from oracle import prepare as op
+    from treelearn_amd.synth import make_tile
+    from treelearn_amd.util.prepare import compute_features
+    t = make_tile(extent=12.0, voxel=0.1, n_trees=5, fill=0.10, seed=8)
+    pts = t["points"].astype(np.float64)
+    pts = np.vstack([pts, np.array([[40.0, 40.0, 3.0], [40.2, 40.0, 3.0], [-50.0, 7.0, 1.0]])])       # isolated points: < 3 neighbours
+    ref, gap = op.verticality(pts, 0.6)
+    ours = compute_features(pts, search_radius=0.6).cpu().numpy()[:, 0]
+    nan = np.isnan(ref)
+    assert 3 <= nan.sum() < 50
+    good = ~nan & (gap > 1e-6)
+    assert good.mean() > 0.99
+    assert np.abs(ours[good] - ref[good]).max() < 1e-5
+    filled = op.replace_nan(ref)
+    assert np.abs(ours[nan] - filled[nan]).max() < 1e-4 and ours.dtype == np.float32
