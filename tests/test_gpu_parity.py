@@ -472,3 +472,49 @@ def test_next_rows_verticality_vs_oracle():
     assert np.abs(ours[good] - ref[good]).max() < 1e-5
     filled = op.replace_nan(ref)
     assert np.abs(ours[nan] - filled[nan]).max() < 1e-4 and ours.dtype == np.float32
+
+
+def test_end_to_end_plot_pipeline_runs_and_is_deterministic():
+    """All rows of SURVEY 8 chained on one small raw cloud, everything on the device: down-sample + verticality (8f #4) ->
+    tiles (8f #3) -> tile loop (a2..a13) -> ensemble (8f #1) -> grouping (a14..a17) -> k-NN fill (8f #2) -> back to the
+    original points.  Random weights: the check is plumbing (shapes, label ranges, every original point labelled) and
+    run-to-run determinism of the whole chain."""
+    from oracle import model as om
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_tile
+    from treelearn_amd.util import get_instances, get_pointwise_preds
+    from treelearn_amd.util.postprocess import assign_remaining_points_nearest_neighbor, ensemble
+    from treelearn_amd.util.prepare import compute_features, propagate_to_original, voxelize
+    from treelearn_amd.util.tiles import PlotTiler
+    t = make_tile(extent=14.0, voxel=0.1, n_trees=6, fill=0.10, seed=5)
+    rng = np.random.default_rng(0)
+    raw = np.vstack([t["points"].astype(np.float64) + rng.normal(0, 0.015, size=t["points"].shape) for _ in range(2)])
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1)
+    model.load_state_dict(om.random_state_dict(3, channels=32, num_blocks=7)); model = model.cuda().eval()
+    cfg = dict(tree_conf_thresh=0.5, tau_vert=0.0, tau_off=1e9, tau_group=0.3, tau_min=20, use_hdbscan=False)
+
+    def run():
+        down, trace = voxelize(raw, 0.1)
+        feats = compute_features(down[:, :3], 0.6)
+        tiler = PlotTiler(down[:, :3].float(), torch.full((len(down),), -1.0), feats)
+        res = get_pointwise_preds(model, tiler.tiles(4.0, 5.0, 0.5, 4.0, offset_labels="none"), dict(voxel_size=0.1))
+        res = ensemble(res[4], res[0], res[1], res[2], res[3], res[5], res[6], res[7])
+        coords, sem, _, off, _, _, _, infeat = res
+        inst = get_instances(coords, off, sem, cfg, infeat[:, -1], 0, 0, -1, 1)
+        tree = inst != 0
+        if tree.any() and (inst[tree] != -1).any():
+            inst[tree] = assign_remaining_points_nearest_neighbor(coords[tree] + off[tree], inst[tree], -1)
+        return down, trace, coords, inst
+
+    down, trace, coords, inst = run()
+    assert len(coords) > 0.5 * len(down) and inst.dtype == np.int64 and inst.min() >= -1
+    # the ensembled inner points are voxelised points: map them back onto the down-sampled rows, then onto the raw cloud
+    dn = down[:, :3].cpu().numpy().astype(np.float32)
+    key = lambda a: np.round(a * 100).astype(np.int64) @ np.array([1 << 40, 1 << 20, 1], np.int64)        # noqa: E731
+    order = np.argsort(key(dn)); pos = np.searchsorted(key(dn)[order], key(coords.astype(np.float32)))
+    assert (key(dn)[order][np.minimum(pos, len(dn) - 1)] == key(coords.astype(np.float32))).mean() > 0.999
+    vox_pred = np.zeros(len(dn), np.int64); vox_pred[order[np.minimum(pos, len(dn) - 1)]] = inst
+    full = propagate_to_original(vox_pred, trace).cpu().numpy()
+    assert full.shape == (len(raw),)
+    down2, _, coords2, inst2 = run()
+    np.testing.assert_array_equal(coords, coords2); np.testing.assert_array_equal(inst, inst2)
