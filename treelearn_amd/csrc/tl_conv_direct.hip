@@ -17,7 +17,9 @@
 
 namespace {
 
-template <bool BF16, int K, int NB, int UN, int G, int WAVES>
+// ABL: developer ablation bits (tools/dev_direct_abl.py; results are wrong on purpose): 1 no gathers, 2 no MFMA,
+// 4 no output stores, 8 no rulebook loads (identity rows)
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles) {
   constexpr int EB = BF16 ? 2 : 4;                   // bytes per element
   constexpr int UB = 32 * EB;                        // bytes of one 32-channel unit of a row
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
     const bool rvalid = row < p.n_out;
     int idx[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) idx[k] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+    for (int k = 0; k < K; ++k) idx[k] = rvalid ? ((p.table && !(ABL & 8)) ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
 
     f32x16 acc[NB];
 #pragma unroll
@@ -76,7 +78,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
           for (int c = 0; c < UN; ++c)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              dst[t][c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
+              if constexpr (ABL & 1) dst[t][c][j] = u32x4{base, base + 1, base + 2, base + 3};
+              else dst[t][c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
         }
       }
     };
@@ -95,7 +98,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) {
                 const u32x4 bf = *reinterpret_cast<const u32x4*>(wl + ((k * UN + c) * COUT + nb * 32) * UB + (((2 * j + fh) ^ swz) * 16));
-                mma16<BF16>(acc[nb], a[g & 1][t][c][j], bf);
+                if constexpr (ABL & 2) acc[nb][(k + j) & 15] += __uint_as_float(a[g & 1][t][c][j][0] ^ bf[1]);
+                else mma16<BF16>(acc[nb], a[g & 1][t][c][j], bf);
               }
             }
         }
@@ -116,7 +120,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
       if (orow >= p.n_out) continue;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      epi_views8<BF16>(p, orow, cvv * 8, v);
+      if constexpr (ABL & 4) { if (v[0] == 1.2345e30f) epi_views8<BF16>(p, orow, cvv * 8, v); }
+      else epi_views8<BF16>(p, orow, cvv * 8, v);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -197,14 +202,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   }
 }
 
-template <bool BF16, int K, int NB, int UN, int G, int WAVES>
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0>
 int launch(const ConvP& p, hipStream_t s) {
   constexpr int UB = BF16 ? 64 : 128;
   const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
@@ -213,13 +218,30 @@ int launch(const ConvP& p, hipStream_t s) {
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_direct<BF16, K, NB, UN, G, WAVES><<<grid, WAVES * 64, lds, s>>>(p, ntiles);
+  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL><<<grid, WAVES * 64, lds, s>>>(p, ntiles);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
+
+int g_direct_abl = 0;
 
 template <bool BF16, int K, int G>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
+  if constexpr (BF16 && K == 27) {
+    if (g_direct_abl && nb == 1 && un == 1) {
+      switch (g_direct_abl) {
+        case 1: return launch<true, 27, 1, 1, 3, 16, 1>(p, s);
+        case 2: return launch<true, 27, 1, 1, 3, 16, 2>(p, s);
+        case 3: return launch<true, 27, 1, 1, 3, 16, 4>(p, s);
+        case 4: return launch<true, 27, 1, 1, 3, 16, 8>(p, s);
+        case 5: return launch<true, 27, 1, 1, 3, 16, 9>(p, s);
+        case 6: return launch<true, 27, 1, 1, 3, 16, 5>(p, s);
+        case 7: return launch<true, 27, 1, 1, 3, 8>(p, s);
+        case 8: return launch<true, 27, 1, 1, 9, 16>(p, s);
+        case 9: return launch<true, 27, 1, 1, 1, 16>(p, s);
+      }
+    }
+  }
   const size_t wbytes = (size_t)K * p.Cout * p.Cin * (BF16 ? 2 : 4);
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \
@@ -233,6 +255,8 @@ int dispatch(const ConvP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int tl_dev_direct_abl(int mode) { g_direct_abl = mode; return TL_OK; }   // developer hook, not part of the C ABI
 
 // Eligibility (beyond the tile kernel's alignment rules): no gather-side prologue, whole weight tensor + epilogue
 // scratch within LDS, input view below 4 GB.  Returns TL_ERR_UNSUPPORTED when the shape is not covered.
