@@ -111,8 +111,8 @@ def main():
         print(json.dumps(cpu_baseline_worker()), flush=True)
         return
 
-    torch.set_num_threads(host_cores())
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.set_num_threads(max(1, host_cores() // int(os.environ.get("LOCAL_WORLD_SIZE", world))))     # ranks share the host-core quota
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dist = None

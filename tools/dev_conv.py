@@ -6,7 +6,7 @@ from treelearn_amd import ops, _hip
 from treelearn_amd.geometry import build_geometry
 from treelearn_amd.synth import CONFIGS, make_tile
 
-for key in ("bf16_depth", "bf16_units", "small_rows", "dbg", "direct", "stream", "streamq", "stream_rb"):
+for key in ("bf16_depth", "bf16_units", "small_rows", "small_mode", "dbg", "direct", "stream", "streamq", "stream_rb"):
     if os.environ.get("TL_" + key.upper()):
         _hip.check(_hip.lib().tl_set_tuning(key.encode(), int(os.environ["TL_" + key.upper()])), key)
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # 0-based level

@@ -13,11 +13,11 @@
 
 namespace {
 
-template <bool BF16, int NBB>
-__global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
+template <bool BF16, int NBB, int WV>
+__global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
   constexpr int PF = 4;                                       // steps in flight per wave (independent loads issued together)
-  __shared__ float red[4][NBB][16][64];
+  __shared__ float red[WV][NBB][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rt = blockIdx.x / ncolblk, cb = blockIdx.x % ncolblk;
   const int64_t row = (int64_t)rt * 32 + (lane & 31);
@@ -40,13 +40,13 @@ __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-  // The wave's steps are s = wv, wv+4, ...; PF of them are processed per iteration with all their loads issued before
+  // The wave's steps are s = wv, wv+WV, ...; PF of them are processed per iteration with all their loads issued before
   // the first MFMA (deep levels are latency-bound: a few hundred rows, 27 x Cin/32 dependent load->MFMA chains).
-  for (int s0 = wv; s0 < nsteps; s0 += 4 * PF) {
+  for (int s0 = wv; s0 < nsteps; s0 += WV * PF) {
     int idx[PF]; int kk[PF], ch[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int s = s0 + 4 * u;
+      const int s = s0 + WV * u;
       const bool sv = s < nsteps;
       kk[u] = sv ? s / nchunk : 0; ch[u] = sv ? s % nchunk : 0;
       idx[u] = (sv && rvalid) ? (p.table ? p.table[(int64_t)kk[u] * p.n_out + row] : (int)row) : -1;
@@ -110,17 +110,20 @@ __global__ void __launch_bounds__(256) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wv][nb][r][lane] = acc[nb][r];
   __syncthreads();
-  // wave w finishes registers r = 4w..4w+3 of every column block (fixed summation order => deterministic)
+  // wave w finishes registers r = (16/WV) w .. of every column block (fixed summation order => deterministic)
   const int col = lane & 31;
+  constexpr int RPW = 16 / WV;
 #pragma unroll
   for (int nb = 0; nb < NBB; ++nb) {
     const int j = col0 + nb * 32 + col;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = wv * 4 + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = wv * RPW + rr;
       const int64_t orow = (int64_t)rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
       if (orow >= p.n_out) continue;
-      float v = ((red[0][nb][r][lane] + red[1][nb][r][lane]) + red[2][nb][r][lane]) + red[3][nb][r][lane];
+      float v = red[0][nb][r][lane];
+#pragma unroll
+      for (int w = 1; w < WV; ++w) v += red[w][nb][r][lane];
       if constexpr (BF16) {
         if (p.res) v += __uint_as_float((uint32_t)((const uint16_t*)p.res)[orow * p.res_ld + j] << 16);
       } else {
@@ -191,15 +194,24 @@ int launch_tiny(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
+int g_small_mode = 0;   // developer A/B (tl_set_tuning "small_mode"): 0 = by size, 1 = always 4 waves, 2 = always 8 waves x 32 columns
+
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
   const int nrt = (int)tl_cdiv(p.n_out, 32);
-  const bool two = (p.Cout % 64 == 0);
+  // few row tiles: 8 waves split the (tap, chunk) steps of a 32 x 32 output block (more, shorter dependent chains);
+  // otherwise 4 waves per 32 x 64 (or 32 x 32) block
+  const bool eight = g_small_mode == 2 || (g_small_mode == 0 && nrt * (p.Cout / 32) <= 512 && p.K * (p.Cin / 32) >= 32);   // measured: l=6,7 1.5x, l=5 equal, 1x1 slower
+  const bool two = !eight && (p.Cout % 64 == 0);
   const int ncb = p.Cout / (two ? 64 : 32);
   const unsigned g = (unsigned)(nrt * ncb);
   if (dtype == TL_BF16) {
-    if (two) k_conv_small<true, 2><<<g, 256, 0, s>>>(p, ncb); else k_conv_small<true, 1><<<g, 256, 0, s>>>(p, ncb);
+    if (eight) k_conv_small<true, 1, 8><<<g, 512, 0, s>>>(p, ncb);
+    else if (two) k_conv_small<true, 2, 4><<<g, 256, 0, s>>>(p, ncb);
+    else k_conv_small<true, 1, 4><<<g, 256, 0, s>>>(p, ncb);
   } else {
-    if (two) k_conv_small<false, 2><<<g, 256, 0, s>>>(p, ncb); else k_conv_small<false, 1><<<g, 256, 0, s>>>(p, ncb);
+    if (eight) k_conv_small<false, 1, 8><<<g, 512, 0, s>>>(p, ncb);
+    else if (two) k_conv_small<false, 2, 4><<<g, 256, 0, s>>>(p, ncb);
+    else k_conv_small<false, 1, 4><<<g, 256, 0, s>>>(p, ncb);
   }
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
