@@ -127,6 +127,9 @@ typedef struct tl_conv_args {
    * raw tensor (for the residual branch) AND relu(bn_next(y)) (for the next conv's gathers) in one pass: */
   void* out2; int64_t out2_ld; const float* out2_scale; const float* out2_shift; int32_t out2_relu;
   void* out3; int64_t out3_ld; const float* out3_scale; const float* out3_shift; int32_t out3_relu;
+  /* optional second copy of the weights in MFMA-fragment order (tl_pack_weight_frag), NULL if absent: kernels that
+   * read B operands straight from global memory (the small-level kernel) then load 1 KB contiguous per instruction */
+  const void* weight_frag;
 } tl_conv_args;
 
 int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
@@ -134,6 +137,10 @@ int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
 /* Repack a reference-layout conv weight [Cout, k,k,k, Cin] (spconv `.weight`)
  * into the kernel layout [K=k^3][Cout][Cin] with dtype conversion. */
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream);
+/* Same weights in fragment order (Cout % 32 == 0, Cin % 32 == 0): [K][Cout/32][Cin/32][J][64 lanes][16 B], where lane
+ * (fi = lane & 31, fh = lane >> 5) of 16-B piece j holds W[k][32 cb + fi][32 ch + (32 j + 16 fh) / sizeof(elem) ...]:
+ * the B operand of one 32x32 MFMA step is one contiguous 1 KB block (J = 2 for bf16, 4 for fp32). */
+int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_frag, int dtype, tl_stream_t stream);
 
 /* ------------------------------------------------------------------ per-point heads
  * Replaces forward_head (tree_learn.py:97-103): features[v2p] gather, output_layer BN+ReLU

@@ -25,6 +25,7 @@ class ConvArgs(_c.Structure):
         ("out", _vp), ("out_ld", _i64), ("stats", _vp),
         ("out2", _vp), ("out2_ld", _i64), ("out2_scale", _vp), ("out2_shift", _vp), ("out2_relu", _i32),
         ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
+        ("weight_frag", _vp),
     ]
 
 
@@ -53,6 +54,7 @@ PROTOTYPES = {
     "tl_table_tapmask": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_head_mlp": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_affine_relu": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "tl_compact_ws_words": (_i64, [_i64]),

@@ -207,6 +207,23 @@ __global__ void k_pack_weight(const float* __restrict__ w, int Cout, int K, int 
   }
 }
 
+// fragment order: vector v = ((((k*CB + cb)*CH + ch)*J + j)*64 + lane) holds 16 B = W[k][32cb + (lane&31)][32ch + (32j + 16(lane>>5))/EB ..]
+__global__ void k_pack_weight_frag(const float* __restrict__ w, int Cout, int K, int Cin, void* __restrict__ o, int dtype) {
+  const int EB = dtype == TL_F32 ? 4 : 2, J = 32 * EB / 32, EPV = 16 / EB;
+  const int CB = Cout / 32, CH = Cin / 32;
+  const int64_t nvec = (int64_t)K * CB * CH * J * 64;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(v & 63); int64_t r = v >> 6;
+    const int j = (int)(r % J); r /= J; const int ch = (int)(r % CH); r /= CH; const int cb = (int)(r % CB); const int k = (int)(r / CB);
+    const int col = cb * 32 + (lane & 31), c0 = ch * 32 + (32 * j + 16 * (lane >> 5)) / EB;
+    for (int e = 0; e < EPV; ++e) {
+      const float x = w[((int64_t)col * K + k) * Cin + c0 + e];
+      if (dtype == TL_F32) reinterpret_cast<float*>(o)[v * EPV + e] = x;
+      else reinterpret_cast<__hip_bfloat16*>(o)[v * EPV + e] = __float2bfloat16(x);
+    }
+  }
+}
+
 template <typename T>
 __global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld, int64_t n, int C,
                               const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
@@ -254,7 +271,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (a->stats) return TL_ERR_UNSUPPORTED;
   if (a->dtype != TL_F32 && a->dtype != TL_BF16) return TL_ERR_ARG;
   ConvP p;
-  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.table = a->table; p.n_out = a->n_out; p.n_in = a->n_in;
+  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.n_out = a->n_out; p.n_in = a->n_in;
   p.K = a->K; p.Cin = a->Cin; p.Cout = a->Cout; p.in_scale = a->in_scale; p.in_shift = a->in_shift;
   p.in_relu = a->in_relu; p.out_relu = a->out_relu; p.res = a->residual; p.res_ld = a->res_ld;
   p.out_scale = a->out_scale; p.out_shift = a->out_shift; p.out = a->out; p.out_ld = a->out_ld;
@@ -321,6 +338,13 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream) {
   if (!w_ref || !w_packed || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
   k_pack_weight<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_packed, dtype);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_frag, int dtype, tl_stream_t stream) {
+  if (!w_ref || !w_frag || Cout <= 0 || K <= 0 || Cin <= 0 || Cout % 32 || Cin % 32 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  k_pack_weight_frag<<<tl_grid((int64_t)Cout * K * Cin / 8, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_frag, dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

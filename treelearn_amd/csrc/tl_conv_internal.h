@@ -11,6 +11,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 struct ConvP {
   const void* in; int64_t in_ld;
   const void* w;
+  const void* w_frag;   // optional fragment-order copy of w (tl_pack_weight_frag) or nullptr
   const int32_t* table;
   int64_t n_out, n_in;
   int K, Cin, Cout;

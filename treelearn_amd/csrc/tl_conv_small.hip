@@ -13,7 +13,8 @@
 
 namespace {
 
-template <bool BF16, int NBB, int WV>
+// FR: B operands come from the fragment-order weight copy (p.w_frag): 1 KB contiguous per load instead of 32 rows x 32 B
+template <bool BF16, int NBB, int WV, bool FR>
 __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
   constexpr int PF = 4;                                       // steps in flight per wave (independent loads issued together)
@@ -32,7 +33,8 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)p.Cin * EB;
   const bool buf_ok = in_bytes > 0 && in_bytes + 2 * (int64_t)in_ld_b < 0xFFFFFFFFll;       // else: clamp + mask path
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, buf_ok ? (int)in_bytes : 0, 0x00020000);
-  const char* inb = (const char*)p.in; const char* Wb = (const char*)p.w;
+  const char* inb = (const char*)p.in; const char* Wb = (const char*)(FR ? p.w_frag : p.w);
+  const int CBt = p.Cout / 32;
 
   f32x16 acc[NBB];
 #pragma unroll
@@ -67,7 +69,8 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
       for (int nb = 0; nb < NBB; ++nb)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk[u] * p.Cout + col0 + nb * 32 + fi) * p.Cin + ch[u] * 32) * EB + j * 32 + fh * 16);
+          if constexpr (FR) b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk[u] * CBt + col0 / 32 + nb) * nchunk + ch[u]) * NJ + j) * 64 + lane) * 16);
+          else b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk[u] * p.Cout + col0 + nb * 32 + fi) * p.Cin + ch[u] * 32) * EB + j * 32 + fh * 16);
     }
     if (pro) {                                                // gather-side BatchNorm+ReLU (module-by-module path only)
 #pragma unroll
@@ -194,7 +197,7 @@ int launch_tiny(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-int g_small_mode = 0;   // developer A/B (tl_set_tuning "small_mode"): 0 = by size, 1 = always 4 waves, 2 = always 8 waves x 32 columns
+int g_small_mode = 0;   // developer A/B (tl_set_tuning "small_mode"): 0 = by size, 1 = always 4 waves, 2 = always 8 waves x 32 columns, 3 = ignore the fragment-order weights
 
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
   const int nrt = (int)tl_cdiv(p.n_out, 32);
@@ -204,15 +207,16 @@ int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
   const bool two = !eight && (p.Cout % 64 == 0);
   const int ncb = p.Cout / (two ? 64 : 32);
   const unsigned g = (unsigned)(nrt * ncb);
-  if (dtype == TL_BF16) {
-    if (eight) k_conv_small<true, 1, 8><<<g, 512, 0, s>>>(p, ncb);
-    else if (two) k_conv_small<true, 2, 4><<<g, 256, 0, s>>>(p, ncb);
-    else k_conv_small<true, 1, 4><<<g, 256, 0, s>>>(p, ncb);
-  } else {
-    if (eight) k_conv_small<false, 1, 8><<<g, 512, 0, s>>>(p, ncb);
-    else if (two) k_conv_small<false, 2, 4><<<g, 256, 0, s>>>(p, ncb);
-    else k_conv_small<false, 1, 4><<<g, 256, 0, s>>>(p, ncb);
-  }
+#define TL_SMALL(BF_, FR_)                                                                   \
+  do {                                                                                         \
+    if (eight) k_conv_small<BF_, 1, 8, FR_><<<g, 512, 0, s>>>(p, ncb);                         \
+    else if (two) k_conv_small<BF_, 2, 4, FR_><<<g, 256, 0, s>>>(p, ncb);                      \
+    else k_conv_small<BF_, 1, 4, FR_><<<g, 256, 0, s>>>(p, ncb);                               \
+  } while (0)
+  const bool fr = p.w_frag != nullptr && ((uintptr_t)p.w_frag) % 16 == 0 && g_small_mode != 3;
+  if (dtype == TL_BF16) { if (fr) TL_SMALL(true, true); else TL_SMALL(true, false); }
+  else { if (fr) TL_SMALL(false, true); else TL_SMALL(false, false); }
+#undef TL_SMALL
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 

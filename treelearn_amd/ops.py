@@ -19,6 +19,12 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     K = w.numel() // (co * ci)
     out = torch.empty((K, co, ci), dtype=dtype, device=w.device)
     _hip.check(L.tl_pack_weight(_hip.ptr(w), co, K, ci, _hip.ptr(out), _hip.dtype_code(dtype), _hip.stream()), "tl_pack_weight")
+    if co % 32 == 0 and ci % 32 == 0 and K > 1:
+        # second copy in MFMA-fragment order for the kernels that read B operands straight from global memory (small levels);
+        # it rides on the packed tensor as an attribute so that callers keep passing one object
+        frag = torch.empty(K * co * ci, dtype=dtype, device=w.device)
+        _hip.check(L.tl_pack_weight_frag(_hip.ptr(w), co, K, ci, _hip.ptr(frag), _hip.dtype_code(dtype), _hip.stream()), "tl_pack_weight_frag")
+        out._tl_frag = frag
     return out
 
 
@@ -42,6 +48,7 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.weight = w_packed.data_ptr()
     a.table = table.data_ptr() if table is not None else None
     a.tapmask = None
+    a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
     a.n_out = n_out; a.n_in = x.shape[0]
     a.K = K; a.Cin = Cin; a.Cout = Cout; a.dtype = _hip.dtype_code(x.dtype)
     a.in_scale = in_scale.data_ptr() if in_scale is not None else None
