@@ -130,6 +130,9 @@ typedef struct tl_conv_args {
   /* optional second copy of the weights in MFMA-fragment order (tl_pack_weight_frag), NULL if absent: kernels that
    * read B operands straight from global memory (the small-level kernel) then load 1 KB contiguous per instruction */
   const void* weight_frag;
+  /* != 0: every output row has at most ONE valid table entry (SparseInverseConv3d: the row's parent through its own
+   * octant tap).  Kernels may then gather that single row once and route it to its tap instead of issuing K gathers. */
+  int32_t table_one_hot;
 } tl_conv_args;
 
 int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);

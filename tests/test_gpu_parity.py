@@ -518,3 +518,28 @@ def test_end_to_end_plot_pipeline_runs_and_is_deterministic():
     assert full.shape == (len(raw),)
     down2, _, coords2, inst2 = run()
     np.testing.assert_array_equal(coords, coords2); np.testing.assert_array_equal(inst, inst2)
+
+
+@pytest.mark.parametrize("cin,cout,n_out", [(64, 32, 20000), (96, 64, 16500), (128, 96, 17000), (160, 128, 3000)])
+def test_inverse_conv_one_hot_form(cin, cout, n_out):
+    """SparseInverseConv3d rulebooks have one valid entry per output row: the gather-once path (table_one_hot) must give
+    the same result as the general path and as the oracle, including rows with no parent at all."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    d = _dev()
+    n_in = n_out // 5 + 3
+    x = _bf16_round(rng.normal(size=(n_in, cin)).astype(np.float32))
+    w = _bf16_round((rng.normal(size=(cout, 2, 2, 2, cin)) / np.sqrt(cin)).astype(np.float32))
+    table = np.full((n_out, 8), -1, np.int32)
+    table[np.arange(n_out), rng.integers(0, 8, n_out)] = rng.integers(0, n_in, n_out)
+    table[rng.uniform(size=n_out) < 0.02] = -1                                        # orphans
+    y = osp.conv_table(torch.from_numpy(x), torch.from_numpy(w), table, n_out).numpy()
+    T = lambda a, dt=torch.float32: torch.from_numpy(a).to(d).to(dt)
+    wp = ops.pack_weight(T(w), torch.bfloat16)
+    tab = torch.from_numpy(np.ascontiguousarray(table.T)).to(d)
+    s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32); h2 = rng.normal(0, 0.3, cout).astype(np.float32)
+    o2a = torch.empty((n_out, cout), dtype=torch.bfloat16, device=d); o2b = torch.empty_like(o2a)
+    a = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, out2=(o2a, T(s2), T(h2), True), one_hot=True)
+    b = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, out2=(o2b, T(s2), T(h2), True), one_hot=False)
+    assert rel_err(a.float().cpu().numpy(), y) < 8e-3
+    assert torch.equal(a, b) and torch.equal(o2a, o2b)

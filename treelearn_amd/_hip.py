@@ -25,7 +25,7 @@ class ConvArgs(_c.Structure):
         ("out", _vp), ("out_ld", _i64), ("stats", _vp),
         ("out2", _vp), ("out2_ld", _i64), ("out2_scale", _vp), ("out2_shift", _vp), ("out2_relu", _i32),
         ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
-        ("weight_frag", _vp),
+        ("weight_frag", _vp), ("table_one_hot", _i32),
     ]
 
 

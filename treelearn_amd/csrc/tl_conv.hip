@@ -279,7 +279,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   p.out3 = a->out3; p.out3_ld = a->out3_ld; p.out3_scale = a->out3_scale; p.out3_shift = a->out3_shift; p.out3_relu = a->out3_relu;
   if ((a->out2_scale == nullptr) != (a->out2_shift == nullptr) || (a->out3_scale == nullptr) != (a->out3_shift == nullptr)) return TL_ERR_ARG;
   p.nblk = (int)tl_cdiv(a->n_out, TM);
-  p.dbg = g_dbg;
+  p.dbg = g_dbg; p.one_hot = a->table_one_hot && a->table != nullptr;
   hipStream_t s = tl_s(stream);
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
@@ -314,6 +314,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
   {
+    if (p.one_hot && g_stream && a->K == 8) {                  // inverse convs: the stream kernel's gather-once form
+      const int rc = tl_launch_conv_stream(p, TL_BF16, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
     if (g_direct) {
       const int rc = tl_launch_conv_direct(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;

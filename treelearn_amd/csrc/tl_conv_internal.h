@@ -23,6 +23,7 @@ struct ConvP {
   void* out2; int64_t out2_ld; const float* out2_scale; const float* out2_shift; int out2_relu;
   void* out3; int64_t out3_ld; const float* out3_scale; const float* out3_shift; int out3_relu;
   int nblk;
+  int one_hot; // every output row has at most one valid table entry (inverse conv)
   int dbg;     // developer ablation bits (tl_set_tuning "dbg"): 1 no A loads, 2 no B loads, 4 no MFMA, 8 no stores
 };
 

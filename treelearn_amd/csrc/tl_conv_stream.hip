@@ -21,7 +21,9 @@ constexpr int NT = WAVES * 64;
 
 __device__ unsigned long long g_tm[8];   // developer timing mode (tl_dev_stream_tm): cycles summed over waves per step segment
 
-template <bool BF16, int K, int NB, int UN, int DA, int RB, int OCC, bool TM = false>
+// OH (inverse conv, one valid table entry per output row): the row's single input row is gathered ONCE and routed to its
+// tap by a per-lane select, instead of K gathers of which K - 1 are out of range.
+template <bool BF16, int K, int NB, int UN, int DA, int RB, int OCC, bool TM = false, bool OH = false>
 __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32, SLOTS = UB / 16;
   constexpr int COUT = NB * 32, CIN = UN * 32;
@@ -99,10 +101,25 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
 
   // prologue: weights of tap 0 -> LDS; taps 1..WA-1 of the weights and 0..DA-1 of A in flight, interleaved in tap order
   load_b(0, bw0);
+  [[maybe_unused]] u32x4 a1[RB][UN][NJ];                   // OH: the one gathered row per output row
+  if constexpr (OH) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      int ip = -1;
+#pragma unroll
+      for (int k = 0; k < K; ++k) ip = max(ip, idx[k][rb]);
+      const unsigned base = (unsigned)ip * (unsigned)in_ld_b + lane_off;
+#pragma unroll
+      for (int c = 0; c < UN; ++c)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          a1[rb][c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base + c * UB + j * 32), 0, 0));
+    }
+  }
 #pragma unroll
   for (int d = 0; d < WA; ++d) {
     if (d >= 1 && d < K) load_b(d, bw[d % RW]);
-    if (d < DA && d < K) issue_a(d, a[d]);
+    if constexpr (!OH) { if (d < DA && d < K) issue_a(d, a[d]); }
   }
   store_b(0, bw0);
   __syncthreads();
@@ -135,11 +152,16 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
           const int slot = c * SLOTS + 2 * j + fh;
           const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + slot * 16);
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) mma16<BF16>(acc[rb][nb], a[k % DA][rb][c][j], bf);   // one weight fragment, RB MFMAs
+          for (int rb = 0; rb < RB; ++rb) {                                                     // one weight fragment, RB MFMAs
+            if constexpr (OH) {
+              const u32x4 z = {0u, 0u, 0u, 0u};
+              mma16<BF16>(acc[rb][nb], idx[k][rb] >= 0 ? a1[rb][c][j] : z, bf);
+            } else mma16<BF16>(acc[rb][nb], a[k % DA][rb][c][j], bf);
+          }
         }
       }
     tick(1);
-    if (k + DA < K) issue_a(k + DA, a[k % DA]);
+    if constexpr (!OH) { if (k + DA < K) issue_a(k + DA, a[k % DA]); }
     tick(2);
     if (k + 1 < K) __syncthreads();
     tick(3);
@@ -179,7 +201,7 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
     }
 }
 
-template <bool BF16, int K, int NB, int UN, int DA, int RB, bool TM = false>
+template <bool BF16, int K, int NB, int UN, int DA, int RB, bool TM = false, bool OH = false>
 int launch(ConvP p, hipStream_t s) {
   constexpr int EB = BF16 ? 2 : 4;
   constexpr int BPTL = (NB * 32 * UN * (BF16 ? 4 : 8) + NT - 1) / NT;
@@ -190,12 +212,12 @@ int launch(ConvP p, hipStream_t s) {
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
   p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32 * RB);
-  k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM><<<p.nblk, NT, lds, s>>>(p);
+  k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH><<<p.nblk, NT, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -206,6 +228,13 @@ int g_stream_rb = 0;     // bf16: 32-row blocks per wave (tl_set_tuning "stream_
 template <bool BF16, int K>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
+  if constexpr (BF16 && K == 8) {
+    if (p.one_hot) {                                          // the up (inverse) convs of the large levels
+      if (nb == 2 && un == 3) return launch<true, 8, 2, 3, 1, 1, false, true>(p, s);
+      if (nb == 1 && un == 2) return launch<true, 8, 1, 2, 1, 1, false, true>(p, s);
+      if (nb == 3 && un == 4) return launch<true, 8, 3, 4, 1, 1, false, true>(p, s);
+    }
+  }
   if constexpr (BF16 && K == 27) {
     if (g_stream_tm && nb == 2 && un == 2) return launch<true, 27, 2, 2, 3, 1, true>(p, s);
     if (g_stream_da && nb == 2 && un == 2) {                  // developer A/B of the prefetch depth on the 64->64 shape

@@ -42,13 +42,13 @@ RAW = lambda buf=None: View(buf=buf)                                   # noqa: E
 ACT = lambda aff, buf=None: View(aff[0], aff[1], True, buf)            # noqa: E731
 
 
-def _conv_views(x, w, table, n, views, residual=None):
+def _conv_views(x, w, table, n, views, residual=None, one_hot=False):
     """Run one conv producing up to three views; returns the list of result tensors (same order)."""
     outs = [v.buf if v.buf is not None else torch.empty((n, w.shape[1]), dtype=x.dtype, device=x.device) for v in views]
     v0 = views[0]
     extra = [(o, v.scale, v.shift, v.relu) for o, v in zip(outs[1:], views[1:])]
     ops.conv_fwd(x, w, table, n, out=outs[0], residual=residual, out_scale=v0.scale, out_shift=v0.shift, out_relu=v0.relu,
-                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None)
+                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None, one_hot=one_hot)
     return outs
 
 
@@ -100,7 +100,7 @@ class _U:
         nxt = geom.levels[li + 1]
         d_raw, d_act = _conv_views(xd, self.wd, lv.child, nxt.n, [RAW(), ACT(self.u.blocks[0].bn0)])
         (e_act,) = self.u.run(d_raw, d_act, geom, li + 1, [ACT(self.bn_up)])
-        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:]), ACT(self.bn_cat_r, cat_act[:, C:])])
+        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:]), ACT(self.bn_cat_r, cat_act[:, C:])], one_hot=True)
         y_raw, y_act = self.tail[0].run(cat_raw, cat_act, lv.nbr, n, [RAW(), ACT(self.tail[1].bn0)])
         return self.tail[1].run(y_raw, y_act, lv.nbr, n, views)
 

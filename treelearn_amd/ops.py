@@ -30,7 +30,7 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
              in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False,
-             out2=None, out3=None):
+             out2=None, out3=None, one_hot=False):
     """out[o] = epi(sum_k W[k] . pro(x[table[k][o]])); x / out / residual may be column views of wider
     row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused."""
     L = _hip.lib()
@@ -49,6 +49,7 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.table = table.data_ptr() if table is not None else None
     a.tapmask = None
     a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
+    a.table_one_hot = int(bool(one_hot))          # inverse conv: one valid entry per output row
     a.n_out = n_out; a.n_in = x.shape[0]
     a.K = K; a.Cin = Cin; a.Cout = Cout; a.dtype = _hip.dtype_code(x.dtype)
     a.in_scale = in_scale.data_ptr() if in_scale is not None else None
