@@ -145,6 +145,14 @@ int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed,
  * the B operand of one 32x32 MFMA step is one contiguous 1 KB block (J = 2 for bf16, 4 for fp32). */
 int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_frag, int dtype, tl_stream_t stream);
 
+/* Weight gradient (training step; spconv's autograd behind the conv modules, tools/training/train.py:40):
+ *   gw[k][co][ci] = sum_o gout[o][co] * x[table[k][o]][ci]   over the present rulebook entries, fp32.
+ * x f32[n_in, x_ld >= Cin], gout f32[n_out, g_ld >= Cout], table i32[K][n_out] or NULL (K = 1: identity),
+ * gw f32[K][Cout][Cin] out (fully written), ws f32[tl_conv_wgrad_ws_floats(...)] scratch.  Deterministic. */
+int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout);
+int tl_conv_wgrad(const float* x, int64_t x_ld, const float* gout, int64_t g_ld, const int32_t* table, int64_t n_out,
+                  int64_t n_in, int K, int Cin, int Cout, float* gw, float* ws, tl_stream_t stream);
+
 /* ------------------------------------------------------------------ per-point heads
  * Replaces forward_head (tree_learn.py:97-103): features[v2p] gather, output_layer BN+ReLU
  * (tree_learn.py:42,93) as prologue, then both MLPs (blocks.py:8-18) with eval-mode BN folded:

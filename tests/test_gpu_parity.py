@@ -543,3 +543,28 @@ def test_inverse_conv_one_hot_form(cin, cout, n_out):
     b = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, out2=(o2b, T(s2), T(h2), True), one_hot=False)
     assert rel_err(a.float().cpu().numpy(), y) < 8e-3
     assert torch.equal(a, b) and torch.equal(o2a, o2b)
+
+
+@pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 9000), (64, 32, 27, 5000), (4, 32, 27, 7000), (96, 64, 8, 4100), (160, 192, 8, 700),
+                                               (64, 32, 1, 6000), (224, 224, 27, 223)])
+def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
+    """tl_conv_wgrad (present pairs only, fp32 MFMA, deterministic) vs gather + matmul in float64."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin * 7 + cout + K)
+    d = _dev()
+    n_in = n_out + 50 if K != 1 else n_out
+    x = rng.normal(size=(n_in, cin)).astype(np.float32); g = rng.normal(size=(n_out, cout)).astype(np.float32)
+    table = rng.integers(-1, n_in, size=(n_out, K)).astype(np.int32)
+    table[rng.uniform(size=table.shape) < 0.7] = -1
+    if K == 1:
+        table = np.arange(n_in, dtype=np.int32)[:, None]
+    ref = np.zeros((K, cout, cin))
+    for k in range(K):
+        m = table[:, k] >= 0
+        ref[k] = g[m].astype(np.float64).T @ x[table[m, k]].astype(np.float64)
+    tab = None if K == 1 else torch.from_numpy(np.ascontiguousarray(table.T)).to(d)
+    wide = torch.zeros((n_in, cin + 8), dtype=torch.float32, device=d); wide[:, 8:] = torch.from_numpy(x).to(d)      # column view input
+    a = ops.conv_wgrad(wide[:, 8:], torch.from_numpy(g).to(d), tab, n_out, K)
+    b = ops.conv_wgrad(wide[:, 8:], torch.from_numpy(g).to(d), tab, n_out, K)
+    assert torch.equal(a, b)                                                        # deterministic
+    assert rel_err(a.cpu().numpy(), ref) < 2e-5

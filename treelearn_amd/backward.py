@@ -6,9 +6,8 @@ gather-GEMM over the TRANSPOSED table with transposed weights --
     down k2s2 : gin[i] = sum_k W[k]^T gout[inv[k][i]]
     inverse   : gin[q] = sum_k W[k]^T gout[child[k][q]]
     1x1       : gin    = gout . W
-all through `tl_conv_fwd`.  wgrad (gW[k] = sum_o gout[o] (x) x[table[k][o]]) is, in this round, one gather of
-all (row, tap) neighbour rows followed by a single library GEMM on the GPU (torch.mm -> rocBLAS/hipBLASLt):
-[Cout x N] x [N x K*Cin].  A fused HIP wgrad (no materialised gather) is the next step.
+all through `tl_conv_fwd`.  wgrad (gW[k] = sum_o gout[o] (x) x[table[k][o]]) is `tl_conv_wgrad` (csrc/tl_wgrad.hip): fp32
+32x32x2 MFMAs over the present (output row, input row) pairs only, two pairs per instruction, no materialised gather.
 """
 import torch
 
@@ -32,19 +31,16 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
         if ref.flip:
             w = w.flip(0)
         wt = w.contiguous().to(grad_out.dtype)                             # kernel layout [K]["Cout"=Cin]["Cin"=Cout]
-        gx = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in)
-    if need_gw:
-        g32 = grad_out.float()
-        if ref.table is None:
-            gw = (g32.t() @ x.float()).reshape(co, 1, ci)
+        if ci <= 224:
+            gx = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in)
         else:
-            # one gather of every (row, tap) neighbour row ([N, K, Cin]; absent -> the appended zero row), then ONE
-            # [Cout x N] x [N x K*Cin] GEMM: a tall reduction the library handles far better than K thin ones
-            n = x.shape[0]
-            xpad = torch.cat([x.float(), x.new_zeros((1, ci), dtype=torch.float32)], 0)
-            idx = ref.table.t().long()                                         # [n_out, K]
-            idx = torch.where(idx < 0, torch.full_like(idx, n), idx)
-            xg = xpad[idx].reshape(idx.shape[0], K * ci)
-            gw = (g32.t() @ xg).reshape(co, K, ci)
-        gw = gw.reshape(weight.shape).to(weight.dtype)
+            # the 2C -> C convs of the decoder have up to 448 "output" channels when transposed; the MFMA kernels cover
+            # <= 224, so run column slices of the transposed weights into column views of the result
+            gx = torch.empty((ref.n_in, ci), dtype=grad_out.dtype, device=grad_out.device)
+            step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
+            for s in range(0, ci, step):
+                ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=gx[:, s:s + step])
+    if need_gw:
+        gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K)               # [K, Cout, Cin] fp32, present pairs only
+        gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
     return gx, gw

@@ -1,0 +1,132 @@
+// Weight gradient of the sparse convolution (training step; reference: spconv's autograd behind SubMConv3d / SparseConv3d /
+// SparseInverseConv3d.forward, reached from tools/training/train.py:40 `scaler.scale(loss).backward()`):
+//     gW[k][co][ci] = sum over output rows o with table[k][o] >= 0 of  gout[o][co] * x[table[k][o]][ci]
+// fp32 on the matrix cores with NO operand transposition: the 32x32x2 fp32 MFMA takes A[m][kk] and B[kk][n] as one float per
+// lane with m = n = lane & 31 and kk = lane >> 5, so with kk = "which of two rows" both operands are plain 128-B row reads
+// (A = 32 channels of gout[o], B = 32 channels of x[table[k][o]]): two (output row, input row) pairs per MFMA.
+// Only PRESENT pairs are multiplied: a wave ballots the rulebook entries of 64 rows and walks the set bits two at a time
+// (at level 1 only 5.5 of 27 taps are present per voxel, so this is ~5x less matrix work than the dense form).
+// Work split: workgroup = (row chunk, tap, 64x64 block of [Cout x Cin]); each wave owns a quarter of the chunk and writes its
+// partial [co][ci] tile to the workspace; tl_wgrad_reduce adds the partials in ascending chunk order -> deterministic.
+// Replaces the round-1 "gather all [N, K, Cin] rows + one library GEMM" (6 GB of scratch per level-1 conv).
+#include "tl_conv_internal.h"
+
+namespace {
+
+constexpr int kRowsPerWave = 2048;
+constexpr int kWaves = 4;
+
+template <int NBO, int NBI>
+__global__ void __launch_bounds__(kWaves * 64) k_wgrad(const float* __restrict__ x, int64_t x_ld, const float* __restrict__ g, int64_t g_ld,
+                                                       const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
+                                                       int nbi_blocks, float* __restrict__ ws) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int k = blockIdx.y;
+  const int bo = blockIdx.z / nbi_blocks, bi = blockIdx.z % nbi_blocks;
+  const int co0 = bo * (NBO * 32), ci0 = bi * (NBI * 32);
+  const int64_t part = (int64_t)blockIdx.x * kWaves + wv;
+  const int64_t r_begin = part * kRowsPerWave, r_end = min(n_out, r_begin + kRowsPerWave);
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 4), 0x00020000);
+  unsigned offx[NBI], offg[NBO];                 // per-lane channel offsets (bytes), out of range -> 0xFFFFFFFF (reads as 0)
+#pragma unroll
+  for (int b = 0; b < NBI; ++b) offx[b] = (ci0 + b * 32 + fi < Cin) ? (unsigned)((ci0 + b * 32 + fi) * 4) : 0xFFFFFFFFu;
+#pragma unroll
+  for (int b = 0; b < NBO; ++b) offg[b] = (co0 + b * 32 + fi < Cout) ? (unsigned)((co0 + b * 32 + fi) * 4) : 0xFFFFFFFFu;
+
+  f32x16 acc[NBO][NBI];
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  constexpr int PF = 4;                          // (row, row) pairs whose loads are in flight together
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
+    const int64_t row = r0 + lane;
+    int idx = -1;
+    if (row < r_end) idx = table ? table[(int64_t)k * n_out + row] : (int)row;
+    unsigned long long m = __ballot(idx >= 0);
+    while (m) {
+      float gv[PF][NBO], xv[PF][NBI];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        // two present rows of this 64-row group (or one and nothing): lane half fh takes the fh-th of them
+        int b1 = -1, b2 = -1;
+        if (m) { b1 = __builtin_ctzll(m); m &= m - 1; }
+        if (m) { b2 = __builtin_ctzll(m); m &= m - 1; }
+        const int i1 = b1 >= 0 ? __builtin_amdgcn_readlane(idx, b1) : -1;
+        const int i2 = b2 >= 0 ? __builtin_amdgcn_readlane(idx, b2) : -1;
+        const int bsel = fh ? b2 : b1, isel = fh ? i2 : i1;
+        const unsigned gbase = bsel >= 0 ? (unsigned)((r0 + bsel) * g_ld * 4) : 0xFFFFFFFFu;
+        const unsigned xbase = isel >= 0 ? (unsigned)((int64_t)isel * x_ld * 4) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = 0; b < NBO; ++b)
+          gv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)((gbase | offg[b]) == 0xFFFFFFFFu ? 0xFFFFFFFFu : gbase + offg[b]), 0, 0));
+#pragma unroll
+        for (int b = 0; b < NBI; ++b)
+          xv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)((xbase | offx[b]) == 0xFFFFFFFFu ? 0xFFFFFFFFu : xbase + offx[b]), 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int a = 0; a < NBO; ++a)
+#pragma unroll
+          for (int b = 0; b < NBI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u][a], xv[u][b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // partial tile -> workspace [part][K][Cout][Cin]
+  float* wp = ws + ((part * K + k) * (int64_t)Cout) * Cin;
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ci = ci0 + b * 32 + fi;
+        if (co < Cout && ci < Cin) wp[(int64_t)co * Cin + ci] = acc[a][b][r];
+      }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t nparts, int64_t per, float* __restrict__ gw) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int64_t p = 0; p < nparts; ++p) s += ws[p * per + e];          // ascending chunk order: deterministic
+    gw[e] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
+  const int64_t nparts = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves) * kWaves;
+  return nparts * K * Cout * Cin;
+}
+
+int tl_conv_wgrad(const float* x, int64_t x_ld, const float* gout, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K,
+                  int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
+  if (!x || !gout || !gw || !ws || n_out <= 0 || n_in <= 0 || K <= 0 || Cin <= 0 || Cout <= 0 || x_ld < Cin || g_ld < Cout) return TL_ERR_ARG;
+  if (!table && K != 1) return TL_ERR_ARG;
+  if (n_in * x_ld * 4 > 0x7FFFFFFFll || n_out * g_ld * 4 > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
+  hipStream_t s = tl_s(stream);
+  const int64_t nchunks = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves);
+  const bool big_o = Cout > 32, big_i = Cin > 32;
+  const int nbo = (int)tl_cdiv(Cout, big_o ? 64 : 32), nbi = (int)tl_cdiv(Cin, big_i ? 64 : 32);
+  const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
+  if (big_o && big_i) k_wgrad<2, 2><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+  else if (big_o) k_wgrad<2, 1><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+  else if (big_i) k_wgrad<1, 2><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+  else k_wgrad<1, 1><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+  const int64_t per = (int64_t)K * Cout * Cin;
+  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nchunks * kWaves, per, gw);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+}  // extern "C"
