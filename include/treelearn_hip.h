@@ -98,6 +98,12 @@ int tl_rulebook_subm(const int32_t* coords, int64_t M, const uint64_t* bitmap, c
 int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap, const uint32_t* fprefix,
                      const int32_t fdims[4], int64_t Mf, int32_t* child, int32_t* parent, int32_t* inv, tl_stream_t stream);
 
+/* Column form of a 27-tap SubM rulebook built by tl_rulebook_subm: compact i32[10][n] = the row of the first present
+ * dz neighbour of each of the 9 (dx, dy) columns (or -1) followed by a 27-bit presence mask.  Present neighbours of a
+ * column are consecutive rows, so entry k = 3 c + d is compact[c] + popcount(mask bits 3c .. k-1).  tl_conv_fwd reads this
+ * (40 B per voxel) instead of the table (108 B) in the kernels that support it (tl_conv_args.table_compact). */
+int tl_rulebook_compact(const int32_t* table, int64_t n, int32_t* compact, tl_stream_t stream);
+
 /* tapmask u32[ceil(n_out/32)]: bit k set iff some row of the 32-row group has table[k][row] >= 0. */
 int tl_table_tapmask(const int32_t* table, int K, int64_t n_out, uint32_t* tapmask, tl_stream_t stream);
 
@@ -133,6 +139,8 @@ typedef struct tl_conv_args {
   /* != 0: every output row has at most ONE valid table entry (SparseInverseConv3d: the row's parent through its own
    * octant tap).  Kernels may then gather that single row once and route it to its tap instead of issuing K gathers. */
   int32_t table_one_hot;
+  /* optional column form of `table` (tl_rulebook_compact; K must be 27), NULL if absent */
+  const int32_t* table_compact;
 } tl_conv_args;
 
 int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);

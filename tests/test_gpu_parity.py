@@ -568,3 +568,32 @@ def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     b = ops.conv_wgrad(wide[:, 8:], torch.from_numpy(g).to(d), tab, n_out, K)
     assert torch.equal(a, b)                                                        # deterministic
     assert rel_err(a.cpu().numpy(), ref) < 2e-5
+
+
+def test_compact_rulebook_equals_table():
+    """Column form of the level-1 rulebook (tl_rulebook_compact, 9 bases + presence mask): the direct kernel fed with it
+    must reproduce the table-fed result bit for bit on a real geometry (incl. tile-boundary rows and a ragged last tile)."""
+    from treelearn_amd import ops
+    from treelearn_amd.geometry import build_geometry
+    from treelearn_amd.synth import make_tile
+    t = make_tile(extent=16.0, voxel=0.1, n_trees=8, fill=0.10, seed=2)
+    pts = torch.from_numpy(t["points"]).cuda(); bid = torch.zeros(len(pts), dtype=torch.int64, device="cuda")
+    g = build_geometry(pts, bid, 1, 0.1, 7, [500, 500, 1000])
+    lv = g.levels[0]
+    ct = getattr(lv.nbr, "_tl_compact", None)
+    assert ct is not None and ct.shape == (10, lv.n)
+    nbr = lv.nbr.cpu().numpy(); c = ct.cpu().numpy()
+    mask = c[9].astype(np.uint32)
+    for k in range(27):
+        col = k // 3
+        below = (mask >> np.uint32(3 * col)) & np.uint32((1 << (k % 3)) - 1)
+        dec = np.where((mask >> np.uint32(k)) & 1, c[col] + np.array([bin(int(v)).count("1") for v in np.unique(below)])[np.searchsorted(np.unique(below), below)], -1)
+        np.testing.assert_array_equal(dec, nbr[k])
+    for cin in (32, 64):
+        x = torch.randn(lv.n, cin, device="cuda").to(torch.bfloat16)
+        w = ops.pack_weight(torch.randn(32, 3, 3, 3, cin, device="cuda") * 0.05, torch.bfloat16)
+        res = torch.randn(lv.n, 32, device="cuda").to(torch.bfloat16)
+        a = ops.conv_fwd(x, w, lv.nbr, lv.n, residual=res)
+        plain = lv.nbr.clone()                                   # same table without the attached column form
+        b = ops.conv_fwd(x, w, plain, lv.n, residual=res)
+        assert torch.equal(a, b)

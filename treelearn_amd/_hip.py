@@ -25,7 +25,7 @@ class ConvArgs(_c.Structure):
         ("out", _vp), ("out_ld", _i64), ("stats", _vp),
         ("out2", _vp), ("out2_ld", _i64), ("out2_scale", _vp), ("out2_shift", _vp), ("out2_relu", _i32),
         ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
-        ("weight_frag", _vp), ("table_one_hot", _i32),
+        ("weight_frag", _vp), ("table_one_hot", _i32), ("table_compact", _vp),
     ]
 
 
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tl_voxel_mean_feats": (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
     "tl_rulebook_down": (_i32, [_vp, _i64, _vp, _vp, _I4, _i64, _vp, _vp, _vp, _vp]),
+    "tl_rulebook_compact": (_i32, [_vp, _i64, _vp, _vp]),
     "tl_table_tapmask": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),

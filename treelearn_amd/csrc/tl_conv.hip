@@ -271,7 +271,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (a->stats) return TL_ERR_UNSUPPORTED;
   if (a->dtype != TL_F32 && a->dtype != TL_BF16) return TL_ERR_ARG;
   ConvP p;
-  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.n_out = a->n_out; p.n_in = a->n_in;
+  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
   p.K = a->K; p.Cin = a->Cin; p.Cout = a->Cout; p.in_scale = a->in_scale; p.in_shift = a->in_shift;
   p.in_relu = a->in_relu; p.out_relu = a->out_relu; p.res = a->residual; p.res_ld = a->res_ld;
   p.out_scale = a->out_scale; p.out_shift = a->out_shift; p.out = a->out; p.out_ld = a->out_ld;

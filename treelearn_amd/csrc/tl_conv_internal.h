@@ -13,6 +13,7 @@ struct ConvP {
   const void* w;
   const void* w_frag;   // optional fragment-order copy of w (tl_pack_weight_frag) or nullptr
   const int32_t* table;
+  const int32_t* ctab;  // optional column form of a 27-tap table (tl_rulebook_compact) or nullptr
   int64_t n_out, n_in;
   int K, Cin, Cout;
   const float* in_scale; const float* in_shift; int in_relu, out_relu;
@@ -119,6 +120,21 @@ static __device__ __forceinline__ void epi_views8(const ConvP& p, int64_t row, i
   epi_store8<BF16>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, row, c0, v);
   if (p.out2) epi_store8<BF16>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, row, c0, v);
   if (p.out3) epi_store8<BF16>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, row, c0, v);
+}
+
+// One lane's 27 rulebook entries from the column form (9 bases + presence mask, tl_rulebook_compact)
+static __device__ __forceinline__ void decode_ctab(const int32_t* __restrict__ ctab, int64_t n, int64_t row, bool rvalid, int (&idx)[27]) {
+  int base[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) base[c] = rvalid ? ctab[(int64_t)c * n + row] : -1;
+  const uint32_t mask = rvalid ? (uint32_t)ctab[(int64_t)9 * n + row] : 0u;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const uint32_t m = (mask >> (3 * c)) & 7u;
+    idx[3 * c] = (m & 1u) ? base[c] : -1;
+    idx[3 * c + 1] = (m & 2u) ? base[c] + (int)(m & 1u) : -1;
+    idx[3 * c + 2] = (m & 4u) ? base[c] + (int)(m & 1u) + (int)((m >> 1) & 1u) : -1;
+  }
 }
 
 // tl_conv_bf16.hip

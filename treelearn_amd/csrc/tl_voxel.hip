@@ -321,6 +321,24 @@ __global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restr
   }
 }
 
+// 27-tap SubM rulebook -> column form: for each of the 9 (dx, dy) columns the row index of its first present dz neighbour,
+// plus one 27-bit presence mask.  The present neighbours of a column are CONSECUTIVE rows (rows are in ascending (b, x, y, z)
+// order with z fastest), so tap k = 3c + d is base[c] + popc(mask bits 3c .. k-1): 40 B per voxel instead of 108.
+__global__ void __launch_bounds__(kBlock) k_table_compact(const int32_t* __restrict__ t, int64_t n, int32_t* __restrict__ o) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t mask = 0;
+    for (int c = 0; c < 9; ++c) {
+      int base = -1;
+      for (int d = 2; d >= 0; --d) {
+        const int v = t[(int64_t)(3 * c + d) * n + r];
+        if (v >= 0) { base = v; mask |= 1u << (3 * c + d); }
+      }
+      o[(int64_t)c * n + r] = base;
+    }
+    o[(int64_t)9 * n + r] = (int32_t)mask;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) k_tapmask(const int32_t* __restrict__ table, int K, int64_t n, uint32_t* __restrict__ mask) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per row, 64 rows per wave
   const int lane = threadIdx.x & 63;
@@ -455,6 +473,13 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
   if (hipMemsetAsync(parent, 0xFF, Mf * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   if (hipMemsetAsync(inv, 0xFF, Mf * 8 * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_rulebook_compact(const int32_t* table, int64_t n, int32_t* compact, tl_stream_t stream) {
+  if (!table || !compact || n <= 0) return TL_ERR_ARG;
+  k_table_compact<<<tl_grid(n, kBlock), kBlock, 0, tl_s(stream)>>>(table, n, compact);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

@@ -1,6 +1,8 @@
 """Thin host wrappers over the HIP operators (tl_conv_fwd, tl_head_mlp, ...)."""
 import ctypes
 
+import os
+
 import torch
 
 from . import _hip
@@ -50,6 +52,7 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.tapmask = None
     a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
     a.table_one_hot = int(bool(one_hot))          # inverse conv: one valid entry per output row
+    a.table_compact = _hip.ptr(getattr(table, "_tl_compact", None)) if (table is not None and os.environ.get("TL_NO_COMPACT") != "1") else None
     a.n_out = n_out; a.n_in = x.shape[0]
     a.K = K; a.Cin = Cin; a.Cout = Cout; a.dtype = _hip.dtype_code(x.dtype)
     a.in_scale = in_scale.data_ptr() if in_scale is not None else None
