@@ -52,20 +52,21 @@ def host_cores():
 
 
 def cpu_baseline_worker():
-    """Oracle (CPU port of the same path) on a bounded sample: a 12x12 m tile of the config-2
-    generator, same voxel size / model; all usable host cores.  Runs in a child process."""
+    """Oracle (CPU port of the same path) on a bounded sample: a 26x26 m tile of the config-2
+    generator (about 40 % of the 40x40 m workload, 10-20 s of CPU work), same voxel size / model; all usable host cores.
+    Runs in a child process."""
     from oracle import model as om
     from treelearn_amd.synth import make_tile
     cores = host_cores()
     torch.set_num_threads(cores)
-    t = make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=0)
+    t = make_tile(extent=26.0, voxel=0.1, n_trees=27, fill=0.10, seed=0)
     pts = t["points"]; n = len(pts)
     sd = om.random_state_dict(7, channels=32, num_blocks=7)
     t0 = time.time()
     om.forward(sd, pts, t["feat"], np.zeros(n, np.int64), 1, voxel_size=0.1, num_blocks=7, spatial_shape=[500, 500, 1000])
     dt = time.time() - t0
     return dict(value=n / dt / 1e6, unit="Mpoints/s", cores=cores, kind="port",
-                sample=f"12x12 m tile of the config-2 generator (voxel 0.1 m, 7-level 32-ch model), {n} points, 1 forward, "
+                sample=f"26x26 m tile of the config-2 generator (voxel 0.1 m, 7-level 32-ch model), {n} points, 1 forward, "
                        f"fp32 torch-CPU oracle, {dt:.1f} s")
 
 
@@ -116,7 +117,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TL_BENCH_FORCE_DIST") == "1":          # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
