@@ -227,6 +227,12 @@ int tl_cell_keys(const double* xyz, int64_t n, double cell, double min_bound, co
 int64_t tl_downsample_ws_words(int64_t n);
 int tl_downsample_reduce(const double* xyz, const int64_t* sorted_keys, const int64_t* perm, int64_t n, float* out_xyz,
                          int64_t* first_idx, int64_t* point2vox, int64_t* n_voxels, int32_t* ws, tl_stream_t stream);
+/* Group means for `ensemble` (tree_learn/util/pipeline.py:113-141: pandas groupby(['x','y','z']).mean() over the rounded
+ * coordinates): keys sorted ascending with the stable permutation `perm`; per group and column the double-precision sum of
+ * the members in input order divided by their number.  src f32[n,C]; mean f64[n,C] capacity (first n_groups rows written);
+ * first_idx i64 = smallest original index of each group; ws i32[tl_downsample_ws_words(n)].  Deterministic. */
+int tl_group_mean(const float* src, int64_t n, int C, const int64_t* sorted_keys, const int64_t* perm, double* mean,
+                  int64_t* first_idx, int64_t* n_groups, int32_t* ws, tl_stream_t stream);
 int tl_verticality(const double* xyz_sorted, const int64_t* sorted_keys, int64_t n, double radius, const int64_t* extent2,
                    float* out, tl_stream_t stream);
 

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "tl_cell_keys": (_i32, [_vp, _i64, _c.c_double, _c.c_double, _vp, _i32, _vp, _vp, _vp]),
     "tl_downsample_ws_words": (_i64, [_i64]),
     "tl_downsample_reduce": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tl_group_mean": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_verticality": (_i32, [_vp, _vp, _i64, _c.c_double, _vp, _vp, _vp]),
     "tl_cluster_ws_bytes": (_i64, [_i64]),
     "tl_cluster_grid": (_i32, [_vp, _i64, _c.c_double, _vp, _vp, _vp, _vp]),

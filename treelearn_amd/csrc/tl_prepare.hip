@@ -98,6 +98,33 @@ __global__ void __launch_bounds__(256) k_ds_reduce(const double* __restrict__ xy
     }
 }
 
+// one thread per group (segment of equal sorted keys): per column the double sum of the members in input order / count
+__global__ void __launch_bounds__(256) k_group_mean(const float* __restrict__ src, int C, const int64_t* __restrict__ keys,
+                                                    const int64_t* __restrict__ perm, int64_t n, const int32_t* __restrict__ part,
+                                                    double* __restrict__ mean, int64_t* __restrict__ first_idx) {
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
+  uint32_t s = 0; bool head[kItems];
+  for (int j = 0; j < kItems; ++j) { const int64_t i = base + j; head[j] = i < n && (i == 0 || keys[i] != keys[i - 1]); s += head[j]; }
+  uint32_t tot; int64_t grp = block_scan3(s, &tot) + (uint32_t)part[blockIdx.x];
+  for (int j = 0; j < kItems; ++j)
+    if (head[j]) {
+      const int64_t i = base + j, key = keys[i];
+      int64_t cnt = 0;
+      for (int64_t q = i; q < n && keys[q] == key; ++q) ++cnt;
+      const double inv = 1.0 / (double)cnt;
+      for (int c0 = 0; c0 < C; c0 += 8) {                      // eight columns at a time: bounded registers, rows re-read from L2
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t q = i; q < i + cnt; ++q) {
+          const float* row = src + perm[q] * (int64_t)C + c0;
+          for (int c = 0; c < 8; ++c) if (c0 + c < C) acc[c] += (double)row[c];
+        }
+        for (int c = 0; c < 8; ++c) if (c0 + c < C) mean[grp * C + c0 + c] = acc[c] * inv;
+      }
+      first_idx[grp] = perm[i];
+      ++grp;
+    }
+}
+
 __device__ __forceinline__ int64_t lower_bound(const int64_t* __restrict__ a, int64_t n, int64_t v) {
   int64_t lo = 0, hi = n;
   while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
@@ -184,6 +211,18 @@ int tl_downsample_reduce(const double* xyz, const int64_t* sorted_keys, const in
   k_head_partials<<<(unsigned)nb, 256, 0, s>>>(sorted_keys, n, ws);
   k_head_scan<<<1, 256, 0, s>>>(ws, nb, n_voxels);
   k_ds_reduce<<<(unsigned)nb, 256, 0, s>>>(xyz, sorted_keys, perm, n, ws, out_xyz, first_idx, point2vox);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_group_mean(const float* src, int64_t n, int C, const int64_t* sorted_keys, const int64_t* perm, double* mean, int64_t* first_idx,
+                  int64_t* n_groups, int32_t* ws, tl_stream_t stream) {
+  if (!src || !sorted_keys || !perm || !mean || !first_idx || !n_groups || !ws || n <= 0 || C <= 0) return TL_ERR_ARG;
+  const int64_t nb = tl_cdiv(n, kTile);
+  hipStream_t s = tl_s(stream);
+  k_head_partials<<<(unsigned)nb, 256, 0, s>>>(sorted_keys, n, ws);
+  k_head_scan<<<1, 256, 0, s>>>(ws, nb, n_groups);
+  k_group_mean<<<(unsigned)nb, 256, 0, s>>>(src, C, sorted_keys, perm, n, ws, mean, first_idx);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

@@ -11,40 +11,39 @@ def ensemble(coords, semantic_scores, semantic_labels, offset_predictions, offse
     """Mean of duplicate predictions keyed by coords rounded to 0.01 m, output sorted by (x, y, z).
 
     Reference: pandas `df.round({'x':2,'y':2,'z':2}).groupby(['x','y','z']).mean()`.  Here: the float32 rounding
-    np.round(x, 2) = rint(x * 100) / 100 gives integer keys; one device sort + segmented mean (fp64 accumulation, as the
-    groupby kernels do); integer label columns are averaged as floats then truncated, like the reference (:130,135,138).
+    np.round(x, 2) = rint(x * 100) / 100 gives integer keys; one stable device sort, then `tl_group_mean`: one thread per
+    group adds its members in input order in fp64 (as the groupby kernels do) over all 40-odd columns at once; integer label
+    columns are averaged as floats then truncated, like the reference (:130,135,138).
     """
+    L = _hip.lib()
     T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)                       # noqa: E731
     c = T(coords).float()
     q = torch.round(c * 100.0)                                    # float32 multiply + rint == np.round(., 2) numerator
     qi = q.to(torch.int64)
-    off = qi.min(dim=0).values
-    r = qi - off
+    r = qi - qi.min(dim=0).values
     span = r.max(dim=0).values + 1
     key = (r[:, 0] * span[1] + r[:, 1]) * span[2] + r[:, 2]       # lexicographic (x, y, z)
-    ukey, inv = torch.unique(key, sorted=True, return_inverse=True)
-    n = ukey.shape[0]
-    cnt = torch.zeros(n, dtype=torch.float64, device=c.device).index_add_(0, inv, torch.ones_like(key, dtype=torch.float64))
-
-    def gmean(a):
-        a = T(a)
-        two_d = a.dim() == 2
-        a2 = a.reshape(a.shape[0], -1).double()
-        s = torch.zeros((n, a2.shape[1]), dtype=torch.float64, device=c.device).index_add_(0, inv, a2)
-        m = s / cnt[:, None]
-        return m if two_d else m[:, 0]
-
-    first = torch.zeros(n, dtype=torch.int64, device=c.device).scatter_reduce_(0, inv, torch.arange(len(key), device=c.device), "amin", include_self=False)
+    skey, perm = torch.sort(key, stable=True)
+    cols = [semantic_scores, semantic_labels, offset_predictions, offset_labels, instance_labels, feats, input_feats]
+    mats = [T(a).reshape(len(key), -1).float() for a in cols]
+    widths = [m.shape[1] for m in mats]
+    src = torch.cat(mats, 1).contiguous()                         # one [N, 2+1+3+3+1+32+F] matrix -> one fused kernel
+    n, C = src.shape
+    mean = torch.empty((n, C), dtype=torch.float64, device=src.device)
+    first = torch.empty(n, dtype=torch.int64, device=src.device); m = torch.empty(1, dtype=torch.int64, device=src.device)
+    ws = torch.empty(int(L.tl_downsample_ws_words(n)), dtype=torch.int32, device=src.device)
+    _hip.check(L.tl_group_mean(_hip.ptr(src), n, C, _hip.ptr(skey), _hip.ptr(perm), _hip.ptr(mean), _hip.ptr(first), _hip.ptr(m), _hip.ptr(ws),
+                               _hip.stream()), "tl_group_mean")
+    M = int(m.item())
+    mean = mean[:M]; first = first[:M]
+    parts = torch.split(mean, widths, dim=1)
     out_coords = (q[first] / 100.0).float()                       # the rounded coordinates themselves
-    res = (out_coords.cpu().numpy(),
-           gmean(semantic_scores).float().cpu().numpy(),
-           gmean(semantic_labels).cpu().numpy().astype('int64').flatten(),
-           gmean(offset_predictions).float().cpu().numpy(),
-           gmean(offset_labels).float().cpu().numpy(),
-           gmean(instance_labels).cpu().numpy().astype('int64').flatten(),
-           gmean(feats).float().cpu().numpy(),
-           gmean(input_feats).float().cpu().numpy())
-    return res
+    f32 = lambda t: t.float().cpu().numpy()                                                  # noqa: E731
+    i64 = lambda t: t[:, 0].cpu().numpy().astype('int64').flatten()                          # noqa: E731
+    one = lambda t, a: t[:, 0] if np.ndim(a) == 1 else t                                     # noqa: E731
+    return (out_coords.cpu().numpy(),
+            f32(one(parts[0], semantic_scores)), i64(parts[1]), f32(one(parts[2], offset_predictions)), f32(one(parts[3], offset_labels)),
+            i64(parts[4]), f32(one(parts[5], feats)), f32(one(parts[6], input_feats)))
 
 
 def assign_remaining_points_nearest_neighbor(coords, predictions, remaining_points_idx, n_neighbors=5, device="cuda"):
