@@ -63,8 +63,9 @@ class TreeLearn(nn.Module):
         self._plan = None
 
     def train(self, mode=True):
+        if mode != self.training:                      # the packed weights of the fused plan stay valid across repeated .eval() calls
+            self._plan = None
         super().train(mode)
-        self._plan = None
         for name in self.fixed_modules:
             for m in getattr(self, name).modules():
                 if isinstance(m, nn.BatchNorm1d):

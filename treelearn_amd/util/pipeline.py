@@ -1,6 +1,8 @@
 """Tile loop and instance grouping -- mirrors reference tree_learn/util/pipeline.py
 (`get_pointwise_preds` :79-109, `get_instances` :145-169, `group_dbscan` :173-180,
 `make_labels_consecutive` :195-206) with the device work on the HIP library."""
+import os
+
 import numpy as np
 import torch
 
@@ -24,69 +26,94 @@ def _to_device_async(batch, stream):
 
 
 def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True):
-    """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one small D2H
-    instead of the reference's three full-tile `.cpu()` copies), `coords += centers`, and skip tiles
-    whose forward raises "... reach zero!!! ..." (pipeline.py:91-97).  The next tile's H2D copy runs on a
-    side stream while the current tile computes."""
+    """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one packed D2H copy instead of the
+    reference's full-tile `.cpu()` copies), `coords += centers`, and skip tiles whose forward raises
+    "... reach zero!!! ..." (pipeline.py:91-97).
+
+    Software-pipelined by one tile: the forward of tile i+1 is enqueued on the main stream before tile i is read back on a
+    second stream (which waits only for the event recorded after forward i), so the synchronising read-back, the host-side
+    bookkeeping and the launch overhead of the next tile hide behind GPU work.  The next tile's H2D copy runs on a third
+    (copy) stream.  Building the next tile's geometry concurrently on a side stream was measured slower (the convs already
+    fill the GPU and the geometry's host syncs stall the launch thread) and is not done."""
     outs = [[] for _ in range(8)]
     use_gpu = torch.cuda.is_available()
     copy_stream = torch.cuda.Stream() if use_gpu else None
+    rb_stream = torch.cuda.Stream() if use_gpu else None
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
+
+    def read_back(batch, gbatch, output, done):
+        if done is not None:
+            with torch.cuda.stream(rb_stream):
+                rb_stream.wait_event(done)
+                return _read_back(batch, gbatch, output)
+        return _read_back(batch, gbatch, output)
+
+    def _read_back(batch, gbatch, output):
+        dev = output['offset_predictions'].device
+        idx = torch.nonzero(gbatch['masks_inner'].to(dev)).squeeze(1)          # one small sync; 4-5 % of the rows survive
+        ci = None
+
+        def rows(t):
+            """Inner rows of a per-point array: gathered on the device if it lives there, else on the host."""
+            nonlocal ci
+            if t.is_cuda:
+                return t.index_select(0, idx)
+            if ci is None:
+                ci = idx.cpu()
+            return t.index_select(0, ci)
+
+        bb = output['backbone_feats']
+        # every device-side result goes home in ONE packed D2H copy (float columns) instead of one copy + sync per array
+        cols = [rows(output['semantic_prediction_logits']).float(), rows(output['offset_predictions']).float()]
+        if bb is not None:
+            cols.append(rows(bb).float())
+        on_dev = {}
+        for k in ('offset_labels', 'coords', 'centers', 'input_feats'):
+            src = gbatch[k] if (torch.is_tensor(gbatch.get(k)) and gbatch[k].is_cuda) else batch[k]
+            if src.is_cuda:
+                on_dev[k] = len(cols); cols.append(rows(src).float().reshape(idx.shape[0], -1))
+        widths = [c.shape[1] for c in cols]
+        parts = list(torch.split(torch.cat(cols, 1).cpu(), widths, dim=1))
+        get = lambda k: parts[on_dev[k]] if k in on_dev else rows(batch[k])                  # noqa: E731
+        lab = lambda k: rows(batch[k]).cpu() if batch[k].is_cuda else rows(batch[k])         # noqa: E731
+        outs[0].append(parts[0]); outs[1].append(lab('semantic_labels'))
+        outs[2].append(parts[1]); outs[3].append(get('offset_labels'))
+        outs[4].append(get('coords') + get('centers')); outs[5].append(lab('instance_labels'))
+        outs[6].append(parts[2] if bb is not None else torch.zeros((idx.shape[0], 0))); outs[7].append(get('input_feats'))
+
     with torch.no_grad():
         model.eval()
-        two_phase = use_gpu and hasattr(model, "prepare") and hasattr(model, "infer")
-
-        def stage(b):
-            """H2D on the copy stream, then (two-phase models) voxel hashing + rulebooks on the model's side stream;
-            a tile whose U-Net would collapse raises here and is reported as skipped."""
-            gb, ev = _to_device_async(b, copy_stream) if use_gpu else (b, None)
-            if not two_phase:
-                return gb, ev, None, None
-            try:
-                torch.cuda.current_stream().wait_event(ev)
-                return gb, None, model.prepare(gb), None
-            except Exception as e:                                     # noqa: BLE001
-                return gb, None, None, e
-
         it = iter(dataloader)
         nxt = next(it, None)
-        staged = stage(nxt) if nxt is not None else None
+        staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+        pending = None                                                 # tile whose results are still on the device
         while nxt is not None:
-            batch, (gbatch, ev, handle, err) = nxt, staged
+            batch, (gbatch, ev) = nxt, staged
             gbatch['voxel_size'] = vs
-            try:
-                if err is not None:
-                    raise err
-                if two_phase:
-                    output = model.infer(handle)                       # convs of this tile go on the main stream ...
-                else:
-                    if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
-                    output = model(gbatch, return_loss=False)
-            except Exception as e:                                     # noqa: BLE001
-                if "reach zero!!!" in str(e):
-                    if logger:
-                        logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
-                                    'If this does not happen too often, the results should not be influenced.')
-                    nxt = next(it, None)
-                    staged = stage(nxt) if nxt is not None else None
-                    continue
-                raise
             nxt = next(it, None)
-            staged = stage(nxt) if nxt is not None else None           # ... while the next tile's geometry is built
-            dev = output['offset_predictions'].device
-            m_dev = gbatch['masks_inner'].to(dev)
-            idx = torch.nonzero(m_dev).squeeze(1)                      # one small sync; 4-5 % of the rows survive
-            off = output['offset_predictions'].index_select(0, idx).cpu()
-            sem = output['semantic_prediction_logits'].index_select(0, idx).cpu()
-            bb = output['backbone_feats']
-            bb = bb.index_select(0, idx).cpu() if bb is not None else torch.zeros((idx.shape[0], 0))
-            ci = idx.cpu()
-            sel = lambda t: t.index_select(0, ci) if not t.is_cuda else t.index_select(0, idx).cpu()   # noqa: E731
-            outs[0].append(sem); outs[1].append(sel(batch['semantic_labels']))
-            outs[2].append(off); outs[3].append(sel(batch['offset_labels']))
-            outs[4].append(sel(batch['coords']) + sel(batch['centers'])); outs[5].append(sel(batch['instance_labels']))
-            outs[6].append(bb); outs[7].append(sel(batch['input_feats']))
+            staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+            try:
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                output = model(gbatch, return_loss=False)
+            except Exception as e:                                     # noqa: BLE001
+                if "reach zero!!!" not in str(e):
+                    raise
+                if logger:
+                    logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
+                                'If this does not happen too often, the results should not be influenced.')
+                continue
+            done = None
+            if use_gpu:
+                done = torch.cuda.Event(); done.record()
+            if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":           # A/B switch: read every tile back right away
+                read_back(batch, gbatch, output, None)
+                continue
+            if pending is not None:
+                read_back(*pending)                                    # tile i-1 comes home while tile i computes
+            pending = (batch, gbatch, output, done)
+        if pending is not None:
+            read_back(*pending)
     if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
         return tuple(np.zeros((0,), np.float32) for _ in outs)
     return tuple(torch.cat(o, 0).numpy() for o in outs)
