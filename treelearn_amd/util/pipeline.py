@@ -25,7 +25,7 @@ def _to_device_async(batch, stream):
     return out, ev
 
 
-def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True):
+def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True, return_tile_rows=False):
     """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one packed D2H copy instead of the
     reference's full-tile `.cpu()` copies), `coords += centers`, and skip tiles whose forward raises
     "... reach zero!!! ..." (pipeline.py:91-97).
@@ -36,12 +36,18 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     (copy) stream.  Building the next tile's geometry concurrently on a side stream was measured slower (the convs already
     fill the GPU and the geometry's host syncs stall the launch thread) and is not done."""
     outs = [[] for _ in range(8)]
+    tile_rows = []                                                     # (position in the iterable, inner rows) of every tile that produced output
     use_gpu = torch.cuda.is_available()
     copy_stream = torch.cuda.Stream() if use_gpu else None
     rb_stream = torch.cuda.Stream() if use_gpu else None
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
 
-    def read_back(batch, gbatch, output, done):
+    def read_back(pos, batch, gbatch, output, done):
+        n0 = sum(len(o) for o in outs[0])
+        _read_back_on(batch, gbatch, output, done)
+        tile_rows.append((pos, sum(len(o) for o in outs[0]) - n0))
+
+    def _read_back_on(batch, gbatch, output, done):
         if done is not None:
             with torch.cuda.stream(rb_stream):
                 rb_stream.wait_event(done)
@@ -87,8 +93,10 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
         nxt = next(it, None)
         staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
         pending = None                                                 # tile whose results are still on the device
+        pos = -1
         while nxt is not None:
             batch, (gbatch, ev) = nxt, staged
+            pos += 1
             gbatch['voxel_size'] = vs
             nxt = next(it, None)
             staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
@@ -107,16 +115,18 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             if use_gpu:
                 done = torch.cuda.Event(); done.record()
             if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":           # A/B switch: read every tile back right away
-                read_back(batch, gbatch, output, None)
+                read_back(pos, batch, gbatch, output, None)
                 continue
             if pending is not None:
                 read_back(*pending)                                    # tile i-1 comes home while tile i computes
-            pending = (batch, gbatch, output, done)
+            pending = (pos, batch, gbatch, output, done)
         if pending is not None:
             read_back(*pending)
     if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
-        return tuple(np.zeros((0,), np.float32) for _ in outs)
-    return tuple(torch.cat(o, 0).numpy() for o in outs)
+        res = tuple(np.zeros((0,), np.float32) for _ in outs)
+    else:
+        res = tuple(torch.cat(o, 0).numpy() for o in outs)
+    return (res, tile_rows) if return_tile_rows else res
 
 
 def make_labels_consecutive(labels, start_num):

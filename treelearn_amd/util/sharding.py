@@ -45,11 +45,13 @@ def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, d
     from .pipeline import get_pointwise_preds
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = assign_tiles([t["coords"].shape[0] for t in tiles], world)[rank]
-    per_tile = []
-    for i in mine:                                       # one call per tile keeps per-tile boundaries
-        res = get_pointwise_preds(model, [tiles[i]], config, logger)
-        if res[0].shape[0]:                              # skipped ("reach zero!!!") or empty-inner tiles contribute nothing
-            per_tile.append((i, res))
+    # one pipelined pass over this rank's tiles; the per-tile row counts restore the global tile order afterwards
+    res, rows = get_pointwise_preds(model, [tiles[i] for i in mine], config, logger, return_tile_rows=True)
+    per_tile, off = [], 0
+    for pos, n in rows:
+        if n:                                            # skipped ("reach zero!!!") or empty-inner tiles contribute nothing
+            per_tile.append((mine[pos], tuple(r[off:off + n] for r in res)))
+        off += n
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     # header: (tile index, rows) per local tile; payload: the 8 arrays concatenated row-wise
     hdr = torch.tensor([[i, r[0].shape[0]] for i, r in per_tile], dtype=torch.int64, device=dev).reshape(-1, 2)
