@@ -331,6 +331,11 @@ def g6_g7_next_rows():
     pts = rng.normal(size=(600, 3)).astype(np.float32) + rng.integers(0, 3, 600)[:, None].astype(np.float32) * 4
     pred = (pts[:, 0] // 4 + 1).clip(1, 3).astype(np.int64); pred[rng.uniform(size=600) < 0.3] = -1
     out.update(k_coords=pts, k_pred=pred, k_out=ref_pipe.assign_remaining_points_nearest_neighbor(pts, pred, -1))
+    # propagate_preds (util/pipeline.py:300-331): labels incl. negatives, ties between equally frequent labels
+    rng2 = np.random.default_rng(77)
+    src = rng2.normal(size=(3000, 3)).astype(np.float32) * 4; tgt = rng2.normal(size=(5000, 3)).astype(np.float32) * 4
+    sp = rng2.integers(-1, 12, 3000).astype(np.int64)
+    out.update(p_src=src, p_pred=sp, p_tgt=tgt, p_out5=ref_pipe.propagate_preds(src, sp, tgt, 5), p_out4=ref_pipe.propagate_preds(src, sp, tgt, 4))
     save("g6_g7_next.npz", **out)
 
 

@@ -433,6 +433,17 @@ def test_next_rows_device_tiler_vs_golden(golden_dir):
     assert len(fast) == n and not bool(fast[0]["masks_off"].any()) and fast[0]["coords"].is_cuda
 
 
+def test_next_rows_propagate_preds_vs_golden(golden_dir):
+    """propagate_preds (k-NN label propagation, util/pipeline.py:300-331) against the reference's own output, k = 5 and k = 4
+    (even k: ties between equally frequent labels resolve to the smallest label, negatives included)."""
+    from treelearn_amd.util.postprocess import propagate_preds
+    g = np.load(os.path.join(golden_dir, "g6_g7_next.npz"))
+    for k in (5, 4):
+        ours = propagate_preds(g["p_src"], g["p_pred"], g["p_tgt"], k)
+        assert ours.dtype == np.int64
+        np.testing.assert_array_equal(ours, g[f"p_out{k}"])
+
+
 def test_next_rows_voxel_downsample_vs_oracle():
     """SURVEY.md 8f #4 (parity unpinned by the reference: open3d is absent): the device down-sample equals the numpy
     restatement bit for bit -- voxel set, in-order double means -> float32 -> 2 decimals, first indices, trace."""

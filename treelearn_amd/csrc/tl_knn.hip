@@ -11,7 +11,7 @@ constexpr int kMaxK = 8;
 
 template <int KK>
 __global__ void __launch_bounds__(kBlock) k_knn_vote(const float* __restrict__ ref, const int64_t* __restrict__ rlab, int64_t nr,
-                                                     const float* __restrict__ q, int64_t nq, int64_t* __restrict__ out) {
+                                                     const float* __restrict__ q, int64_t nq, int k, int64_t* __restrict__ out) {
   __shared__ float sx[kBlock], sy[kBlock], sz[kBlock];
   __shared__ int64_t sl[kBlock];
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(kBlock) k_knn_vote(const float* __restrict__ r
     }
   }
   if (!live) return;
-  const int kk = (int)(nr < KK ? nr : KK);
+  const int kk = (int)(nr < k ? nr : k);                  // k <= KK: the vote looks at the k nearest of the KK kept
   int best_cnt = 0; int64_t best_lab = 0;
   for (int a = 0; a < kk; ++a) {
     int c = 0;
@@ -57,10 +57,10 @@ extern "C" int tl_knn_vote(const float* ref_xyz, const int64_t* ref_label, int64
   const unsigned g = (unsigned)tl_cdiv(nq, kBlock);
   hipStream_t s = tl_s(stream);
   switch (k) {
-    case 1: k_knn_vote<1><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, out_label); break;
-    case 3: k_knn_vote<3><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, out_label); break;
-    case 5: k_knn_vote<5><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, out_label); break;
-    default: k_knn_vote<kMaxK><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, out_label); break;
+    case 1: k_knn_vote<1><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, k, out_label); break;
+    case 3: k_knn_vote<3><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, k, out_label); break;
+    case 5: k_knn_vote<5><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, k, out_label); break;
+    default: k_knn_vote<kMaxK><<<g, kBlock, 0, s>>>(ref_xyz, ref_label, nr, q_xyz, nq, k, out_label); break;
   }
   TL_CHECK_LAUNCH();
   return TL_OK;

@@ -63,3 +63,15 @@ def assign_remaining_points_nearest_neighbor(coords, predictions, remaining_poin
     _hip.check(L.tl_knn_vote(_hip.ptr(ref), _hip.ptr(lab), len(ri), _hip.ptr(qry), len(qi), int(n_neighbors), _hip.ptr(out), _hip.stream()), "tl_knn_vote")
     predictions[qi] = out.cpu().numpy()
     return predictions.astype(np.int64)
+
+
+def propagate_preds(source_coords, source_preds, target_coords, n_neighbors, n_jobs=1, device="cuda"):
+    """Every target point takes the most frequent label among its k nearest source points, the smallest label on ties
+    (reference util/pipeline.py:300-331: sklearn NearestNeighbors + np.bincount(...).argmax()); exact k-NN on the GPU."""
+    L = _hip.lib()
+    ref = torch.from_numpy(np.ascontiguousarray(source_coords, dtype=np.float32)).to(device)
+    lab = torch.from_numpy(np.ascontiguousarray(source_preds).astype(np.int64)).to(device)
+    qry = torch.from_numpy(np.ascontiguousarray(target_coords, dtype=np.float32)).to(device)
+    out = torch.empty(len(qry), dtype=torch.int64, device=ref.device)
+    _hip.check(L.tl_knn_vote(_hip.ptr(ref), _hip.ptr(lab), len(ref), _hip.ptr(qry), len(qry), int(n_neighbors), _hip.ptr(out), _hip.stream()), "tl_knn_vote")
+    return out.cpu().numpy()
