@@ -99,7 +99,9 @@ def test_reach_zero_raises():
     (32, 32, 27, 333), (64, 32, 27, 333), (96, 96, 27, 333), (32, 64, 8, 333), (64, 32, 8, 333), (384, 192, 1, 700),
     (224, 224, 27, 333), (4, 32, 27, 333), (16, 8, 27, 333), (24, 40, 8, 333), (4, 16, 27, 5000),
     # > 16384 rows: the 128-row output-stationary MFMA kernels (smaller sizes take the split-tap small-level kernel)
-    (32, 32, 27, 17001), (64, 64, 27, 16500), (128, 64, 27, 16400), (96, 96, 8, 16390), (64, 32, 1, 20000), (224, 224, 8, 16385)])
+    (32, 32, 27, 17001), (64, 64, 27, 16500), (128, 64, 27, 16400), (96, 96, 8, 16390), (64, 32, 1, 20000), (224, 224, 8, 16385),
+    # mid-size levels: the 4-wave small-level kernel with fragment-order weights (more than 512 output blocks)
+    (160, 160, 27, 6500), (320, 160, 27, 6000)])
 def test_conv_fwd_vs_oracle(cin, cout, K, n_out):
     from treelearn_amd import ops
     rng = np.random.default_rng(cin * 1000 + cout + K)
@@ -354,7 +356,8 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
 
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 17001), (64, 32, 27, 16500), (32, 64, 8, 16400), (64, 32, 8, 20000), (64, 96, 8, 16390),
                                                (96, 64, 8, 16385), (64, 32, 1, 20000), (64, 64, 27, 16500), (32, 32, 27, 300), (4, 32, 27, 5000), (128, 64, 27, 16400), (96, 96, 27, 16390),
-                                               (128, 128, 27, 16401), (192, 96, 27, 16402), (96, 128, 8, 16403), (256, 128, 27, 16404)])
+                                               (128, 128, 27, 16401), (192, 96, 27, 16402), (96, 128, 8, 16403), (256, 128, 27, 16404),
+                                               (160, 160, 27, 6500), (320, 160, 27, 6000), (192, 192, 27, 1200)])
 def test_conv_bf16_no_prologue_multi_output(cin, cout, K, n_out):
     """Pre-activated form: no gather-side prologue, residual, three output views (raw, bn+relu, bn+relu) --
     exercises the weights-in-LDS direct kernel (level-1 shapes), the stream kernel (fragment-shaped gathers),
