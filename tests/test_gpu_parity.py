@@ -611,3 +611,50 @@ def test_compact_rulebook_equals_table():
         plain = lv.nbr.clone()                                   # same table without the attached column form
         b = ops.conv_fwd(x, w, plain, lv.n, residual=res)
         assert torch.equal(a, b)
+
+
+def test_kernel_families_agree_on_a_real_tile():
+    """Size-independent check at realistic scale (24 x 24 m tile, 0.7 M points, all seven levels populated): the bf16 forward
+    must not depend on WHICH kernel family serves a layer.  Default dispatch (direct / stream-q / stream / small, column-form
+    rulebook, gather-once inverse convs) vs the fallbacks forced through tl_set_tuning (no direct, no stream-q, no stream ->
+    tile kernel; 4-wave small kernel with row-major weights; plain tables): same outputs up to bf16 re-association."""
+    from oracle import model as om
+    from treelearn_amd import _hip
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile
+    b = make_batch([make_tile(extent=24.0, voxel=0.1, n_trees=20, fill=0.10, seed=4)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
+    model.load_state_dict(om.random_state_dict(11, channels=32, num_blocks=7)); model = model.cuda().eval()
+    L = _hip.lib()
+
+    def run(**tuning):
+        for k, v in tuning.items():
+            _hip.check(L.tl_set_tuning(k.encode(), v), k)
+        try:
+            with torch.no_grad():
+                o = model(gb, return_loss=False)
+            return {k: v.float().cpu().numpy() for k, v in o.items()}
+        finally:
+            for k in tuning:
+                _hip.check(L.tl_set_tuning(k.encode(), {"small_mode": 0}.get(k, 1)), k)
+
+    ref = run()
+    os.environ["TL_NO_COMPACT"] = "1"
+    try:
+        variants = [run(streamq=0), run(direct=0), run(direct=0, stream=0), run(small_mode=3)]
+    finally:
+        os.environ.pop("TL_NO_COMPACT")
+    for i, v in enumerate(variants):
+        for k in ("semantic_prediction_logits", "offset_predictions", "backbone_feats"):
+            assert rel_err(v[k], ref[k]) < 4e-2, (i, k, rel_err(v[k], ref[k]))     # random weights amplify bf16 re-association ~2 %
+    # and the bf16 result stays within bf16 distance of the exact-fp32 mode on the same tile
+    m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1)
+    m32.load_state_dict(model.state_dict()); m32 = m32.cuda().eval()
+    with torch.no_grad():
+        o32 = m32(gb, return_loss=False)
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        e32 = o32[k].float().cpu().numpy()
+        assert rel_err(ref[k], e32) < 6e-2, k
+        for i, v in enumerate(variants):
+            assert rel_err(v[k], e32) < 6e-2, (i, k)
