@@ -185,6 +185,24 @@ def test_forward_default_model_config1_vs_oracle():
         assert torch.equal(out[k], out2[k])
 
 
+def test_forward_fp32_mid_tile_vs_oracle():
+    """12 x 12 m tile at 0.1 m (140 k points; levels 1-3 above the 16 k-row threshold, so the fp32 direct and stream kernels run
+    on real rulebooks, the deeper levels on the small-level kernel): fp32 forward within 1e-3 of the CPU oracle."""
+    from treelearn_amd.model import TreeLearn
+    t = make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=0)
+    batch = make_batch([t])
+    sd = om.random_state_dict(7, channels=32, num_blocks=7)
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        out = model(batch, return_loss=False)
+    ref = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 1,
+                     voxel_size=0.1, num_blocks=7, spatial_shape=[500, 500, 1000])
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, k
+
+
 def test_tile_loop_golden_g9(golden_dir):
     """get_pointwise_preds semantics (skip rule, +centers, masks_inner) with the golden's fake model."""
     from treelearn_amd.util.pipeline import get_pointwise_preds
