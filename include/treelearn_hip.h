@@ -104,9 +104,6 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
  * (40 B per voxel) instead of the table (108 B) in the kernels that support it (tl_conv_args.table_compact). */
 int tl_rulebook_compact(const int32_t* table, int64_t n, int32_t* compact, tl_stream_t stream);
 
-/* tapmask u32[ceil(n_out/32)]: bit k set iff some row of the 32-row group has table[k][row] >= 0. */
-int tl_table_tapmask(const int32_t* table, int K, int64_t n_out, uint32_t* tapmask, tl_stream_t stream);
-
 /* ------------------------------------------------------------------ sparse convolution
  * Replaces spconv SubMConv3d / SparseConv3d / SparseInverseConv3d forward (blocks.py:57-70,104-123,
  * tree_learn.py:37-39) and Custom1x1Subm3d's torch.mm (blocks.py:29-39), with the surrounding
@@ -121,14 +118,12 @@ typedef struct tl_conv_args {
   const void* in;        int64_t in_ld;   /* row stride in elements (>= Cin) */
   const void* weight;                     /* [K][Cout][Cin], same dtype as `in` */
   const int32_t* table;                   /* [K][n_out], or NULL = identity (K must be 1) */
-  const uint32_t* tapmask;                /* [ceil(n_out/32)] or NULL */
   int64_t n_out;         int64_t n_in;
   int32_t K;             int32_t Cin;     int32_t Cout;   int32_t dtype;   /* TL_F32 | TL_BF16 */
   const float* in_scale; const float* in_shift;  int32_t in_relu;  int32_t out_relu;
   const void* residual;  int64_t res_ld;
   const float* out_scale; const float* out_shift;
   void* out;             int64_t out_ld;
-  float* stats;                           /* optional f32[2*Cout]: += sum, sumsq of (acc+residual) per channel */
   /* up to two extra views of y = acc + residual, each with its own affine/ReLU -- lets a producer store the
    * raw tensor (for the residual branch) AND relu(bn_next(y)) (for the next conv's gathers) in one pass: */
   void* out2; int64_t out2_ld; const float* out2_scale; const float* out2_shift; int32_t out2_relu;

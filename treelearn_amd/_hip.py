@@ -18,11 +18,11 @@ _vp, _i64, _i32, _f32 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_float
 
 class ConvArgs(_c.Structure):
     _fields_ = [
-        ("in_", _vp), ("in_ld", _i64), ("weight", _vp), ("table", _vp), ("tapmask", _vp),
+        ("in_", _vp), ("in_ld", _i64), ("weight", _vp), ("table", _vp),
         ("n_out", _i64), ("n_in", _i64), ("K", _i32), ("Cin", _i32), ("Cout", _i32), ("dtype", _i32),
         ("in_scale", _vp), ("in_shift", _vp), ("in_relu", _i32), ("out_relu", _i32),
         ("residual", _vp), ("res_ld", _i64), ("out_scale", _vp), ("out_shift", _vp),
-        ("out", _vp), ("out_ld", _i64), ("stats", _vp),
+        ("out", _vp), ("out_ld", _i64),
         ("out2", _vp), ("out2_ld", _i64), ("out2_scale", _vp), ("out2_shift", _vp), ("out2_relu", _i32),
         ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
         ("weight_frag", _vp), ("table_one_hot", _i32), ("table_compact", _vp),
@@ -52,7 +52,6 @@ PROTOTYPES = {
     "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
     "tl_rulebook_down": (_i32, [_vp, _i64, _vp, _vp, _I4, _i64, _vp, _vp, _vp, _vp]),
     "tl_rulebook_compact": (_i32, [_vp, _i64, _vp, _vp]),
-    "tl_table_tapmask": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -268,7 +268,6 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (!a->table && a->K != 1) return TL_ERR_ARG;
   if ((a->in_scale == nullptr) != (a->in_shift == nullptr)) return TL_ERR_ARG;
   if ((a->out_scale == nullptr) != (a->out_shift == nullptr)) return TL_ERR_ARG;
-  if (a->stats) return TL_ERR_UNSUPPORTED;
   if (a->dtype != TL_F32 && a->dtype != TL_BF16) return TL_ERR_ARG;
   ConvP p;
   p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;

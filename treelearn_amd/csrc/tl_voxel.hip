@@ -339,19 +339,6 @@ __global__ void __launch_bounds__(kBlock) k_table_compact(const int32_t* __restr
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_tapmask(const int32_t* __restrict__ table, int K, int64_t n, uint32_t* __restrict__ mask) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per row, 64 rows per wave
-  const int lane = threadIdx.x & 63;
-  uint32_t m = 0;
-  for (int k = 0; k < K; ++k) {
-    const bool v = (i < n) && table[(int64_t)k * n + i] >= 0;
-    const unsigned long long bal = __ballot(v);
-    const uint32_t half = (lane < 32) ? (uint32_t)bal : (uint32_t)(bal >> 32);
-    if (half) m |= 1u << k;
-  }
-  if ((lane & 31) == 0 && i < n) mask[i >> 5] = m;
-}
-
 // ---------------------------------------------------------------- optional voxel features (use_coords/use_feats)
 __global__ void __launch_bounds__(kBlock) k_fill_i32(int32_t* p, int64_t n, int32_t v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -480,13 +467,6 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
 int tl_rulebook_compact(const int32_t* table, int64_t n, int32_t* compact, tl_stream_t stream) {
   if (!table || !compact || n <= 0) return TL_ERR_ARG;
   k_table_compact<<<tl_grid(n, kBlock), kBlock, 0, tl_s(stream)>>>(table, n, compact);
-  TL_CHECK_LAUNCH();
-  return TL_OK;
-}
-
-int tl_table_tapmask(const int32_t* table, int K, int64_t n_out, uint32_t* tapmask, tl_stream_t stream) {
-  if (!table || !tapmask || K <= 0 || K > 32 || n_out <= 0) return TL_ERR_ARG;
-  k_tapmask<<<(unsigned)tl_cdiv(n_out, kBlock), kBlock, 0, tl_s(stream)>>>(table, K, n_out, tapmask);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

@@ -49,7 +49,6 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.in_ = x.data_ptr(); a.in_ld = x.stride(0)
     a.weight = w_packed.data_ptr()
     a.table = table.data_ptr() if table is not None else None
-    a.tapmask = None
     a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
     a.table_one_hot = int(bool(one_hot))          # inverse conv: one valid entry per output row
     a.table_compact = _hip.ptr(getattr(table, "_tl_compact", None)) if (table is not None and os.environ.get("TL_NO_COMPACT") != "1") else None
@@ -67,7 +66,6 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.out_scale = out_scale.data_ptr() if out_scale is not None else None
     a.out_shift = out_shift.data_ptr() if out_shift is not None else None
     a.out = out.data_ptr(); a.out_ld = out.stride(0)
-    a.stats = None
     # extra views: (tensor [n_out, Cout] (may be a column view), scale or None, shift or None, relu)
     for name, spec in (("out2", out2), ("out3", out3)):
         if spec is None:
