@@ -372,6 +372,31 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
         assert agree / len(ours) >= 0.99, (n, k, agree / len(ours))
 
 
+def test_training_step_mixed_precision(golden_dir):
+    """compute_dtype = bf16 in training = the reference's autocast regime (convs in half precision, BatchNorm / loss fp32,
+    tools/training/train.py:35-40): loss and gradients stay within bf16 distance of the fp32 golden."""
+    from treelearn_amd.model import TreeLearn
+    name = "m3"
+    g = np.load(os.path.join(golden_dir, "g10_forward.npz"))
+    cfg = json.loads(str(g[f"{name}_cfg"]))
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=cfg["spatial_shape"], voxel_size=cfg["voxel_size"],
+                      compute_dtype=torch.bfloat16, **cfg["cfg"])
+    model.load_state_dict(om.random_state_dict(cfg["seed"], **cfg["cfg"]), strict=True)
+    model = model.cuda().train()
+    model.zero_grad()
+    loss, _ = model(_batch_from_golden(g, name), return_loss=True)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g[f"{name}_train_loss"]), rel=3e-2)
+    names = [str(s) for s in g[f"{name}_grad_names"]]
+    params = dict(model.named_parameters())
+    assert all(params[n].grad is not None and params[n].grad.dtype == torch.float32 for n in names)
+    ours = np.array([float(params[n].grad.norm()) for n in names]); ref = g[f"{name}_grad_norms"]
+    big = ref > 1e-3 * ref.max()
+    assert np.abs(ours[big] / ref[big] - 1).max() < 0.15
+    gi = model.input_conv[0].weight.grad.cpu().numpy().ravel(); ri = g[f"{name}_grad_input_conv"].ravel()
+    assert float(gi @ ri / (np.linalg.norm(gi) * np.linalg.norm(ri))) > 0.95      # deepest gradient path, ~50 bf16 layers (measured 0.979)
+
+
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 17001), (64, 32, 27, 16500), (32, 64, 8, 16400), (64, 32, 8, 20000), (64, 96, 8, 16390),
                                                (96, 64, 8, 16385), (64, 32, 1, 20000), (64, 64, 27, 16500), (32, 32, 27, 300), (4, 32, 27, 5000), (128, 64, 27, 16400), (96, 96, 27, 16390),
                                                (128, 128, 27, 16401), (192, 96, 27, 16402), (96, 128, 8, 16403), (256, 128, 27, 16404),

@@ -113,7 +113,12 @@ class TreeLearn(nn.Module):
             # module-by-module path (batch-statistics BatchNorm, autograd through the HIP convs)
             lv = geom.levels[0]
             x = spconv.SparseConvTensor(vfeats, lv.coords, list(lv.shape), batch_size, geometry=geom, level=0)
-            x = self.output_layer(self.unet(self.input_conv(x)))
+            prev = spconv.SparseConvolution.amp_dtype
+            spconv.SparseConvolution.amp_dtype = None if self.compute_dtype == torch.float32 else self.compute_dtype
+            try:                                                       # compute_dtype = bf16: autocast-like mixed precision
+                x = self.output_layer(self.unet(self.input_conv(x)))
+            finally:
+                spconv.SparseConvolution.amp_dtype = prev
             return x, geom.v2p
         if self._plan is None or self._plan.dtype != self.compute_dtype:
             self._plan = InferencePlan(self, self.compute_dtype)

@@ -71,6 +71,11 @@ class SparseSequential(SparseModule):
 
 
 class SparseConvolution(SparseModule):
+    # Mixed-precision training (the reference trains under torch.cuda.amp.autocast, tools/training/train.py:35-40: spconv
+    # convs in half precision with fp32 accumulation, BatchNorm in fp32): when set, features are cast to this dtype for the
+    # conv (forward and dgrad run on the bf16 MFMA kernels) and the result is returned in fp32.  Set by TreeLearn.forward.
+    amp_dtype = None
+
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  indice_key=None, subm=False, inverse=False):
         super().__init__()
@@ -97,7 +102,11 @@ class SparseConvolution(SparseModule):
     def forward(self, x):
         from .autograd import sparse_conv                  # late import (autograd depends on ops)
         ref, out_level = self._table(x)
-        feats = sparse_conv(x.features, self.weight, ref)
+        amp = SparseConvolution.amp_dtype
+        fin = x.features if (amp is None or x.features.dtype == amp) else x.features.to(amp)
+        feats = sparse_conv(fin, self.weight, ref)
+        if amp is not None:
+            feats = feats.float()
         if self.bias is not None:
             feats = feats + self.bias
         lv = x.geometry.levels[out_level]
