@@ -150,10 +150,11 @@ int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_fr
 
 /* Weight gradient (training step; spconv's autograd behind the conv modules, tools/training/train.py:40):
  *   gw[k][co][ci] = sum_o gout[o][co] * x[table[k][o]][ci]   over the present rulebook entries, fp32.
- * x f32[n_in, x_ld >= Cin], gout f32[n_out, g_ld >= Cout], table i32[K][n_out] or NULL (K = 1: identity),
- * gw f32[K][Cout][Cin] out (fully written), ws f32[tl_conv_wgrad_ws_floats(...)] scratch.  Deterministic. */
+ * x [n_in, x_ld >= Cin] and gout [n_out, g_ld >= Cout] in `dtype` (TL_F32, or TL_BF16 = mixed-precision training: widened
+ * to fp32 in registers), table i32[K][n_out] or NULL (K = 1: identity), gw f32[K][Cout][Cin] out (fully written),
+ * ws f32[tl_conv_wgrad_ws_floats(...)] scratch.  Deterministic. */
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout);
-int tl_conv_wgrad(const float* x, int64_t x_ld, const float* gout, int64_t g_ld, const int32_t* table, int64_t n_out,
+int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out,
                   int64_t n_in, int K, int Cin, int Cout, float* gw, float* ws, tl_stream_t stream);
 
 /* ------------------------------------------------------------------ per-point heads

@@ -625,6 +625,12 @@ def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     b = ops.conv_wgrad(wide[:, 8:], torch.from_numpy(g).to(d), tab, n_out, K)
     assert torch.equal(a, b)                                                        # deterministic
     assert rel_err(a.cpu().numpy(), ref) < 2e-5
+    # bf16 inputs (mixed-precision training): widened in registers, same fp32 accumulation -> equals the fp32 kernel fed with
+    # the bf16-rounded values
+    xb = wide[:, 8:].to(torch.bfloat16); gb = torch.from_numpy(g).to(d).to(torch.bfloat16)
+    c = ops.conv_wgrad(xb, gb, tab, n_out, K)
+    e = ops.conv_wgrad(xb.float(), gb.float(), tab, n_out, K)
+    assert torch.equal(c, e)
 
 
 def test_compact_rulebook_equals_table():

@@ -16,8 +16,9 @@ namespace {
 constexpr int kRowsPerWave = 2048;
 constexpr int kWaves = 4;
 
-template <int NBO, int NBI>
-__global__ void __launch_bounds__(kWaves * 64) k_wgrad(const float* __restrict__ x, int64_t x_ld, const float* __restrict__ g, int64_t g_ld,
+// BF16: x and gout are bf16 (mixed-precision training); they are widened to fp32 in registers, the products and sums stay fp32
+template <int NBO, int NBI, bool BF16>
+__global__ void __launch_bounds__(kWaves * 64) k_wgrad(const void* __restrict__ x, int64_t x_ld, const void* __restrict__ g, int64_t g_ld,
                                                        const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
                                                        int nbi_blocks, float* __restrict__ ws) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -28,13 +29,18 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad(const float* __restrict__
   const int64_t part = (int64_t)blockIdx.x * kWaves + wv;
   const int64_t r_begin = part * kRowsPerWave, r_end = min(n_out, r_begin + kRowsPerWave);
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 4), 0x00020000);
+  constexpr int EB = BF16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * EB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * EB), 0x00020000);
+  auto ld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned off) __attribute__((always_inline)) -> float {
+    if constexpr (BF16) return __uint_as_float((uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0) << 16);
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  };
   unsigned offx[NBI], offg[NBO];                 // per-lane channel offsets (bytes), out of range -> 0xFFFFFFFF (reads as 0)
 #pragma unroll
-  for (int b = 0; b < NBI; ++b) offx[b] = (ci0 + b * 32 + fi < Cin) ? (unsigned)((ci0 + b * 32 + fi) * 4) : 0xFFFFFFFFu;
+  for (int b = 0; b < NBI; ++b) offx[b] = (ci0 + b * 32 + fi < Cin) ? (unsigned)((ci0 + b * 32 + fi) * EB) : 0xFFFFFFFFu;
 #pragma unroll
-  for (int b = 0; b < NBO; ++b) offg[b] = (co0 + b * 32 + fi < Cout) ? (unsigned)((co0 + b * 32 + fi) * 4) : 0xFFFFFFFFu;
+  for (int b = 0; b < NBO; ++b) offg[b] = (co0 + b * 32 + fi < Cout) ? (unsigned)((co0 + b * 32 + fi) * EB) : 0xFFFFFFFFu;
 
   f32x16 acc[NBO][NBI];
 #pragma unroll
@@ -61,14 +67,14 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad(const float* __restrict__
         const int i1 = b1 >= 0 ? __builtin_amdgcn_readlane(idx, b1) : -1;
         const int i2 = b2 >= 0 ? __builtin_amdgcn_readlane(idx, b2) : -1;
         const int bsel = fh ? b2 : b1, isel = fh ? i2 : i1;
-        const unsigned gbase = bsel >= 0 ? (unsigned)((r0 + bsel) * g_ld * 4) : 0xFFFFFFFFu;
-        const unsigned xbase = isel >= 0 ? (unsigned)((int64_t)isel * x_ld * 4) : 0xFFFFFFFFu;
+        const unsigned gbase = bsel >= 0 ? (unsigned)((r0 + bsel) * g_ld * EB) : 0xFFFFFFFFu;
+        const unsigned xbase = isel >= 0 ? (unsigned)((int64_t)isel * x_ld * EB) : 0xFFFFFFFFu;
 #pragma unroll
         for (int b = 0; b < NBO; ++b)
-          gv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)((gbase | offg[b]) == 0xFFFFFFFFu ? 0xFFFFFFFFu : gbase + offg[b]), 0, 0));
+          gv[u][b] = ld(rg, (gbase | offg[b]) == 0xFFFFFFFFu ? 0xFFFFFFFFu : gbase + offg[b]);
 #pragma unroll
         for (int b = 0; b < NBI; ++b)
-          xv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)((xbase | offx[b]) == 0xFFFFFFFFu ? 0xFFFFFFFFu : xbase + offx[b]), 0, 0));
+          xv[u][b] = ld(rx, (xbase | offx[b]) == 0xFFFFFFFFu ? 0xFFFFFFFFu : xbase + offx[b]);
       }
 #pragma unroll
       for (int u = 0; u < PF; ++u)
@@ -109,20 +115,25 @@ int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
   return nparts * K * Cout * Cin;
 }
 
-int tl_conv_wgrad(const float* x, int64_t x_ld, const float* gout, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K,
+int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
                   int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
   if (!x || !gout || !gw || !ws || n_out <= 0 || n_in <= 0 || K <= 0 || Cin <= 0 || Cout <= 0 || x_ld < Cin || g_ld < Cout) return TL_ERR_ARG;
   if (!table && K != 1) return TL_ERR_ARG;
-  if (n_in * x_ld * 4 > 0x7FFFFFFFll || n_out * g_ld * 4 > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
+  if (dtype != TL_F32 && dtype != TL_BF16) return TL_ERR_ARG;
+  const int eb = dtype == TL_BF16 ? 2 : 4;
+  if (n_in * x_ld * eb > 0x7FFFFFFFll || n_out * g_ld * eb > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   hipStream_t s = tl_s(stream);
   const int64_t nchunks = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves);
   const bool big_o = Cout > 32, big_i = Cin > 32;
   const int nbo = (int)tl_cdiv(Cout, big_o ? 64 : 32), nbi = (int)tl_cdiv(Cin, big_i ? 64 : 32);
   const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
-  if (big_o && big_i) k_wgrad<2, 2><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
-  else if (big_o) k_wgrad<2, 1><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
-  else if (big_i) k_wgrad<1, 2><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
-  else k_wgrad<1, 1><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+#define TL_W(O_, I_)                                                                                                         \
+  do {                                                                                                                       \
+    if (dtype == TL_BF16) k_wgrad<O_, I_, true><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws); \
+    else k_wgrad<O_, I_, false><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);               \
+  } while (0)
+  if (big_o && big_i) TL_W(2, 2); else if (big_o) TL_W(2, 1); else if (big_i) TL_W(1, 2); else TL_W(1, 1);
+#undef TL_W
   const int64_t per = (int64_t)K * Cout * Cin;
   k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nchunks * kWaves, per, gw);
   TL_CHECK_LAUNCH();

@@ -93,7 +93,10 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
 def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: int) -> torch.Tensor:
     """gW[k][co][ci] = sum_o grad_out[o][co] * x[table[k][o]][ci] (fp32, present entries only) -> [K, Cout, Cin]."""
     L = _hip.lib()
-    x = x.float(); g = grad_out.float()
+    if x.dtype == torch.bfloat16 and grad_out.dtype == torch.bfloat16:
+        g = grad_out                                     # mixed precision: the kernel widens bf16 in registers
+    else:
+        x = x.float(); g = grad_out.float()
     if x.stride(1) != 1: x = x.contiguous()
     if g.stride(1) != 1: g = g.contiguous()
     if not (x.is_cuda and g.is_cuda):
@@ -101,7 +104,7 @@ def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: in
     ci, co = x.shape[1], g.shape[1]
     gw = torch.empty((K, co, ci), dtype=torch.float32, device=x.device)
     ws = torch.empty(int(L.tl_conv_wgrad_ws_floats(n_out, K, ci, co)), dtype=torch.float32, device=x.device)
-    _hip.check(L.tl_conv_wgrad(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), _hip.ptr(table) if table is not None else None, n_out, x.shape[0],
+    _hip.check(L.tl_conv_wgrad(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(table) if table is not None else None, n_out, x.shape[0],
                                K, ci, co, _hip.ptr(gw), _hip.ptr(ws), _hip.stream()), "tl_conv_wgrad")
     return gw
 
