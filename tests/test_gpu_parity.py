@@ -603,7 +603,7 @@ def test_inverse_conv_one_hot_form(cin, cout, n_out):
 
 
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 9000), (64, 32, 27, 5000), (4, 32, 27, 7000), (96, 64, 8, 4100), (160, 192, 8, 700),
-                                               (64, 32, 1, 6000), (224, 224, 27, 223)])
+                                               (64, 32, 1, 6000), (224, 224, 27, 223), (96, 96, 27, 3000), (192, 96, 27, 1500)])
 def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     """tl_conv_wgrad (present pairs only, fp32 MFMA, deterministic) vs gather + matmul in float64."""
     from treelearn_amd import ops

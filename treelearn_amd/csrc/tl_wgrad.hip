@@ -124,15 +124,22 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   if (n_in * x_ld * eb > 0x7FFFFFFFll || n_out * g_ld * eb > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   hipStream_t s = tl_s(stream);
   const int64_t nchunks = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves);
-  const bool big_o = Cout > 32, big_i = Cin > 32;
-  const int nbo = (int)tl_cdiv(Cout, big_o ? 64 : 32), nbi = (int)tl_cdiv(Cin, big_i ? 64 : 32);
+  // [Cout x Cin] is cut into blocks of 32 NBO x 32 NBI; 96 channels take one 3-tile block instead of two 2-tile blocks
+  // (a 2 x 2 tiling of 96 x 96 would spend 16 MFMAs where 9 are needed)
+  auto tiles = [](int c) { return c <= 32 ? 1 : ((c > 64 && c <= 96) ? 3 : 2); };
+  const int to = tiles(Cout), ti = tiles(Cin);
+  const int nbo = (int)tl_cdiv(Cout, 32 * to), nbi = (int)tl_cdiv(Cin, 32 * ti);
   const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
 #define TL_W(O_, I_)                                                                                                         \
   do {                                                                                                                       \
     if (dtype == TL_BF16) k_wgrad<O_, I_, true><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws); \
     else k_wgrad<O_, I_, false><<<grid, kWaves * 64, 0, s>>>(x, x_ld, gout, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);               \
   } while (0)
-  if (big_o && big_i) TL_W(2, 2); else if (big_o) TL_W(2, 1); else if (big_i) TL_W(1, 2); else TL_W(1, 1);
+  switch (to * 10 + ti) {
+    case 11: TL_W(1, 1); break; case 12: TL_W(1, 2); break; case 13: TL_W(1, 3); break;
+    case 21: TL_W(2, 1); break; case 22: TL_W(2, 2); break; case 23: TL_W(2, 3); break;
+    case 31: TL_W(3, 1); break; case 32: TL_W(3, 2); break; case 33: TL_W(3, 3); break;
+  }
 #undef TL_W
   const int64_t per = (int64_t)K * Cout * Cin;
   k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nchunks * kWaves, per, gw);
