@@ -82,6 +82,33 @@ def cpu_baseline(timeout_s=240):
         return dict(value=None, unit="Mpoints/s", cores=host_cores(), kind="port", sample=f"failed: {type(e).__name__}")
 
 
+def power_probe(step_fn, seconds=2.5):
+    """Board power and shader clock while the forward loops (rocm-smi sampled from a thread; not part of the timed region).
+    The mid-level conv kernels run at the 1400 W cap, so the clock is part of the story."""
+    import re, subprocess, threading
+    out = {}
+
+    def sample():
+        time.sleep(seconds * 0.55)
+        try:
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"sclk clock level[^(]*\((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if m: out["sclk_mhz"] = int(m.group(1))
+            if w: out["board_w"] = float(w.group(1))
+        except Exception:                                    # noqa: BLE001
+            pass
+
+    th = threading.Thread(target=sample); th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            step_fn()
+        torch.cuda.synchronize()
+    th.join()
+    return out or None
+
+
 def pmc_traffic(dtype, workload):
     """HBM bytes per step of the conv launches from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, KB units, gfx950 half-count correction) -- collected offline, not in this run."""
@@ -229,6 +256,10 @@ def main():
                 torch.cuda.synchronize(); d32 = (time.perf_counter() - t1) / 5
             res["fp32_parity_mode"] = dict(value=n_pts / d32 / 1e6, unit="Mpoints/s", ms_per_step=d32 * 1e3)
             del m32
+        if world == 1:
+            pw = power_probe(step)
+            if pw:
+                res["power"] = dict(pw, note="rocm-smi sample while the same forward loops for 2.5 s (untimed)")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
