@@ -224,6 +224,9 @@ def test_tile_loop_golden_g9(golden_dir):
     res = get_pointwise_preds(Fake(), tiles, dict(voxel_size=0.2))
     for i, r in enumerate(res):
         np.testing.assert_allclose(r, g[f"out{i}"], rtol=1e-6, atol=1e-6)
+    dres = get_pointwise_preds(Fake(), tiles, dict(voxel_size=0.2), keep_on_device=True)          # same results, left on the GPU
+    for r, d in zip(res, dres):
+        assert d.is_cuda and np.array_equal(d.cpu().numpy(), r)
 
 
 def _bf16_round(a):

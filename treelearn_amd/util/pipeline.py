@@ -25,7 +25,8 @@ def _to_device_async(batch, stream):
     return out, ev
 
 
-def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True, return_tile_rows=False):
+def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True, return_tile_rows=False,
+                        keep_on_device=False):
     """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one packed D2H copy instead of the
     reference's full-tile `.cpu()` copies), `coords += centers`, and skip tiles whose forward raises
     "... reach zero!!! ..." (pipeline.py:91-97).
@@ -34,12 +35,16 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     second stream (which waits only for the event recorded after forward i), so the synchronising read-back, the host-side
     bookkeeping and the launch overhead of the next tile hide behind GPU work.  The next tile's H2D copy runs on a third
     (copy) stream.  Building the next tile's geometry concurrently on a side stream was measured slower (the convs already
-    fill the GPU and the geometry's host syncs stall the launch thread) and is not done."""
+    fill the GPU and the geometry's host syncs stall the launch thread) and is not done.
+
+    keep_on_device=True returns the 8 results as device tensors instead of numpy arrays (no D2H at all), for a consumer that
+    continues on the GPU -- `postprocess.ensemble` accepts them."""
     outs = [[] for _ in range(8)]
     tile_rows = []                                                     # (position in the iterable, inner rows) of every tile that produced output
     use_gpu = torch.cuda.is_available()
     copy_stream = torch.cuda.Stream() if use_gpu else None
     rb_stream = torch.cuda.Stream() if use_gpu else None
+    main_stream = torch.cuda.current_stream() if use_gpu else None
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
 
     def read_back(pos, batch, gbatch, output, done):
@@ -79,13 +84,19 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             if src.is_cuda:
                 on_dev[k] = len(cols); cols.append(rows(src).float().reshape(idx.shape[0], -1))
         widths = [c.shape[1] for c in cols]
-        parts = list(torch.split(torch.cat(cols, 1).cpu(), widths, dim=1))
+        packed = torch.cat(cols, 1)
+        if keep_on_device and packed.is_cuda:
+            packed.record_stream(main_stream)                          # produced on the read-back stream, consumed on the main one
+        parts = list(torch.split(packed if keep_on_device else packed.cpu(), widths, dim=1))
         get = lambda k: parts[on_dev[k]] if k in on_dev else rows(batch[k])                  # noqa: E731
-        lab = lambda k: rows(batch[k]).cpu() if batch[k].is_cuda else rows(batch[k])         # noqa: E731
+        home = (lambda t: t.to(dev)) if keep_on_device else (lambda t: t.cpu() if t.is_cuda else t)   # noqa: E731
+        get0 = get
+        get = lambda k: home(get0(k))                                                        # noqa: E731
+        lab = lambda k: home(rows(batch[k]))                                                 # noqa: E731
         outs[0].append(parts[0]); outs[1].append(lab('semantic_labels'))
         outs[2].append(parts[1]); outs[3].append(get('offset_labels'))
         outs[4].append(get('coords') + get('centers')); outs[5].append(lab('instance_labels'))
-        outs[6].append(parts[2] if bb is not None else torch.zeros((idx.shape[0], 0))); outs[7].append(get('input_feats'))
+        outs[6].append(parts[2] if bb is not None else torch.zeros((idx.shape[0], 0), device=parts[0].device)); outs[7].append(get('input_feats'))
 
     with torch.no_grad():
         model.eval()
@@ -124,6 +135,10 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             read_back(*pending)
     if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
         res = tuple(np.zeros((0,), np.float32) for _ in outs)
+    elif keep_on_device:
+        if use_gpu:
+            main_stream.wait_stream(rb_stream)
+        res = tuple(torch.cat(o, 0) for o in outs)
     else:
         res = tuple(torch.cat(o, 0).numpy() for o in outs)
     return (res, tile_rows) if return_tile_rows else res

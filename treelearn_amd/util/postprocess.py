@@ -16,7 +16,7 @@ def ensemble(coords, semantic_scores, semantic_labels, offset_predictions, offse
     columns are averaged as floats then truncated, like the reference (:130,135,138).
     """
     L = _hip.lib()
-    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)                       # noqa: E731
+    T = lambda a: a.to(device) if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a)).to(device)   # noqa: E731
     c = T(coords).float()
     q = torch.round(c * 100.0)                                    # float32 multiply + rint == np.round(., 2) numerator
     qi = q.to(torch.int64)
@@ -40,7 +40,7 @@ def ensemble(coords, semantic_scores, semantic_labels, offset_predictions, offse
     out_coords = (q[first] / 100.0).float()                       # the rounded coordinates themselves
     f32 = lambda t: t.float().cpu().numpy()                                                  # noqa: E731
     i64 = lambda t: t[:, 0].cpu().numpy().astype('int64').flatten()                          # noqa: E731
-    one = lambda t, a: t[:, 0] if np.ndim(a) == 1 else t                                     # noqa: E731
+    one = lambda t, a: t[:, 0] if a.ndim == 1 else t                                         # noqa: E731
     return (out_coords.cpu().numpy(),
             f32(one(parts[0], semantic_scores)), i64(parts[1]), f32(one(parts[2], offset_predictions)), f32(one(parts[3], offset_labels)),
             i64(parts[4]), f32(one(parts[5], feats)), f32(one(parts[6], input_feats)))
