@@ -114,6 +114,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             try:
                 if ev is not None:
                     torch.cuda.current_stream().wait_event(ev)
+                if gbatch.get('_ready_event') is not None:              # device-resident tile produced on another stream (PlotTiler)
+                    torch.cuda.current_stream().wait_event(gbatch['_ready_event'])
                 output = model(gbatch, return_loss=False)
             except Exception as e:                                     # noqa: BLE001
                 if "reach zero!!!" not in str(e):

@@ -84,6 +84,7 @@ class PlotTiler:
         L = _hip.lib()
         self._ws = torch.empty(int(L.tl_tile_crop_ws_words(n)), dtype=torch.int32, device=dev)
         self._count = torch.empty(2, dtype=torch.int32, device=dev)
+        self._stream = torch.cuda.Stream(device=dev)        # crops run beside the consumer's forward passes, not behind them
         self._buf = dict(coords=torch.empty((n, 3), dtype=torch.float32, device=dev), feats=torch.empty((n, max(F, 1)), dtype=torch.float32, device=dev),
                          inst=torch.empty(n, dtype=torch.int64, device=dev), sem=torch.empty(n, dtype=torch.int64, device=dev),
                          m_inner=torch.empty(n, dtype=torch.uint8, device=dev), m_sem=torch.empty(n, dtype=torch.uint8, device=dev))
@@ -110,20 +111,31 @@ class PlotTiler:
         assert offset_labels in ("host", "none")
         inner, outer = tile_grid(self.x_range, self.y_range, inner_edge, outer_edge, stride)
         F = self.feats.shape[1]
+        main = torch.cuda.current_stream()
+        self._stream.wait_stream(main)                         # the plot arrays may have just been produced on the caller's stream
         for t in range(len(inner)):
-            kept, n_inner, center = self.crop(inner[t], outer[t], inner_square_edge_length)
-            if n_inner == 0:                                   # data_preparation.py:412-427: tiles whose inner square is empty are dropped
-                continue
-            b = self._buf
-            coords = b["coords"][:kept].clone(); inst = b["inst"][:kept].clone(); sem = b["sem"][:kept].clone()
-            m_inner = b["m_inner"][:kept].bool(); m_sem = b["m_sem"][:kept].bool()
-            if offset_labels == "host":
-                off, valid = _offset_labels_host(coords.cpu().numpy(), inst.cpu().numpy(), sem.cpu().numpy())
-                off_t = torch.from_numpy(off.astype(np.float32)).to(coords.device)
-                m_off = m_sem & (sem != NON_TREE_CLASS) & torch.from_numpy(valid).to(coords.device)
-            else:
-                off_t = torch.zeros_like(coords); m_off = torch.zeros_like(m_sem)
-            c32 = torch.from_numpy(center.astype(np.float32)).to(coords.device)
-            yield dict(coords=coords, input_feats=b["feats"][:kept, :F].clone(), batch_ids=torch.zeros(kept, dtype=torch.int64, device=coords.device),
-                       semantic_labels=sem, instance_labels=inst, masks_inner=m_inner, masks_off=m_off, masks_sem=m_sem,
-                       offset_labels=off_t, batch_size=1, centers=c32.expand(kept, 3).contiguous(), tile_index=t)
+            # The crop (and its one host sync for the row count) goes on the tiler's own stream: a consumer that pulls the next
+            # tile before launching the current forward (util/pipeline.get_pointwise_preds) then never waits for its own convs.
+            with torch.cuda.stream(self._stream):
+                kept, n_inner, center = self.crop(inner[t], outer[t], inner_square_edge_length)
+                if n_inner == 0:                               # data_preparation.py:412-427: tiles whose inner square is empty are dropped
+                    continue
+                b = self._buf
+                coords = b["coords"][:kept].clone(); inst = b["inst"][:kept].clone(); sem = b["sem"][:kept].clone()
+                m_inner = b["m_inner"][:kept].bool(); m_sem = b["m_sem"][:kept].bool()
+                if offset_labels == "host":
+                    off, valid = _offset_labels_host(coords.cpu().numpy(), inst.cpu().numpy(), sem.cpu().numpy())
+                    off_t = torch.from_numpy(off.astype(np.float32)).to(coords.device)
+                    m_off = m_sem & (sem != NON_TREE_CLASS) & torch.from_numpy(valid).to(coords.device)
+                else:
+                    off_t = torch.zeros_like(coords); m_off = torch.zeros_like(m_sem)
+                c32 = torch.from_numpy(center.astype(np.float32)).to(coords.device)
+                batch = dict(coords=coords, input_feats=b["feats"][:kept, :F].clone(), batch_ids=torch.zeros(kept, dtype=torch.int64, device=coords.device),
+                             semantic_labels=sem, instance_labels=inst, masks_inner=m_inner, masks_off=m_off, masks_sem=m_sem,
+                             offset_labels=off_t, batch_size=1, centers=c32.expand(kept, 3).contiguous(), tile_index=t)
+                ready = torch.cuda.Event(); ready.record(self._stream)
+            for v in batch.values():
+                if torch.is_tensor(v):
+                    v.record_stream(main)                      # allocated on the tiler's stream, consumed on the caller's
+            batch["_ready_event"] = ready                      # consumers on another stream wait for this before reading the tile
+            yield batch
