@@ -710,3 +710,35 @@ def test_kernel_families_agree_on_a_real_tile():
         assert rel_err(ref[k], e32) < 6e-2, k
         for i, v in enumerate(variants):
             assert rel_err(v[k], e32) < 6e-2, (i, k)
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_forward_fuzz_small_tiles_vs_oracle(seed):
+    """Ragged inputs: random small tiles (odd point counts, thin slabs, a batch of two very unequal elements, voxel sizes 0.1-0.3)
+    through the default model in fp32 against the oracle; a tile that collapses must raise the same "reach zero!!!" error in both."""
+    from treelearn_amd.model import TreeLearn
+    rng = np.random.default_rng(seed)
+    voxel = float(rng.choice([0.1, 0.2, 0.3]))
+    tiles = []
+    for _ in range(int(rng.integers(1, 3))):
+        t = make_tile(extent=float(rng.uniform(4, 9)), voxel=voxel, n_trees=int(rng.integers(1, 4)), fill=0.1, seed=int(rng.integers(1 << 30)))
+        keep = rng.uniform(size=len(t["points"])) < rng.uniform(0.2, 1.0)
+        keep[: 5] = True
+        tiles.append({k: (v[keep] if k != "center" else v) for k, v in t.items()})
+    batch = make_batch(tiles)
+    sd = om.random_state_dict(seed, channels=32, num_blocks=7)
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=voxel)
+    model.load_state_dict(sd, strict=True); model = model.cuda().eval()
+    args = (sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), len(tiles))
+    try:
+        ref = om.forward(*args, voxel_size=voxel, num_blocks=7, spatial_shape=[500, 500, 1000])
+    except ValueError as e:
+        assert "reach zero!!!" in str(e)
+        with pytest.raises(ValueError, match="reach zero!!!"), torch.no_grad():
+            model(batch, return_loss=False)
+        return
+    with torch.no_grad():
+        out = model(batch, return_loss=False)
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert np.isfinite(out[k].cpu().numpy()).all()
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, (k, len(batch["coords"]))
