@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad(const void* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  constexpr int PF = 4;                          // (row, row) pairs whose loads are in flight together
+  constexpr int PF = 8;                          // (row, row) pairs whose loads are in flight together
   for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
     const int64_t row = r0 + lane;
     int idx = -1;
