@@ -35,8 +35,8 @@ def tiles():
     for b in tiler.tiles(inner, outer, stride, inner, offset_labels="none"):
         ntiles[0] += 1; yield b
 res = get_pointwise_preds(model, tiles(), dict(voxel_size=0.1), keep_on_device=True); t0 = lap("tiling + tile loop", t0)
-ens = ensemble(res[4], res[0], res[1], res[2], res[3], res[5], res[6], res[7]); t0 = lap("ensemble", t0)
-coords, sem, _, off, _, _, _, infeat = ens
+ens = ensemble(res[4], res[0], res[1], res[2], res[3], res[5], res[6], res[7], return_device=True); t0 = lap("ensemble", t0)
+coords, sem, off, infeat = (ens[i].cpu().numpy() for i in (0, 1, 3, 7)); t0 = lap("D2H of what grouping reads", t0)
 cfg = dict(tree_conf_thresh=0.5, tau_vert=0.0, tau_off=1e9, tau_group=0.3, tau_min=20, use_hdbscan=False)
 inst = get_instances(coords, off, sem, cfg, infeat[:, -1], 0, 0, -1, 1); t0 = lap("grouping (DBSCAN)", t0)
 tree = inst != 0

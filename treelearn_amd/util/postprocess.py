@@ -7,7 +7,7 @@ from .. import _hip
 
 
 def ensemble(coords, semantic_scores, semantic_labels, offset_predictions, offset_labels, instance_labels, feats, input_feats,
-             device="cuda"):
+             device="cuda", return_device=False):
     """Mean of duplicate predictions keyed by coords rounded to 0.01 m, output sorted by (x, y, z).
 
     Reference: pandas `df.round({'x':2,'y':2,'z':2}).groupby(['x','y','z']).mean()`.  Here: the float32 rounding
@@ -38,10 +38,14 @@ def ensemble(coords, semantic_scores, semantic_labels, offset_predictions, offse
     mean = mean[:M]; first = first[:M]
     parts = torch.split(mean, widths, dim=1)
     out_coords = (q[first] / 100.0).float()                       # the rounded coordinates themselves
-    f32 = lambda t: t.float().cpu().numpy()                                                  # noqa: E731
-    i64 = lambda t: t[:, 0].cpu().numpy().astype('int64').flatten()                          # noqa: E731
+    if return_device:            # same eight results as device tensors (the 32 backbone columns are the bulk of the D2H otherwise)
+        f32 = lambda t: t.float()                                                            # noqa: E731
+        i64 = lambda t: t[:, 0].to(torch.int64)                                              # noqa: E731
+    else:
+        f32 = lambda t: t.float().cpu().numpy()                                              # noqa: E731
+        i64 = lambda t: t[:, 0].cpu().numpy().astype('int64').flatten()                      # noqa: E731
     one = lambda t, a: t[:, 0] if a.ndim == 1 else t                                         # noqa: E731
-    return (out_coords.cpu().numpy(),
+    return (out_coords if return_device else out_coords.cpu().numpy(),
             f32(one(parts[0], semantic_scores)), i64(parts[1]), f32(one(parts[2], offset_predictions)), f32(one(parts[3], offset_labels)),
             i64(parts[4]), f32(one(parts[5], feats)), f32(one(parts[6], input_feats)))
 
