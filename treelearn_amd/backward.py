@@ -7,7 +7,8 @@ gather-GEMM over the TRANSPOSED table with transposed weights --
     inverse   : gin[q] = sum_k W[k]^T gout[child[k][q]]
     1x1       : gin    = gout . W
 all through `tl_conv_fwd`.  wgrad (gW[k] = sum_o gout[o] (x) x[table[k][o]]) is `tl_conv_wgrad` (csrc/tl_wgrad.hip): fp32
-32x32x2 MFMAs over the present (output row, input row) pairs only, two pairs per instruction, no materialised gather.
+32x32x2 MFMAs over the present (output row, input row) pairs only, two pairs per instruction, no materialised gather; with bf16
+inputs (mixed-precision training) the bf16 32x32x16 MFMA takes 16 pairs per instruction from LDS-staged rows.
 """
 import torch
 

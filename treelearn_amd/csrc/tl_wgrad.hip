@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int kRowsPerWave = 2048;
+constexpr int kRowsPerWave = 4096;
 constexpr int kWaves = 4;
 
 // BF16: x and gout are bf16 (mixed-precision training); they are widened to fp32 in registers, the products and sums stay fp32
@@ -98,6 +98,106 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad(const void* __restrict__ 
       }
 }
 
+// bf16 inputs on the bf16 matrix cores (mixed-precision training): 16 (output row, input row) pairs per 32x32x16 MFMA instead of
+// two per fp32 MFMA.  The contraction index is the PAIR, so lane (m, h) needs 8 different rows at one column -- not something a
+// row-major gather delivers.  Hence: the wave compacts the present pairs of a 64-row group into a wave-private LDS list
+// (rank = popcount of the lower lanes' ballot bits), fetches 16 pair rows of gout and of x at a time with full-row 16-B loads
+// (NB*4 lanes per row), parks them row-major in LDS and reads the operand columns back as 2-byte elements (32 consecutive
+// channels of one row per half-wave: conflict-free).  Accumulation stays fp32; partial tiles and the ordered reduction are those
+// of the fp32 kernel.  NBO, NBI in {1, 2}; channel counts must be multiples of 8 (16-B pieces).
+template <int NBO, int NBI>
+__global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
+                                                            const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
+                                                            int nbi_blocks, float* __restrict__ ws) {
+  constexpr int GP = NBO * 32 + 8, XP = NBI * 32 + 8;        // LDS row pitch in elements (+16 B: the 16-B row writes of 8 rows per instruction spread over the banks)
+  __shared__ __attribute__((aligned(16))) uint16_t Gs[kWaves][16][GP];
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kWaves][16][XP];
+  __shared__ int2 Ls[kWaves][64];                             // compacted (row, input row) pairs of the current 64-row group
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int k = blockIdx.y;
+  const int bo = blockIdx.z / nbi_blocks, bi = blockIdx.z % nbi_blocks;
+  const int co0 = bo * (NBO * 32), ci0 = bi * (NBI * 32);
+  const int64_t part = (int64_t)blockIdx.x * kWaves + wv;
+  const int64_t r_begin = part * kRowsPerWave, r_end = min(n_out, r_begin + kRowsPerWave);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 2), 0x00020000);
+  // staging pattern: LG (LX) lanes cover one row of the gout (x) block with 16-B pieces
+  constexpr int LG = NBO * 4, LX = NBI * 4, RG = 64 / LG, RX = 64 / LX;       // lanes per row, rows per load instruction
+  const int g_piece = lane % LG, g_row = lane / LG, x_piece = lane % LX, x_row = lane / LX;
+  const unsigned g_coff = (co0 + g_piece * 8 < Cout) ? (unsigned)((co0 + g_piece * 8) * 2) : 0xFFFFFFFFu;
+  const unsigned x_coff = (ci0 + x_piece * 8 < Cin) ? (unsigned)((ci0 + x_piece * 8) * 2) : 0xFFFFFFFFu;
+
+  f32x16 acc[NBO][NBI];
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
+    const int64_t row = r0 + lane;
+    int idx = -1;
+    if (row < r_end) idx = table ? table[(int64_t)k * n_out + row] : (int)row;
+    const unsigned long long m = __ballot(idx >= 0);
+    const int cnt = __builtin_popcountll(m);
+    if (cnt == 0) continue;
+    if (idx >= 0) Ls[wv][__builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2((int)(row - r_begin), idx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int p0 = 0; p0 < cnt; p0 += 16) {
+      // 16 pair rows of gout and x -> LDS (absent pairs and channels past the end read as zeros)
+#pragma unroll
+      for (int i = 0; i < 16 / RG; ++i) {
+        const int pl = g_row + i * RG, p = p0 + pl;
+        const int2 e = Ls[wv][p < cnt ? p : 0];
+        const unsigned base = (p < cnt && g_coff != 0xFFFFFFFFu) ? (unsigned)((r_begin + e.x) * g_ld * 2) + g_coff : 0xFFFFFFFFu;
+        *reinterpret_cast<u32x4*>(&Gs[wv][pl][g_piece * 8]) = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)base, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 16 / RX; ++i) {
+        const int pl = x_row + i * RX, p = p0 + pl;
+        const int2 e = Ls[wv][p < cnt ? p : 0];
+        const unsigned base = (p < cnt && x_coff != 0xFFFFFFFFu) ? (unsigned)((int64_t)e.y * x_ld * 2) + x_coff : 0xFFFFFFFFu;
+        *reinterpret_cast<u32x4*>(&Xs[wv][pl][x_piece * 8]) = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)base, 0, 0));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // operand columns: lane (m = fi, h = fh) takes pairs 8h .. 8h+7 of channel m of its block
+      u32x4 A[NBO], B[NBI];
+#pragma unroll
+      for (int a = 0; a < NBO; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          A[a][t] = (uint32_t)Gs[wv][8 * fh + 2 * t][a * 32 + fi] | ((uint32_t)Gs[wv][8 * fh + 2 * t + 1][a * 32 + fi] << 16);
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          B[b][t] = (uint32_t)Xs[wv][8 * fh + 2 * t][b * 32 + fi] | ((uint32_t)Xs[wv][8 * fh + 2 * t + 1][b * 32 + fi] << 16);
+#pragma unroll
+      for (int a = 0; a < NBO; ++a)
+#pragma unroll
+        for (int b = 0; b < NBI; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  float* wp = ws + ((part * K + k) * (int64_t)Cout) * Cin;
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ci = ci0 + b * 32 + fi;
+        if (co < Cout && ci < Cin) wp[(int64_t)co * Cin + ci] = acc[a][b][r];
+      }
+}
+
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t nparts, int64_t per, float* __restrict__ gw) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -108,7 +208,11 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t nparts, int
 
 }  // namespace
 
+static int g_wgrad_bf16_mfma = 1;          // developer A/B (tl_dev_wgrad_mode): 0 = bf16 inputs through the fp32-MFMA kernel
+
 extern "C" {
+
+int tl_dev_wgrad_mode(int bf16_mfma) { g_wgrad_bf16_mfma = bf16_mfma; return TL_OK; }
 
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
   const int64_t nparts = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves) * kWaves;
@@ -124,6 +228,18 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   if (n_in * x_ld * eb > 0x7FFFFFFFll || n_out * g_ld * eb > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   hipStream_t s = tl_s(stream);
   const int64_t nchunks = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves);
+  if (dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)gout) % 16 == 0 &&
+      g_wgrad_bf16_mfma) {
+    // bf16 matrix cores: blocks of at most 64 x 64 channels (partially filled blocks are masked)
+    const int to = Cout > 32 ? 2 : 1, ti = Cin > 32 ? 2 : 1;
+    const int nbo = (int)tl_cdiv(Cout, 32 * to), nbi = (int)tl_cdiv(Cin, 32 * ti);
+    const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
+    const uint16_t* xb = (const uint16_t*)x; const uint16_t* gb = (const uint16_t*)gout;
+    if (to == 2 && ti == 2) k_wgrad_bf16<2, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+    else if (to == 2) k_wgrad_bf16<2, 1><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+    else if (ti == 2) k_wgrad_bf16<1, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+    else k_wgrad_bf16<1, 1><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+  } else {
   // [Cout x Cin] is cut into blocks of 32 NBO x 32 NBI; 96 channels take one 3-tile block instead of two 2-tile blocks
   // (a 2 x 2 tiling of 96 x 96 would spend 16 MFMAs where 9 are needed)
   auto tiles = [](int c) { return c <= 32 ? 1 : ((c > 64 && c <= 96) ? 3 : 2); };
@@ -141,6 +257,7 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
     case 31: TL_W(3, 1); break; case 32: TL_W(3, 2); break; case 33: TL_W(3, 3); break;
   }
 #undef TL_W
+  }
   const int64_t per = (int64_t)K * Cout * Cin;
   k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nchunks * kWaves, per, gw);
   TL_CHECK_LAUNCH();
