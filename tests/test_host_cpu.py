@@ -156,3 +156,21 @@ def test_tile_grid_and_offset_labels_host_logic(golden_dir):
         assert np.array_equal(off.astype(np.float32), g[f"tile{i}_offset_labels"])
         m_off = g[f"tile{i}_masks_sem"] & (g[f"tile{i}_semantic_labels"] != 1) & valid
         assert np.array_equal(m_off, g[f"tile{i}_masks_off"])
+
+
+def test_column_form_rulebook_property_on_oracle_tables():
+    """The column form used by tl_rulebook_compact relies on one property of the canonical voxel order: the present dz
+    neighbours of a (dx, dy) column are CONSECUTIVE rows.  Checked on the oracle's rulebook of a ragged two-element batch."""
+    from oracle import voxel as ov
+    from treelearn_amd.synth import make_tile
+    tiles = [make_tile(extent=5.0, voxel=0.2, n_trees=2, fill=0.1, seed=s) for s in (3, 4)]
+    pts = np.concatenate([t["points"] for t in tiles]); bid = np.concatenate([np.full(len(t["points"]), i) for i, t in enumerate(tiles)])
+    vc = np.asarray(ov.voxelize(torch.from_numpy(pts), torch.zeros(len(pts), 1), torch.from_numpy(bid), 2, 0.2)[1]).astype(np.int64)
+    nbr = np.asarray(ov.rulebook_subm(vc))
+    nbr = nbr.T if nbr.shape[0] == 27 else nbr                      # [N, 27]
+    for c in range(9):
+        col = nbr[:, 3 * c:3 * c + 3].astype(np.int64)
+        present = col >= 0
+        base = np.where(present.any(1), np.where(present, col, np.iinfo(np.int64).max).min(1), -1)
+        rank = np.cumsum(present, 1) - present                      # present neighbours below this dz
+        np.testing.assert_array_equal(np.where(present, base[:, None] + rank, -1), col)
