@@ -91,7 +91,8 @@ int tl_voxel_mean_feats(const float* pf, int C, const int64_t* v2p, int64_t N, i
 
 /* nbr i32[27][M]: tap = (dx+1)*9 + (dy+1)*3 + (dz+1), entry = input row or -1; nbr[13][i] == i. */
 int tl_rulebook_subm(const int32_t* coords, int64_t M, const uint64_t* bitmap, const uint32_t* prefix,
-                     const int32_t dims[4], int32_t* nbr, tl_stream_t stream);
+                     const int32_t dims[4], int32_t* nbr, int32_t* compact /* optional i32[10][M] column form, see tl_rulebook_compact */,
+                     tl_stream_t stream);
 
 /* child i32[8][Mc] (tap = (x&1)*4+(y&1)*2+(z&1)), parent i32[Mf] (-1 = dropped), inv i32[8][Mf]
  * (inv[tap(p)][p] = parent[p], other taps -1: the inverse conv's table).  parent and inv are filled here. */

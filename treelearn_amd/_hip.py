@@ -49,7 +49,7 @@ PROTOTYPES = {
     "tl_expand_coords": (_i32, [_vp, _vp, _I4, _vp, _vp]),
     "tl_point_rank": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
     "tl_voxel_mean_feats": (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
-    "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
+    "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp, _vp]),
     "tl_rulebook_down": (_i32, [_vp, _i64, _vp, _vp, _I4, _i64, _vp, _vp, _vp, _vp]),
     "tl_rulebook_compact": (_i32, [_vp, _i64, _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),

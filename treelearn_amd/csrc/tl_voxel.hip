@@ -272,9 +272,11 @@ __global__ void __launch_bounds__(kBlock) k_point_rank(const int32_t* __restrict
 
 // ---------------------------------------------------------------- rulebooks
 __global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restrict__ coords, int64_t M, const uint64_t* __restrict__ bm,
-                                                          const uint32_t* __restrict__ pf, TlDims d, int32_t* __restrict__ nbr) {
+                                                          const uint32_t* __restrict__ pf, TlDims d, int32_t* __restrict__ nbr,
+                                                          int32_t* __restrict__ compact) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    uint32_t cmask = 0;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll
@@ -300,8 +302,13 @@ __global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restr
         nbr[(int64_t)(tap0 + 0) * M + i] = r0;
         nbr[(int64_t)(tap0 + 1) * M + i] = r1;
         nbr[(int64_t)(tap0 + 2) * M + i] = r2;
+        if (compact) {                                       // column form (see k_table_compact): first present dz neighbour + presence bits
+          compact[(int64_t)(tap0 / 3) * M + i] = r0 >= 0 ? r0 : (r1 >= 0 ? r1 : r2);
+          cmask |= ((r0 >= 0 ? 1u : 0u) | (r1 >= 0 ? 2u : 0u) | (r2 >= 0 ? 4u : 0u)) << tap0;
+        }
       }
     }
+    if (compact) compact[(int64_t)9 * M + i] = (int32_t)cmask;
   }
 }
 
@@ -446,9 +453,9 @@ int tl_voxel_mean_feats(const float* pf, int C, const int64_t* v2p, int64_t N, i
 }
 
 int tl_rulebook_subm(const int32_t* coords, int64_t M, const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4],
-                     int32_t* nbr, tl_stream_t stream) {
+                     int32_t* nbr, int32_t* compact, tl_stream_t stream) {
   if (!coords || !bitmap || !prefix || !dims || !nbr || M <= 0) return TL_ERR_ARG;
-  k_rulebook_subm<<<tl_grid(M, kBlock), kBlock, 0, tl_s(stream)>>>(coords, M, bitmap, prefix, tl_dims(dims), nbr);
+  k_rulebook_subm<<<tl_grid(M, kBlock), kBlock, 0, tl_s(stream)>>>(coords, M, bitmap, prefix, tl_dims(dims), nbr, compact);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

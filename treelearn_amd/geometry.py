@@ -122,12 +122,12 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         lv.coords = torch.empty((lv.n, 4), dtype=torch.int32, device=dev)
         _hip.check(L.tl_expand_coords(_hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims), _hip.ptr(lv.coords), st), "tl_expand_coords")
         lv.nbr = torch.empty((27, lv.n), dtype=torch.int32, device=dev)
+        # level 1 also gets the column form of its rulebook (40 instead of 108 B/voxel) for the kernels that read it; it rides on
+        # the table tensor as an attribute
+        ct = torch.empty((10, lv.n), dtype=torch.int32, device=dev) if (li == 0 and lv.n >= 65536) else None
         _hip.check(L.tl_rulebook_subm(_hip.ptr(lv.coords), lv.n, _hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims),
-                                      _hip.ptr(lv.nbr), st), "tl_rulebook_subm")
-        if li == 0 and lv.n >= 65536:
-            # column form of the level-1 rulebook (40 instead of 108 B/voxel) for the kernels that read it; rides on the table
-            ct = torch.empty((10, lv.n), dtype=torch.int32, device=dev)
-            _hip.check(L.tl_rulebook_compact(_hip.ptr(lv.nbr), lv.n, _hip.ptr(ct), st), "tl_rulebook_compact")
+                                      _hip.ptr(lv.nbr), _hip.ptr(ct), st), "tl_rulebook_subm")
+        if ct is not None:
             lv.nbr._tl_compact = ct
     for li in range(num_levels - 1):
         f, c = levels[li], levels[li + 1]
