@@ -99,6 +99,41 @@ int tl_rulebook_subm(const int32_t* coords, int64_t M, const uint64_t* bitmap, c
 int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap, const uint32_t* fprefix,
                      const int32_t fdims[4], int64_t Mf, int32_t* child, int32_t* parent, int32_t* inv, tl_stream_t stream);
 
+/* ---- the whole pyramid in two calls (what treelearn_amd.geometry uses; same kernels and results as the per-level calls
+ * above, enqueued back to back, the deep levels -- a few thousand words each -- batched into shared launches).
+ *
+ * tl_pyramid_ws_words: scan scratch (u32 words) for a pyramid whose level 1 has dims0 = {B,X,Y,Z}; level l+1 has
+ *   ceil(dims_l / 2).  level_word_offsets (optional, i64[num_levels+1]) receives the word offset of every level inside the
+ *   `bitmaps` / `prefixes` arrays (the last entry = total words).
+ * tl_pyramid_build: occupancy bitmap of level 1 from pcoords, then per level the k2s2 down-sampling (cells at or beyond
+ *   shape_l = shape0 >> l dropped, spconv's floor((n-2)/2)+1 output shape; tree_learn.py:86-87, blocks.py:104-108) and the
+ *   popcount scan; counts u32[num_levels] (device) = active voxels per level. */
+int64_t tl_pyramid_ws_words(const int32_t dims0[4], int num_levels, int64_t* level_word_offsets);
+int tl_pyramid_build(const int32_t* pcoords, int64_t N, const int32_t dims0[4], const int32_t shape0[3], int num_levels,
+                     uint64_t* bitmaps, uint32_t* prefixes, uint32_t* counts, uint32_t* ws, tl_stream_t stream);
+
+/* One level of the pyramid for tl_rulebooks_build: inputs dims/n/bitmap/prefix, outputs as in tl_expand_coords,
+ * tl_rulebook_subm (nbr, optional compact) and tl_rulebook_down (child/parent/inv: the tables between this level and the
+ * next coarser one; unused on the last level). */
+typedef struct tl_level {
+  int32_t dims[4];
+  int64_t n;
+  const uint64_t* bitmap;
+  const uint32_t* prefix;
+  int32_t* coords;
+  int32_t* nbr;
+  int32_t* compact;
+  int32_t* child;
+  int32_t* parent;
+  int32_t* inv;
+} tl_level;
+
+/* coords + every rulebook of every level + (v2p != NULL) the point -> voxel map, in one call.  parent / inv arrays that lie
+ * inside [minus_one, minus_one + minus_one_words) are set to -1 by a single fill of that block (optional; others are filled
+ * one by one). */
+int tl_rulebooks_build(const tl_level* levels, int num_levels, int32_t* minus_one, int64_t minus_one_words,
+                       const int32_t* pcoords, int64_t N, int64_t* v2p, tl_stream_t stream);
+
 /* Column form of a 27-tap SubM rulebook built by tl_rulebook_subm: compact i32[10][n] = the row of the first present
  * dz neighbour of each of the 9 (dx, dy) columns (or -1) followed by a 27-bit presence mask.  Present neighbours of a
  * column are consecutive rows, so entry k = 3 c + d is compact[c] + popcount(mask bits 3c .. k-1).  tl_conv_fwd reads this

@@ -667,6 +667,62 @@ def test_compact_rulebook_equals_table():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("extent,shape", [(6.0, None), (21.0, [500, 500, 1000]), (9.3, None)])
+def test_pyramid_calls_equal_per_level_calls(extent, shape):
+    """tl_pyramid_build + tl_rulebooks_build (what build_geometry uses: deep levels built by one workgroup / shared launches, one
+    backing block) against the per-level entry points of the same library, array by array, incl. odd extents whose last
+    cells are dropped by the k2s2 output shape (parent = -1 rows)."""
+    from treelearn_amd import _hip
+    from treelearn_amd.geometry import build_geometry, level_shapes, _nwords
+    from treelearn_amd.synth import make_tile
+    L = _hip.lib(); st = _hip.stream()
+    t = make_tile(extent=extent, voxel=0.1, n_trees=5, fill=0.08, seed=11)
+    pts = torch.from_numpy(t["points"]).cuda(); N = len(pts)
+    bid = torch.zeros(N, dtype=torch.int64, device="cuda")
+    nl = 7 if extent > 7 else 4
+    g = build_geometry(pts, bid, 1, 0.1, nl, shape)
+    i32 = lambda *sh: torch.empty(sh, dtype=torch.int32, device="cuda")             # noqa: E731
+    shapes = level_shapes(shape if shape is not None else g.levels[0].dims[1:], nl)
+    bms, pfs, ns = [], [], []
+    for li, lv in enumerate(g.levels):
+        nw = _nwords(lv.dims)
+        bm = torch.empty(nw, dtype=torch.int64, device="cuda"); pf = i32(nw); cnt = i32(1); ws = i32(int(L.tl_scan_ws_words(nw)))
+        if li == 0:
+            _hip.check(L.tl_bitmap_from_points(_hip.ptr(g.pcoords), N, _hip.dims4(lv.dims), _hip.ptr(bm), st), "bitmap")
+        else:
+            _hip.check(L.tl_bitmap_down(_hip.ptr(bms[-1]), _hip.dims4(g.levels[li - 1].dims), _hip.dims3(shapes[li]), _hip.ptr(bm),
+                                        _hip.dims4(lv.dims), st), "down")
+        _hip.check(L.tl_bitmap_scan(_hip.ptr(bm), nw, _hip.ptr(pf), _hip.ptr(cnt), _hip.ptr(ws), st), "scan")
+        bms.append(bm); pfs.append(pf); ns.append(int(cnt.item()))
+        assert torch.equal(bm, lv.bitmap) and torch.equal(pf, lv.prefix) and ns[-1] == lv.n, f"level {li}"
+    coords = []
+    for li, lv in enumerate(g.levels):
+        c = i32(lv.n, 4); nbr = i32(27, lv.n); ct = i32(10, lv.n)
+        _hip.check(L.tl_expand_coords(_hip.ptr(bms[li]), _hip.ptr(pfs[li]), _hip.dims4(lv.dims), _hip.ptr(c), st), "expand")
+        _hip.check(L.tl_rulebook_subm(_hip.ptr(c), lv.n, _hip.ptr(bms[li]), _hip.ptr(pfs[li]), _hip.dims4(lv.dims), _hip.ptr(nbr),
+                                      _hip.ptr(ct), st), "subm")
+        coords.append(c)
+        assert torch.equal(c, lv.coords) and torch.equal(nbr, lv.nbr), f"level {li}"
+        ct2 = i32(10, lv.n)
+        _hip.check(L.tl_rulebook_compact(_hip.ptr(nbr), lv.n, _hip.ptr(ct2), st), "compact")
+        assert torch.equal(ct, ct2)
+        if getattr(lv.nbr, "_tl_compact", None) is not None:
+            assert torch.equal(lv.nbr._tl_compact, ct)
+    dropped = 0
+    for li in range(nl - 1):
+        f, c = g.levels[li], g.levels[li + 1]
+        child = i32(8, c.n); parent = i32(f.n); inv = i32(8, f.n)
+        _hip.check(L.tl_rulebook_down(_hip.ptr(coords[li + 1]), c.n, _hip.ptr(bms[li]), _hip.ptr(pfs[li]), _hip.dims4(f.dims), f.n,
+                                      _hip.ptr(child), _hip.ptr(parent), _hip.ptr(inv), st), "rb down")
+        assert torch.equal(child, f.child) and torch.equal(parent, f.parent) and torch.equal(inv, f.inv), f"level {li}"
+        dropped += int((parent < 0).sum())
+    if shape is None and any(d % 2 for d in g.levels[0].shape):
+        assert dropped > 0                                         # an odd extent drops the cells at its last index (parent = -1)
+    v2p = torch.empty(N, dtype=torch.int64, device="cuda")
+    _hip.check(L.tl_point_rank(_hip.ptr(g.pcoords), N, _hip.ptr(bms[0]), _hip.ptr(pfs[0]), _hip.dims4(g.levels[0].dims), _hip.ptr(v2p), st), "rank")
+    assert torch.equal(v2p, g.v2p)
+
+
 def test_kernel_families_agree_on_a_real_tile():
     """Size-independent check at realistic scale (24 x 24 m tile, 0.7 M points, all seven levels populated): the bf16 forward
     must not depend on WHICH kernel family serves a layer.  Default dispatch (direct / stream-q / stream / small, column-form

@@ -33,6 +33,11 @@ class TileBox(_c.Structure):               # tl_tile_box
     _fields_ = [("outer", _c.c_float * 4), ("inner", _c.c_double * 4), ("center", _c.c_double * 2), ("half_inner", _c.c_float)]
 
 
+class Level(_c.Structure):                 # tl_level
+    _fields_ = [("dims", _c.c_int32 * 4), ("n", _c.c_int64), ("bitmap", _c.c_void_p), ("prefix", _c.c_void_p), ("coords", _c.c_void_p),
+                ("nbr", _c.c_void_p), ("compact", _c.c_void_p), ("child", _c.c_void_p), ("parent", _c.c_void_p), ("inv", _c.c_void_p)]
+
+
 _I4 = _i32 * 4
 _I3 = _i32 * 3
 
@@ -52,6 +57,9 @@ PROTOTYPES = {
     "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp, _vp]),
     "tl_rulebook_down": (_i32, [_vp, _i64, _vp, _vp, _I4, _i64, _vp, _vp, _vp, _vp]),
     "tl_rulebook_compact": (_i32, [_vp, _i64, _vp, _vp]),
+    "tl_pyramid_ws_words": (_i64, [_I4, _i32, _c.POINTER(_i64)]),
+    "tl_pyramid_build": (_i32, [_vp, _i64, _I4, _I3, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tl_rulebooks_build": (_i32, [_c.POINTER(Level), _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -158,32 +158,37 @@ __device__ __forceinline__ uint64_t pair_or_compress(uint64_t w) {  // bit i of 
   return t;
 }
 
+// word i of the coarse bitmap: OR of the 2x2x2 children, cells at or beyond out_shape dropped
+__device__ __forceinline__ uint64_t down_word(const uint64_t* __restrict__ fine, const TlDims& f, int ox, int oy, int oz,
+                                              const TlDims& c, int64_t i) {
+  const int zw = (int)(i % c.Zw);
+  int64_t r = i / c.Zw;
+  const int y = (int)(r % c.Y); r /= c.Y;
+  const int x = (int)(r % c.X);
+  const int b = (int)(r / c.X);
+  uint64_t lo = 0, hi = 0;
+  if (x < ox && y < oy) {
+    for (int dx = 0; dx < 2; ++dx)
+      for (int dy = 0; dy < 2; ++dy) {
+        const int fx = 2 * x + dx, fy = 2 * y + dy;
+        if (fx >= f.X || fy >= f.Y) continue;
+        const int64_t wc = tl_col_word(f, b, fx, fy);
+        if (2 * zw < f.Zw) lo |= fine[wc + 2 * zw];
+        if (2 * zw + 1 < f.Zw) hi |= fine[wc + 2 * zw + 1];
+      }
+  }
+  uint64_t w = pair_or_compress(lo) | (pair_or_compress(hi) << 32);
+  const int z0 = zw * 64;                       // drop cells at or beyond out_shape.z
+  if (oz <= z0) w = 0;
+  else if (oz < z0 + 64) w &= (1ull << (oz - z0)) - 1;
+  return w;
+}
+
 __global__ void __launch_bounds__(kBlock) k_bitmap_down(const uint64_t* __restrict__ fine, TlDims f, int ox, int oy, int oz,
                                                         uint64_t* __restrict__ coarse, TlDims c) {
   const int64_t n = tl_nwords(c);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int zw = (int)(i % c.Zw);
-    int64_t r = i / c.Zw;
-    const int y = (int)(r % c.Y); r /= c.Y;
-    const int x = (int)(r % c.X);
-    const int b = (int)(r / c.X);
-    uint64_t lo = 0, hi = 0;
-    if (x < ox && y < oy) {
-      for (int dx = 0; dx < 2; ++dx)
-        for (int dy = 0; dy < 2; ++dy) {
-          const int fx = 2 * x + dx, fy = 2 * y + dy;
-          if (fx >= f.X || fy >= f.Y) continue;
-          const int64_t wc = tl_col_word(f, b, fx, fy);
-          if (2 * zw < f.Zw) lo |= fine[wc + 2 * zw];
-          if (2 * zw + 1 < f.Zw) hi |= fine[wc + 2 * zw + 1];
-        }
-    }
-    uint64_t w = pair_or_compress(lo) | (pair_or_compress(hi) << 32);
-    const int z0 = zw * 64;                       // drop cells at or beyond out_shape.z
-    if (oz <= z0) w = 0;
-    else if (oz < z0 + 64) w &= (1ull << (oz - z0)) - 1;
-    coarse[i] = w;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    coarse[i] = down_word(fine, f, ox, oy, oz, c, i);
 }
 
 // ---------------------------------------------------------------- popcount exclusive scan (3 passes)
@@ -240,10 +245,63 @@ __global__ void __launch_bounds__(kBlock) k_scan_final(const uint64_t* __restric
   for (int j = 0; j < kScanItems; ++j) { if (base + j < n) prefix[base + j] = ex; ex += c[j]; }
 }
 
-__global__ void __launch_bounds__(kBlock) k_expand_coords(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, TlDims d,
-                                                          int32_t* __restrict__ coords) {
+// The deep levels of the pyramid are a few thousand words each: one 1024-thread workgroup builds all of them (down-sample,
+// popcount scan, total) level after level instead of four launches per level.  Every thread scans the words it wrote itself;
+// the next level reads its neighbours' words after the workgroup barrier.
+constexpr int kPyrBlock = 1024;
+constexpr int kPyrMaxLevels = 8;
+constexpr int64_t kPyrSmallWords = 4096;
+struct PyrSmall {
+  int nl, first;                       // levels first .. first+nl-1 are built here
+  TlDims d[kPyrMaxLevels + 1];         // d[0] = the level they start from, d[1+j] = level first+j
+  int out[kPyrMaxLevels][3];           // out_shape of level first+j
+  int64_t off[kPyrMaxLevels + 1];      // word offsets into the bitmap / prefix arrays, like d
+};
+
+__global__ void __launch_bounds__(kPyrBlock) k_pyramid_small(uint64_t* bm_all, uint32_t* __restrict__ pf_all,
+                                                             uint32_t* __restrict__ counts, PyrSmall p) {
+  __shared__ uint32_t wsum[kPyrBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int j = 0; j < p.nl; ++j) {
+    const uint64_t* fine = bm_all + p.off[j];
+    uint64_t* coarse = bm_all + p.off[j + 1];
+    uint32_t* prefix = pf_all + p.off[j + 1];
+    const TlDims f = p.d[j], c = p.d[j + 1];
+    const int64_t n = tl_nwords(c);
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < n; base += kPyrBlock) {
+      const int64_t i = base + threadIdx.x;
+      uint32_t v = 0;
+      if (i < n) {
+        const uint64_t w = down_word(fine, f, p.out[j][0], p.out[j][1], p.out[j][2], c, i);
+        coarse[i] = w;
+        v = __popcll(w);
+      }
+      uint32_t inc = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += t;
+      }
+      if (lane == 63) wsum[wid] = inc;
+      __syncthreads();
+      uint32_t before = 0, tot = 0;
+      for (int w = 0; w < kPyrBlock / 64; ++w) { if (w < wid) before += wsum[w]; tot += wsum[w]; }
+      __syncthreads();
+      if (i < n) prefix[i] = carry + before + inc - v;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) counts[p.first + j] = carry;
+    __threadfence_block();
+    __syncthreads();                    // level first+j complete before first+j+1 reads it
+  }
+}
+
+// Bodies of the per-level kernels take (first item, stride) so that one launch can also cover several small levels
+// (k_*_multi below: each workgroup finds its level from a table of first-workgroup indices).
+__device__ __forceinline__ void expand_coords_body(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, const TlDims& d,
+                                                   int32_t* __restrict__ coords, int64_t first, int64_t stride) {
   const int64_t n = tl_nwords(d);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = first; i < n; i += stride) {
     uint64_t w = bm[i];
     if (!w) continue;
     const int zw = (int)(i % d.Zw);
@@ -260,6 +318,11 @@ __global__ void __launch_bounds__(kBlock) k_expand_coords(const uint64_t* __rest
   }
 }
 
+__global__ void __launch_bounds__(kBlock) k_expand_coords(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, TlDims d,
+                                                          int32_t* __restrict__ coords) {
+  expand_coords_body(bm, pf, d, coords, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
 __global__ void __launch_bounds__(kBlock) k_point_rank(const int32_t* __restrict__ pc, int64_t N, const uint64_t* __restrict__ bm,
                                                        const uint32_t* __restrict__ pf, TlDims d, int64_t* __restrict__ v2p) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -271,10 +334,10 @@ __global__ void __launch_bounds__(kBlock) k_point_rank(const int32_t* __restrict
 }
 
 // ---------------------------------------------------------------- rulebooks
-__global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restrict__ coords, int64_t M, const uint64_t* __restrict__ bm,
-                                                          const uint32_t* __restrict__ pf, TlDims d, int32_t* __restrict__ nbr,
-                                                          int32_t* __restrict__ compact) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void rulebook_subm_body(const int32_t* __restrict__ coords, int64_t M, const uint64_t* __restrict__ bm,
+                                                   const uint32_t* __restrict__ pf, const TlDims& d, int32_t* __restrict__ nbr,
+                                                   int32_t* __restrict__ compact, int64_t first, int64_t stride) {
+  for (int64_t i = first; i < M; i += stride) {
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     uint32_t cmask = 0;
 #pragma unroll
@@ -312,10 +375,16 @@ __global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restr
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
-                                                          const uint32_t* __restrict__ fpf, TlDims f, int64_t Mf,
-                                                          int32_t* __restrict__ child, int32_t* __restrict__ parent, int32_t* __restrict__ inv) {
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Mc; q += (int64_t)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restrict__ coords, int64_t M, const uint64_t* __restrict__ bm,
+                                                          const uint32_t* __restrict__ pf, TlDims d, int32_t* __restrict__ nbr,
+                                                          int32_t* __restrict__ compact) {
+  rulebook_subm_body(coords, M, bm, pf, d, nbr, compact, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+__device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
+                                                   const uint32_t* __restrict__ fpf, const TlDims& f, int64_t Mf, int32_t* __restrict__ child,
+                                                   int32_t* __restrict__ parent, int32_t* __restrict__ inv, int64_t first, int64_t stride) {
+  for (int64_t q = first; q < Mc; q += stride) {
     const int4 c = reinterpret_cast<const int4*>(cc)[q];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -326,6 +395,47 @@ __global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restr
       if (r >= 0) { parent[r] = (int)q; inv[(int64_t)k * Mf + r] = (int)q; }
     }
   }
+}
+
+__global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
+                                                          const uint32_t* __restrict__ fpf, TlDims f, int64_t Mf,
+                                                          int32_t* __restrict__ child, int32_t* __restrict__ parent, int32_t* __restrict__ inv) {
+  rulebook_down_body(cc, Mc, fbm, fpf, f, Mf, child, parent, inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// One launch over several small levels: workgroup b works on level l with first[l] <= b < first[l+1].
+struct LevelPack {
+  int nl;
+  int first[kPyrMaxLevels + 1];
+  TlDims d[kPyrMaxLevels];
+  int64_t n[kPyrMaxLevels];
+  const uint64_t* bm[kPyrMaxLevels];
+  const uint32_t* pf[kPyrMaxLevels];
+  int32_t* coords[kPyrMaxLevels];
+  int32_t* nbr[kPyrMaxLevels];
+  int32_t* child[kPyrMaxLevels];      // tables between level l (fine) and l+1 (coarse); the launch walks the coarse rows
+  int32_t* parent[kPyrMaxLevels];
+  int32_t* inv[kPyrMaxLevels];
+};
+__device__ __forceinline__ int pack_level(const LevelPack& p) {
+  int l = 0;
+  while (l + 1 < p.nl && (int)blockIdx.x >= p.first[l + 1]) ++l;
+  return l;
+}
+__global__ void __launch_bounds__(kBlock) k_expand_coords_multi(LevelPack p) {
+  const int l = pack_level(p);
+  expand_coords_body(p.bm[l], p.pf[l], p.d[l], p.coords[l], (int64_t)(blockIdx.x - p.first[l]) * kBlock + threadIdx.x,
+                     (int64_t)(p.first[l + 1] - p.first[l]) * kBlock);
+}
+__global__ void __launch_bounds__(kBlock) k_rulebook_subm_multi(LevelPack p) {
+  const int l = pack_level(p);
+  rulebook_subm_body(p.coords[l], p.n[l], p.bm[l], p.pf[l], p.d[l], p.nbr[l], nullptr,
+                     (int64_t)(blockIdx.x - p.first[l]) * kBlock + threadIdx.x, (int64_t)(p.first[l + 1] - p.first[l]) * kBlock);
+}
+__global__ void __launch_bounds__(kBlock) k_rulebook_down_multi(LevelPack p) {    // here level slot l = the FINE level; coarse = slot l+1
+  const int l = pack_level(p);
+  rulebook_down_body(p.coords[l + 1], p.n[l + 1], p.bm[l], p.pf[l], p.d[l], p.n[l], p.child[l], p.parent[l], p.inv[l],
+                     (int64_t)(blockIdx.x - p.first[l]) * kBlock + threadIdx.x, (int64_t)(p.first[l + 1] - p.first[l]) * kBlock);
 }
 
 // 27-tap SubM rulebook -> column form: for each of the 9 (dx, dy) columns the row index of its first present dz neighbour,
@@ -467,6 +577,124 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
   if (hipMemsetAsync(parent, 0xFF, Mf * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   if (hipMemsetAsync(inv, 0xFF, Mf * 8 * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+// ---- whole-pyramid entry points: the same kernels, enqueued from one call each (the per-level calls above leave the GPU
+// waiting on the host between the many tiny launches of the deep levels), the deep levels batched into shared launches.
+int64_t tl_pyramid_ws_words(const int32_t dims0[4], int num_levels, int64_t* level_word_offsets) {
+  if (!dims0 || num_levels < 1 || num_levels > kPyrMaxLevels) return -1;
+  int32_t d[4] = {dims0[0], dims0[1], dims0[2], dims0[3]};
+  int64_t off = 0, mx = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const int64_t nw = tl_nwords(tl_dims(d));
+    if (level_word_offsets) level_word_offsets[l] = off;
+    off += nw;
+    if (nw > mx) mx = nw;
+    for (int j = 1; j < 4; ++j) d[j] = (d[j] + 1) / 2;
+  }
+  if (level_word_offsets) level_word_offsets[num_levels] = off;
+  return tl_scan_ws_words(mx);
+}
+
+int tl_pyramid_build(const int32_t* pcoords, int64_t N, const int32_t dims0[4], const int32_t shape0[3], int num_levels,
+                     uint64_t* bitmaps, uint32_t* prefixes, uint32_t* counts, uint32_t* ws, tl_stream_t stream) {
+  if (!pcoords || !dims0 || !shape0 || !bitmaps || !prefixes || !counts || !ws || N <= 0 || num_levels < 1 || num_levels > kPyrMaxLevels)
+    return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  TlDims d[kPyrMaxLevels];
+  int out[kPyrMaxLevels][3];
+  int64_t off[kPyrMaxLevels + 1];
+  int32_t dd[4] = {dims0[0], dims0[1], dims0[2], dims0[3]};
+  int sh[3] = {shape0[0], shape0[1], shape0[2]};
+  off[0] = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    d[l] = tl_dims(dd);
+    for (int j = 0; j < 3; ++j) out[l][j] = sh[j];
+    off[l + 1] = off[l] + tl_nwords(d[l]);
+    for (int j = 1; j < 4; ++j) dd[j] = (dd[j] + 1) / 2;
+    for (int j = 0; j < 3; ++j) sh[j] /= 2;
+  }
+  if (hipMemsetAsync(bitmaps, 0, tl_nwords(d[0]) * 8, s) != hipSuccess) return TL_ERR_LAUNCH;
+  k_set_bits<<<tl_grid(N, kBlock), kBlock, 0, s>>>(pcoords, N, d[0], reinterpret_cast<unsigned long long*>(bitmaps));
+  int l = 0;
+  for (; l < num_levels; ++l) {
+    const int64_t nw = tl_nwords(d[l]);
+    if (l > 0 && nw <= kPyrSmallWords) break;           // the rest goes into one workgroup
+    if (l > 0)
+      k_bitmap_down<<<tl_grid(nw, kBlock), kBlock, 0, s>>>(bitmaps + off[l - 1], d[l - 1], out[l][0], out[l][1], out[l][2], bitmaps + off[l], d[l]);
+    const int64_t nb = tl_cdiv(nw, kScanTile);
+    k_scan_partials<<<(unsigned)nb, kBlock, 0, s>>>(bitmaps + off[l], nw, ws);
+    k_scan_blocks<<<1, kBlock, 0, s>>>(ws, nb, counts + l);
+    k_scan_final<<<(unsigned)nb, kBlock, 0, s>>>(bitmaps + off[l], nw, ws, prefixes + off[l]);
+  }
+  if (l < num_levels) {
+    PyrSmall p;
+    p.nl = num_levels - l; p.first = l;
+    p.d[0] = d[l - 1]; p.off[0] = off[l - 1];
+    for (int j = 0; j < p.nl; ++j) {
+      p.d[j + 1] = d[l + j]; p.off[j + 1] = off[l + j];
+      for (int k = 0; k < 3; ++k) p.out[j][k] = out[l + j][k];
+    }
+    k_pyramid_small<<<1, kPyrBlock, 0, s>>>(bitmaps, prefixes, counts, p);
+  }
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, int64_t minus_one_words,
+                       const int32_t* pcoords, int64_t N, int64_t* v2p, tl_stream_t stream) {
+  if (!lv || num_levels < 1 || num_levels > kPyrMaxLevels) return TL_ERR_ARG;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!lv[l].bitmap || !lv[l].prefix || !lv[l].coords || !lv[l].nbr || lv[l].n <= 0) return TL_ERR_ARG;
+    if (l + 1 < num_levels && (!lv[l].child || !lv[l].parent || !lv[l].inv)) return TL_ERR_ARG;
+  }
+  hipStream_t s = tl_s(stream);
+  // parent / inv default to -1: one fill when the caller carved them out of one block, else one per array
+  auto inside = [&](const int32_t* q, int64_t words) { return minus_one && q >= minus_one && q + words <= minus_one + minus_one_words; };
+  if (minus_one && minus_one_words > 0 && hipMemsetAsync(minus_one, 0xFF, minus_one_words * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
+  for (int l = 0; l + 1 < num_levels; ++l) {
+    if (!inside(lv[l].parent, lv[l].n) && hipMemsetAsync(lv[l].parent, 0xFF, lv[l].n * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
+    if (!inside(lv[l].inv, lv[l].n * 8) && hipMemsetAsync(lv[l].inv, 0xFF, lv[l].n * 32, s) != hipSuccess) return TL_ERR_LAUNCH;
+  }
+  int small = num_levels;                               // levels small .. L-1 share launches
+  for (int l = num_levels - 1; l >= 1; --l) {
+    if (tl_nwords(tl_dims(lv[l].dims)) <= kPyrSmallWords && lv[l].n <= 64 * kPyrSmallWords && !lv[l].compact) small = l; else break;
+  }
+  if (num_levels - small < 2) small = num_levels;
+  for (int l = 0; l < small; ++l) {
+    const TlDims d = tl_dims(lv[l].dims);
+    k_expand_coords<<<tl_grid(tl_nwords(d), kBlock), kBlock, 0, s>>>(lv[l].bitmap, lv[l].prefix, d, lv[l].coords);
+    k_rulebook_subm<<<tl_grid(lv[l].n, kBlock), kBlock, 0, s>>>(lv[l].coords, lv[l].n, lv[l].bitmap, lv[l].prefix, d, lv[l].nbr, lv[l].compact);
+  }
+  LevelPack p;
+  p.nl = num_levels - small;
+  if (p.nl > 0) {
+    for (int j = 0; j < p.nl; ++j) {
+      const tl_level& v = lv[small + j];
+      p.d[j] = tl_dims(v.dims); p.n[j] = v.n; p.bm[j] = v.bitmap; p.pf[j] = v.prefix; p.coords[j] = v.coords; p.nbr[j] = v.nbr;
+      p.child[j] = v.child; p.parent[j] = v.parent; p.inv[j] = v.inv;
+    }
+    p.first[0] = 0;
+    for (int j = 0; j < p.nl; ++j) p.first[j + 1] = p.first[j] + (int)tl_cdiv(tl_nwords(p.d[j]), kBlock);
+    k_expand_coords_multi<<<p.first[p.nl], kBlock, 0, s>>>(p);
+    for (int j = 0; j < p.nl; ++j) p.first[j + 1] = p.first[j] + (int)tl_cdiv(p.n[j], kBlock);
+    k_rulebook_subm_multi<<<p.first[p.nl], kBlock, 0, s>>>(p);
+  }
+  for (int l = 0; l + 1 < num_levels && l < small; ++l) {   // fine level l big (or the last big one): its own launch
+    const tl_level &f = lv[l], &c = lv[l + 1];
+    k_rulebook_down<<<tl_grid(c.n, kBlock), kBlock, 0, s>>>(c.coords, c.n, f.bitmap, f.prefix, tl_dims(f.dims), f.n, f.child, f.parent, f.inv);
+  }
+  if (p.nl > 1) {                                           // fine levels small .. L-2: workgroups over the coarse rows
+    p.nl -= 1;                                              // slots 0 .. nl-2 are fine levels; slot j+1 is read as the coarse one
+    for (int j = 0; j < p.nl; ++j) p.first[j + 1] = p.first[j] + (int)tl_cdiv(p.n[j + 1], kBlock);
+    k_rulebook_down_multi<<<p.first[p.nl], kBlock, 0, s>>>(p);
+  }
+  if (v2p) {
+    if (!pcoords || N <= 0) return TL_ERR_ARG;
+    k_point_rank<<<tl_grid(N, kBlock), kBlock, 0, s>>>(pcoords, N, lv[0].bitmap, lv[0].prefix, tl_dims(lv[0].dims), v2p);
+  }
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

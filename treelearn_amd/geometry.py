@@ -6,6 +6,7 @@ batch of tiles, the PointToVoxel call and `.tolist()` syncs of `voxelize`
 generation (`subm1..7`, `spconv1..6`; blocks.py:57-70,104-123).  Two host syncs per batch in total:
 the grid extent (3 ints) and the per-level voxel counts (L ints).
 """
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -63,33 +64,9 @@ def level_shapes(shape1, num_levels):
     return shapes
 
 
-def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: int, voxel_size: float,
-                   num_levels: int, spatial_shape: Optional[List[int]] = None, need_inverse: bool = True) -> TileGeometry:
-    L = _hip.lib()
-    st = _hip.stream()
-    _hip.require_cuda(coords, "coords"); _hip.require_cuda(batch_ids, "batch_ids")
-    if coords.dtype != torch.float32 or batch_ids.dtype != torch.int64:
-        raise TypeError("coords must be float32 [N,3] and batch_ids int64 [N]")
-    N = coords.shape[0]
-    dev = coords.device
-    if N == 0:
-        raise ValueError("empty tile")
-
-    # 1. per-point voxel coordinates (fp32 floor((p - min_b)/vs)) + grid extent
-    pcoords = torch.empty((N, 4), dtype=torch.int32, device=dev)
-    maxc = torch.empty(4, dtype=torch.int32, device=dev)
-    ws_mm = torch.empty(batch_size * 6, dtype=torch.int32, device=dev)
-    _hip.check(L.tl_voxel_point_coords(_hip.ptr(coords), _hip.ptr(batch_ids), N, batch_size, float(voxel_size),
-                                       _hip.ptr(ws_mm), _hip.ptr(pcoords), _hip.ptr(maxc), st), "tl_voxel_point_coords")
-    mx = maxc.tolist()                                     # host sync #1
-    if mx[3]:
-        raise ValueError("voxelize: batch id out of range or voxel coordinate outside [0, 65536)")
-    extent = (mx[0] + 1, mx[1] + 1, mx[2] + 1)
-    shape1 = tuple(spatial_shape) if spatial_shape is not None else extent      # tree_learn.py:86-87,165
-    if any(e > s for e, s in zip(extent, shape1)):
-        raise ValueError(f"tile extent {extent} voxels exceeds spatial_shape {shape1}")
-    shapes = level_shapes(shape1, num_levels)
-
+def _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_levels):
+    """The same pyramid through the per-level entry points (one call per kernel group and level; `TL_GEOM=per_level`, kept for
+    A/B runs and as the reference for tests of the two-call form)."""
     # 2. occupancy bitmaps + popcount prefix sums for every level (no host involvement)
     dims = [(batch_size,) + extent]
     for _ in range(num_levels - 1):
@@ -140,6 +117,105 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     _hip.check(L.tl_point_rank(_hip.ptr(pcoords), N, _hip.ptr(levels[0].bitmap), _hip.ptr(levels[0].prefix), _hip.dims4(levels[0].dims),
                                _hip.ptr(v2p), st), "tl_point_rank")
     return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[bm_all, pf_all])
+
+
+def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: int, voxel_size: float,
+                   num_levels: int, spatial_shape: Optional[List[int]] = None, need_inverse: bool = True) -> TileGeometry:
+    L = _hip.lib()
+    st = _hip.stream()
+    _hip.require_cuda(coords, "coords"); _hip.require_cuda(batch_ids, "batch_ids")
+    if coords.dtype != torch.float32 or batch_ids.dtype != torch.int64:
+        raise TypeError("coords must be float32 [N,3] and batch_ids int64 [N]")
+    N = coords.shape[0]
+    dev = coords.device
+    if N == 0:
+        raise ValueError("empty tile")
+
+    # 1. per-point voxel coordinates (fp32 floor((p - min_b)/vs)) + grid extent
+    pcoords = torch.empty((N, 4), dtype=torch.int32, device=dev)
+    maxc = torch.empty(4, dtype=torch.int32, device=dev)
+    ws_mm = torch.empty(batch_size * 6, dtype=torch.int32, device=dev)
+    _hip.check(L.tl_voxel_point_coords(_hip.ptr(coords), _hip.ptr(batch_ids), N, batch_size, float(voxel_size),
+                                       _hip.ptr(ws_mm), _hip.ptr(pcoords), _hip.ptr(maxc), st), "tl_voxel_point_coords")
+    mx = maxc.tolist()                                     # host sync #1
+    if mx[3]:
+        raise ValueError("voxelize: batch id out of range or voxel coordinate outside [0, 65536)")
+    extent = (mx[0] + 1, mx[1] + 1, mx[2] + 1)
+    shape1 = tuple(spatial_shape) if spatial_shape is not None else extent      # tree_learn.py:86-87,165
+    if any(e > s for e, s in zip(extent, shape1)):
+        raise ValueError(f"tile extent {extent} voxels exceeds spatial_shape {shape1}")
+    shapes = level_shapes(shape1, num_levels)
+
+    if os.environ.get("TL_GEOM") == "per_level":
+        return _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_levels)
+
+    # 2. occupancy bitmaps + popcount prefix sums for every level: one call, one backing allocation
+    dims = [(batch_size,) + extent]
+    for _ in range(num_levels - 1):
+        d = dims[-1]
+        dims.append((d[0], (d[1] + 1) // 2, (d[2] + 1) // 2, (d[3] + 1) // 2))
+    nw = [_nwords(d) for d in dims]
+    tw = sum(nw)
+    n_ws = int(L.tl_pyramid_ws_words(_hip.dims4(dims[0]), num_levels, None))
+    # [bitmaps u64 tw | prefixes u32 tw | counts u32 8 | scan scratch]
+    pyr = torch.empty(3 * tw + 8 + n_ws, dtype=torch.int32, device=dev)
+    p0 = pyr.data_ptr()
+    _hip.check(L.tl_pyramid_build(_hip.ptr(pcoords), N, _hip.dims4(dims[0]), _hip.dims3(shapes[0]), num_levels,
+                                  p0, p0 + 8 * tw, p0 + 12 * tw, p0 + 12 * tw + 32, st), "tl_pyramid_build")
+    ns = pyr[3 * tw:3 * tw + num_levels].tolist()          # host sync #2
+    bm_all = pyr[:2 * tw].view(torch.int64)
+    pf_all = pyr[2 * tw:3 * tw]
+    levels = []
+    off = 0
+    for li in range(num_levels):
+        n = int(ns[li])
+        if n <= 0:
+            raise ValueError("sparse conv produced an empty level: output spatial shape reach zero!!!")
+        levels.append(Level(n=n, dims=dims[li], shape=shapes[li], bitmap=bm_all[off:off + nw[li]], prefix=pf_all[off:off + nw[li]]))
+        off += nw[li]
+
+    # 3. coords, v2p, rulebooks: one backing allocation carved into the per-level arrays (64-word aligned), one call; the
+    #    tensor views are made after the launches are queued
+    want_ct = levels[0].n >= 65536                          # level 1 also gets the column form of its rulebook (40 instead of
+    al = lambda w: (w + 63) & ~63                           # noqa: E731   108 B/voxel); it rides on the table tensor as an attribute
+    cur = 0
+    def take(words):
+        nonlocal cur
+        o = cur; cur += al(words); return o
+    o_v2p = take(2 * N)
+    lay = []
+    for li, lv in enumerate(levels):
+        lay.append(dict(coords=take(4 * lv.n), nbr=take(27 * lv.n), ct=take(10 * lv.n) if (li == 0 and want_ct) else None,
+                        child=take(8 * levels[li + 1].n) if li + 1 < num_levels else None))
+    o_m1 = cur                                              # parent / inv of all levels: contiguous, one fill with -1
+    for li, lv in enumerate(levels[:-1]):
+        lay[li]["parent"] = take(lv.n); lay[li]["inv"] = take(8 * lv.n)
+    back = torch.empty(cur, dtype=torch.int32, device=dev)
+    b0 = back.data_ptr()
+    arr = (_hip.Level * num_levels)()
+    for li, lv in enumerate(levels):
+        a, y = arr[li], lay[li]
+        a.dims[:] = lv.dims; a.n = lv.n
+        a.bitmap = p0 + 8 * (sum(nw[:li])); a.prefix = p0 + 8 * tw + 4 * (sum(nw[:li]))
+        a.coords = b0 + 4 * y["coords"]; a.nbr = b0 + 4 * y["nbr"]
+        a.compact = b0 + 4 * y["ct"] if y["ct"] is not None else None
+        if li + 1 < num_levels:
+            a.child = b0 + 4 * y["child"]; a.parent = b0 + 4 * y["parent"]; a.inv = b0 + 4 * y["inv"]
+    _hip.check(L.tl_rulebooks_build(arr, num_levels, b0 + 4 * o_m1, cur - o_m1, _hip.ptr(pcoords), N, b0 + 4 * o_v2p, st),
+               "tl_rulebooks_build")
+    v2p = back[o_v2p:o_v2p + 2 * N].view(torch.int64)
+    for li, lv in enumerate(levels):
+        y = lay[li]
+        lv.coords = back[y["coords"]:y["coords"] + 4 * lv.n].view(lv.n, 4)
+        lv.nbr = back[y["nbr"]:y["nbr"] + 27 * lv.n].view(27, lv.n)
+        if y["ct"] is not None:
+            lv.nbr._tl_compact = back[y["ct"]:y["ct"] + 10 * lv.n].view(10, lv.n)
+        if li + 1 < num_levels:
+            nc = levels[li + 1].n
+            lv.child = back[y["child"]:y["child"] + 8 * nc].view(8, nc)
+            lv.parent = back[y["parent"]:y["parent"] + lv.n]
+            lv.inv = back[y["inv"]:y["inv"] + 8 * lv.n].view(8, lv.n)
+    return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[pyr, back])
 
 
 def voxel_mean_feats(point_feats: torch.Tensor, geom: TileGeometry, max_points: int) -> torch.Tensor:
