@@ -55,9 +55,12 @@ static __device__ __forceinline__ void quad_transpose(const u32x4 (&S)[4], u32x4
 
 // W waves per workgroup, each owning RB blocks of 32 rows (one weight fragment read from LDS feeds RB MFMAs).
 // ABL: developer ablation bits (1 no transposition, 2 no gathers, 4 no barrier, 8 no MFMA, 16 timers)
-template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL>
+// SP: the input channels are walked in SP slices of PN * 64: step v of the K * SP steps contracts slice v % SP of tap v / SP
+// (same registers and LDS as the PN-wide kernel; 256 -> 128 as SP = 2 x 128 instead of a PN = 4 kernel that spills).
+template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL, int SP = 1>
 __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   constexpr bool TM = (ABL & 16) != 0;
+  constexpr int KV = K * SP;
   constexpr int NTH = W * 64;
   constexpr int COUT = NB * 32, CIN = PN * 64;
   constexpr int BROW = CIN * 2 + 16;                  // LDS pitch of a weight row (+16 B: conflict-free ds_read_b128 down a column)
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   __builtin_amdgcn_wave_barrier();
 
   const int in_ld_b = (int)(p.in_ld * 2);
-  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * 2;
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * SP * 2;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
   const unsigned qoff = (unsigned)(fh * 64 + (lane & 3) * 16);
   const int* iq = iw + ((lane >> 2) & 7) * 4;
@@ -119,16 +122,16 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   u32x4 a[DA][RB][PN][4];
   u32x4 bw[RW][BPT], bw0[BPT];
   u32x4 idn[RB];                                       // row indices of the next tap to request
-  auto read_idx = [&](int k) __attribute__((always_inline)) {
+  auto read_idx = [&](int v) __attribute__((always_inline)) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) idn[rb] = *reinterpret_cast<const u32x4*>(iq + (k * RB + rb) * 32);
+    for (int rb = 0; rb < RB; ++rb) idn[rb] = *reinterpret_cast<const u32x4*>(iq + ((v / SP) * RB + rb) * 32);
   };
-  auto issue_a = [&](u32x4 (&dst)[RB][PN][4]) __attribute__((always_inline)) {
+  auto issue_a = [&](int v, u32x4 (&dst)[RB][PN][4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const unsigned base = idn[rb][i] * (unsigned)in_ld_b + qoff;
+        const unsigned base = idn[rb][i] * (unsigned)in_ld_b + qoff + (unsigned)((v % SP) * CIN * 2);
 #pragma unroll
         for (int pp = 0; pp < PN; ++pp) {
           if constexpr (ABL & 2) dst[rb][pp][i] = u32x4{base, base, base, base};
@@ -136,11 +139,12 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
         }
       }
   };
-  auto load_b = [&](int k, u32x4 (&dst)[BPT]) __attribute__((always_inline)) {
+  auto load_b = [&](int kv, u32x4 (&dst)[BPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
-      const int v = tid + q * NTH;
-      dst[q] = wsrc[(int64_t)k * BVEC + (BVEC % NTH == 0 ? v : min(v, BVEC - 1))];
+      const int v = BVEC % NTH == 0 ? tid + q * NTH : min(tid + q * NTH, BVEC - 1);
+      if constexpr (SP == 1) dst[q] = wsrc[(int64_t)kv * BVEC + v];
+      else dst[q] = wsrc[(((int64_t)(kv / SP) * COUT + v / BSLOTS) * SP + kv % SP) * BSLOTS + v % BSLOTS];   // [K][COUT][SP][BSLOTS]
     }
   };
   auto store_b = [&](int buf, const u32x4 (&src)[BPT]) __attribute__((always_inline)) {
@@ -156,8 +160,8 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   read_idx(0);
 #pragma unroll
   for (int d = 0; d < WA; ++d) {
-    if (d >= 1 && d < K) load_b(d, bw[d % RW]);
-    if (d < DA && d < K) { issue_a(a[d]); if (d + 1 < K) read_idx(d + 1); }
+    if (d >= 1 && d < KV) load_b(d, bw[d % RW]);
+    if (d < DA && d < KV) { issue_a(d, a[d]); if (d + 1 < KV) read_idx(d + 1); }
   }
   store_b(0, bw0);
   __syncthreads();
@@ -174,11 +178,11 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   };
   tick(-1);
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (k + 1 < K) store_b((k + 1) & 1, bw[(k + 1) % RW]);
-    if (k + WA < K) load_b(k + WA, bw[(k + WA) % RW]);
+  for (int k = 0; k < KV; ++k) {
+    if (k + 1 < KV) store_b((k + 1) & 1, bw[(k + 1) % RW]);
+    if (k + WA < KV) load_b(k + WA, bw[(k + WA) % RW]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TM) { if (k + DA < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (LA + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
+    if constexpr (TM) { if (k + DA < KV) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (LA + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
     tick(0);
     u32x4 F[RB][PN][4];
 #pragma unroll
@@ -203,9 +207,9 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
           }
         }
     tick(1);
-    if (k + DA < K) { issue_a(a[k % DA]); if (k + DA + 1 < K) read_idx(k + DA + 1); }
+    if (k + DA < KV) { issue_a(k + DA, a[k % DA]); if (k + DA + 1 < KV) read_idx(k + DA + 1); }
     tick(2);
-    if constexpr ((ABL & 4) == 0) { if (k + 1 < K) __syncthreads(); }
+    if constexpr ((ABL & 4) == 0) { if (k + 1 < KV) __syncthreads(); }
     tick(3);
   }
   if constexpr (TM) {
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
     }
 }
 
-template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0>
+template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0, int SP = 1>
 int launch(ConvP p, hipStream_t s) {
   constexpr int OCC = 2;
   const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)W * K * 32 * RB * 4, ep = (size_t)W * 32 * 36 * 4;
@@ -251,12 +255,12 @@ int launch(ConvP p, hipStream_t s) {
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
   p.nblk = (int)tl_cdiv(p.n_out, W * 32 * RB);
-  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL><<<p.nblk, W * 64, lds, s>>>(p);
+  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP><<<p.nblk, W * 64, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -302,6 +306,7 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
     if (nb == 2 && pn == 2) return launch<27, 2, 2, 2>(p, s);
     if (nb == 4 && pn == 2) return launch<27, 4, 2, 2>(p, s);
     if (nb == 3 && pn == 3) return launch<27, 3, 3, 2>(p, s);
+    if (nb == 4 && pn == 4) return launch<27, 4, 2, 2, 8, 1, 0, 2>(p, s);
   } else if (p.K == 8) {
     if (nb == 3 && pn == 1) return launch<8, 3, 1, 2>(p, s);
   }
