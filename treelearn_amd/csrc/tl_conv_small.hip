@@ -17,17 +17,24 @@ namespace {
 template <bool BF16, int NBB, int WV, bool FR>
 __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
-  constexpr int PF = 4;                                       // steps in flight per wave (independent loads issued together)
+  constexpr int PF = 4;                                       // steps per batch and wave (their independent loads are issued together)
+  constexpr int KMAX = 27;
   __shared__ float red[WV][NBB][16][64];
+  __shared__ int Is[KMAX * 32];                               // the block's slice of the rulebook, [k][row]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rt = blockIdx.x / ncolblk, cb = blockIdx.x % ncolblk;
-  const int64_t row = (int64_t)rt * 32 + (lane & 31);
   const int fi = lane & 31, fh = lane >> 5;
   const int col0 = cb * NBB * 32;
   const int nchunk = p.Cin / 32;
   const int nsteps = p.K * nchunk;
-  const bool rvalid = row < p.n_out;
   const bool pro = p.in_scale != nullptr || p.in_relu;
+
+  // Every (tap, chunk) step starts with a rulebook entry: fetched per step, that is a second dependent memory round trip in
+  // front of each batch of gathers.  One coalesced read of the whole [K][32] slice into LDS removes it from the loop.
+  for (int e = tid; e < p.K * 32; e += WV * 64) {
+    const int64_t r = (int64_t)rt * 32 + (e & 31);
+    Is[e] = r < p.n_out ? (p.table ? p.table[(int64_t)(e >> 5) * p.n_out + r] : (int)r) : -1;
+  }
 
   const int in_ld_b = (int)(p.in_ld * EB);
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)p.Cin * EB;
@@ -41,46 +48,47 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   for (int nb = 0; nb < NBB; ++nb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  __syncthreads();
 
-  // The wave's steps are s = wv, wv+WV, ...; PF of them are processed per iteration with all their loads issued before
-  // the first MFMA (deep levels are latency-bound: a few hundred rows, 27 x Cin/32 dependent load->MFMA chains).
-  for (int s0 = wv; s0 < nsteps; s0 += WV * PF) {
-    int idx[PF]; int kk[PF], ch[PF];
+  // The wave's steps are s = wv, wv+WV, ...; PF of them form a batch whose loads are all issued before the first MFMA (deep
+  // levels are latency-bound: a few hundred rows, 27 x Cin/32 dependent load->MFMA chains per wave).  Requesting the next
+  // batch before contracting the current one was measured: l=6,7 -5..-12 %, l=5 +6 % (twice the registers) -- not kept.
+  struct Batch { u32x4 a[PF][NJ], b[PF][NBB][NJ]; int idx[PF], ch[PF]; };
+  auto request = [&](int s0, Batch& B) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int s = s0 + WV * u;
       const bool sv = s < nsteps;
-      kk[u] = sv ? s / nchunk : 0; ch[u] = sv ? s % nchunk : 0;
-      idx[u] = (sv && rvalid) ? (p.table ? p.table[(int64_t)kk[u] * p.n_out + row] : (int)row) : -1;
-    }
-    u32x4 a[PF][NJ], b[PF][NBB][NJ];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
+      const int kk = sv ? s / nchunk : 0;
+      B.ch[u] = sv ? s % nchunk : 0;
+      B.idx[u] = sv ? Is[kk * 32 + fi] : -1;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const unsigned off = (unsigned)(ch[u] * UB + j * 32 + fh * 16);
-        if (buf_ok) a[u][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((unsigned)idx[u] * (unsigned)in_ld_b + off), 0, 0));
+        const unsigned off = (unsigned)(B.ch[u] * UB + j * 32 + fh * 16);
+        if (buf_ok) B.a[u][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((unsigned)B.idx[u] * (unsigned)in_ld_b + off), 0, 0));
         else {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(inb + (int64_t)max(idx[u], 0) * in_ld_b + off);
-          a[u][j] = idx[u] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+          const u32x4 v = *reinterpret_cast<const u32x4*>(inb + (int64_t)max(B.idx[u], 0) * in_ld_b + off);
+          B.a[u][j] = B.idx[u] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
         }
       }
 #pragma unroll
       for (int nb = 0; nb < NBB; ++nb)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          if constexpr (FR) b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk[u] * CBt + col0 / 32 + nb) * nchunk + ch[u]) * NJ + j) * 64 + lane) * 16);
-          else b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk[u] * p.Cout + col0 + nb * 32 + fi) * p.Cin + ch[u] * 32) * EB + j * 32 + fh * 16);
+          if constexpr (FR) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk * CBt + col0 / 32 + nb) * nchunk + B.ch[u]) * NJ + j) * 64 + lane) * 16);
+          else B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk * p.Cout + col0 + nb * 32 + fi) * p.Cin + B.ch[u] * 32) * EB + j * 32 + fh * 16);
     }
+  };
+  auto contract = [&](Batch& B) __attribute__((always_inline)) {
     if (pro) {                                                // gather-side BatchNorm+ReLU (module-by-module path only)
 #pragma unroll
       for (int u = 0; u < PF; ++u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (idx[u] < 0) continue;
-          const int c0 = ch[u] * 32 + (j * 32 + fh * 16) / EB;
+          if (B.idx[u] < 0) continue;
+          const int c0 = B.ch[u] * 32 + (j * 32 + fh * 16) / EB;
           if constexpr (BF16) {
-            u32x4 v = a[u][j];
+            u32x4 v = B.a[u][j];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float lo = bf16_lo(v[q]), hi = bf16_hi(v[q]);
@@ -88,15 +96,15 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
               if (p.in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
               v[q] = pack_bf16x2(lo, hi);
             }
-            a[u][j] = v;
+            B.a[u][j] = v;
           } else {
-            f32x4 v = __builtin_bit_cast(f32x4, a[u][j]);
+            f32x4 v = __builtin_bit_cast(f32x4, B.a[u][j]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               if (p.in_scale) v[q] = fmaf(v[q], p.in_scale[c0 + q], p.in_shift[c0 + q]);
               if (p.in_relu) v[q] = fmaxf(v[q], 0.f);
             }
-            a[u][j] = __builtin_bit_cast(u32x4, v);
+            B.a[u][j] = __builtin_bit_cast(u32x4, v);
           }
         }
     }
@@ -105,8 +113,10 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
       for (int nb = 0; nb < NBB; ++nb)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) mma16<BF16>(acc[nb], a[u][j], b[u][nb][j]);   // steps past the end hold zero A fragments
-  }
+        for (int j = 0; j < NJ; ++j) mma16<BF16>(acc[nb], B.a[u][j], B.b[u][nb][j]);   // steps past the end hold zero A fragments
+  };
+  Batch B0;
+  for (int s0 = wv; s0 < nsteps; s0 += WV * PF) { request(s0, B0); contract(B0); }
 
 #pragma unroll
   for (int nb = 0; nb < NBB; ++nb)
