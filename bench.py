@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
@@ -256,7 +257,7 @@ def main():
                 torch.cuda.synchronize(); d32 = (time.perf_counter() - t1) / 5
             res["fp32_parity_mode"] = dict(value=n_pts / d32 / 1e6, unit="Mpoints/s", ms_per_step=d32 * 1e3)
             del m32
-        if world == 1:
+        if world == 1 and not args.no_power_probe:
             pw = power_probe(step)
             if pw:
                 res["power"] = dict(pw, note="rocm-smi sample while the same forward loops for 2.5 s (untimed)")

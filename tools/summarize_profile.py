@@ -1,13 +1,15 @@
 """Turn the rocprofv3 outputs of a bench.py run into the files kept under profiles/<tag>/.
 
-    python tools/summarize_profile.py <gpurun_out/dir> <profiles/tag> <steps+warmup forwards profiled>
+    python tools/summarize_profile.py <gpurun_out/dir> <profiles/tag>
 
 Expects in <dir>: stats/*kernel_stats.csv (--kernel-trace --stats), fetch/*counter_collection.csv (--pmc FETCH_SIZE),
-write/*counter_collection.csv (--pmc WRITE_SIZE), bench_line.json.  PMC units are KB; gfx950 FETCH_SIZE is doubled
-(MI355X_MICROARCH.md, HBM section)."""
+write/*counter_collection.csv (--pmc WRITE_SIZE), optionally sq/*counter_collection.csv (--pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE), bench_line.json.
+PMC units are KB; gfx950 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section)."""
 import csv, glob, json, os, shutil, sys, collections
 
-src, dst, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3])
+src, dst = sys.argv[1], sys.argv[2]
+forwards = {}                                    # per PMC pass: forwards profiled = k_head dispatches seen
 os.makedirs(dst, exist_ok=True)
 ks = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
@@ -24,6 +26,8 @@ def pmc(sub, counter, out_name):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
+        if "k_head" in name:
+            forwards[sub] = forwards.get(sub, 0) + 1
         if "k_conv" not in name:
             continue
         name = '"' + name[name.index("k_conv"):].split("(ConvP")[0] + '"'
@@ -35,6 +39,35 @@ def pmc(sub, counter, out_name):
     return total
 
 
+def sq():
+    """Per conv kernel: MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (elapsed cycles x 1024 SIMDs), elapsed cycles =
+    GRBM_GUI_ACTIVE / 8 (the counter comes back summed over the 8 XCDs: 4.67 M for a 301 us dispatch = 1.94 GHz each;
+    MFMA_BUSY counts cycles summed over SIMDs = 32 x the number of 32x32x16 MFMAs, checked on the 64->64 conv:
+    1.105 M rows / 32 x 27 taps x 8 = 7.46 M MFMAs x 32 = 238.7 M, the exact counter value), the effective shader clock
+    under the profiler, and how the wave-cycles split into issuing / parked (s_waitcnt, barrier) / issue-stalled."""
+    files = glob.glob(os.path.join(src, "sq", "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        return
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(files[0])):
+        name = r["Kernel_Name"]
+        if "k_conv" not in name and "k_head" not in name:
+            continue
+        key = "k_head" if "k_head" in name else name[name.index("k_conv"):].split("(ConvP")[0]
+        per[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVE_CYCLES":
+            per[key]["dispatches"] += 1
+            per[key]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    with open(os.path.join(dst, "pmc_sq.csv"), "w") as f:
+        f.write("kernel,dispatches,avg_us,sclk_ghz,mfma_util_pct,wave_cycles_issuing_pct,wave_cycles_parked_pct,wave_cycles_issue_stall_pct\n")
+        for k, c in sorted(per.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
+            cyc, wc = max(c["GRBM_GUI_ACTIVE"] / 8, 1.0), max(c["SQ_WAVE_CYCLES"], 1.0)
+            f.write('"%s",%d,%.1f,%.2f,%.1f,%.1f,%.1f,%.1f\n' % (k, c["dispatches"], c["ns"] / c["dispatches"] / 1e3, cyc / max(c["ns"], 1.0),
+                    100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),
+                    100 * c["SQ_ACTIVE_INST_ANY"] / wc, 100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc))
+
+
+sq()
 fetch = pmc("fetch", "FETCH_SIZE", "pmc_fetch_size.csv")
 write = pmc("write", "WRITE_SIZE", "pmc_write_size.csv")
 bl = os.path.join(src, "bench_line.json")
@@ -42,9 +75,9 @@ if os.path.exists(bl):
     shutil.copy(bl, os.path.join(dst, "bench_line.json"))
 if fetch is not None and write is not None:
     t = {"dtype": "bf16", "workload": "config2", "forwards_profiled": forwards,
-         "fetch_size_kb_per_step": fetch / forwards, "write_size_kb_per_step": write / forwards,
+         "fetch_size_kb_per_step": fetch / forwards["fetch"], "write_size_kb_per_step": write / forwards["write"],
          "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled (MI355X_MICROARCH.md HBM section); units KB",
-         "hbm_gb_per_step": (2 * fetch + write) / forwards * 1024 / 1e9,
-         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"}
+         "hbm_gb_per_step": (2 * fetch / forwards["fetch"] + write / forwards["write"]) * 1024 / 1e9,
+         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-power-probe"}
     json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(t, indent=1))
