@@ -20,8 +20,21 @@ namespace {
 // ABL: developer ablation bits (tools/dev_direct_abl.py; results are wrong on purpose): 1 no gathers, 2 no MFMA,
 // 4 no output stores, 8 no rulebook loads (identity rows)
 // CT: the rulebook comes in column form (p.ctab, 40 B per voxel; decode_ctab) instead of the 27-entry table (108 B)
+__device__ unsigned long long g_tmd[8];   // developer timing mode (ABL bit 16): cycles summed over waves per tile segment
+
 template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false>
-__global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles) {
+__global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles, int walk) {
+  constexpr bool TM = (ABL & 16) != 0;
+  [[maybe_unused]] unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+  auto tick = [&](int seg) __attribute__((always_inline)) {
+    if constexpr (TM) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (seg >= 0) tm[seg] += t - tprev;
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   constexpr int EB = BF16 ? 2 : 4;                   // bytes per element
   constexpr int UB = 32 * EB;                        // bytes of one 32-channel unit of a row
   constexpr int NJ = UB / 32;                        // 16-B fragment pairs per unit (lane half h takes bytes j*32 + h*16)
@@ -55,14 +68,53 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
   const char* wl = Ws + fi * UB;
   float* ew = Es + wv * 32 * EP;
 
-  for (int tile = blockIdx.x * WAVES + wv; tile < ntiles; tile += gridDim.x * WAVES) {
-    const int64_t row = (int64_t)tile * 32 + fi;
-    const bool rvalid = row < p.n_out;
-    int idx[K];
-    if constexpr (K == 27 && CT) decode_ctab(p.ctab, p.n_out, row, rvalid, idx);
-    else {
+  // walk 1 (developer A/B): every XCD (block b runs on XCD b % 8) walks its own contiguous eighth of the tiles
+  const int nblk = walk ? ((int)gridDim.x >> 3) : (int)gridDim.x, bidx = walk ? ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t8 = walk ? (((ntiles + 7) / 8 + WAVES - 1) / WAVES) * WAVES : ntiles;
+  const int tbase = walk ? ((int)blockIdx.x & 7) * t8 : 0;
+  // Column-form kernel: the lane's ten rulebook words of tile t+1 are requested right after the LAST gather group of tile t
+  // (younger than every gather, so no gather wait ever includes them -- vmcnt retires in order) and are there when the next
+  // tile starts; taps are decoded from the words on use instead of being kept as 27 indices.  The per-segment timers (ABL 16)
+  // had shown a wave spending 24 % of a tile waiting for its rulebook entries; measured 0.200 -> 0.195 / 0.191 -> 0.175 ms.
+  // Requesting the tile's residual vectors ahead as well (23 % of a tile is the epilogue) pushed the kernel past 128 VGPRs
+  // and gave nothing (0.197 / 0.179); the 27-entry table form spills with any of this and keeps the plain order.
+  constexpr bool PF = (K == 27 && CT) && (ABL & 32) == 0;
+  constexpr int NW = (K == 27 && CT) ? 10 : K;
+  auto load_words = [&](int tile_, int (&w)[NW]) __attribute__((always_inline)) {
+    const int64_t row = (int64_t)tile_ * 32 + fi;
+    const bool rvalid = tile_ < ntiles && row < p.n_out;
 #pragma unroll
-      for (int k = 0; k < K; ++k) idx[k] = rvalid ? ((p.table && !(ABL & 8)) ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+    for (int k = 0; k < NW; ++k) {
+      if constexpr (K == 27 && CT) w[k] = rvalid ? p.ctab[(int64_t)k * p.n_out + row] : (k < 9 ? -1 : 0);
+      else w[k] = rvalid ? ((p.table && !(ABL & 8)) ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+    }
+  };
+  // column form: tap k = 3 c + d of the lane's row from the column base w[c] and the presence bits (see decode_ctab)
+  auto word_tap = [&](const int (&w)[NW], int k) __attribute__((always_inline)) {
+    const uint32_t m = ((uint32_t)w[NW - 1] >> (3 * (k / 3))) & 7u;
+    const int d = k % 3;
+    return ((m >> d) & 1u) ? w[k / 3] + __builtin_popcount(m & ((1u << d) - 1u)) : -1;
+  };
+  constexpr int VROW = NB * 4;
+  [[maybe_unused]] int twn[NW];
+  if constexpr (PF) load_words(tbase + bidx * WAVES + wv, twn);
+  for (int lt = bidx * WAVES + wv; lt < t8; lt += nblk * WAVES) {
+    const int tile = tbase + lt;
+    if (tile >= ntiles) break;
+    tick(-1);
+    [[maybe_unused]] int idx[PF ? 1 : K];
+    [[maybe_unused]] int twc[NW];                              // PF: the lane's rulebook words (requested during the previous tile); taps are decoded on use
+    if constexpr (PF) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) twc[k] = twn[k];
+    } else {
+      const int64_t row = (int64_t)tile * 32 + fi;
+      const bool rvalid = row < p.n_out;
+      if constexpr (K == 27 && CT) decode_ctab(p.ctab, p.n_out, row, rvalid, idx);
+      else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) idx[k] = rvalid ? ((p.table && !(ABL & 8)) ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+      }
     }
 
     f32x16 acc[NB];
@@ -77,7 +129,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
       for (int t = 0; t < G; ++t) {
         const int k = g * G + t;
         if (k < K) {
-          const unsigned base = (unsigned)idx[k] * (unsigned)in_ld_b + lane_off;
+          int ik;
+          if constexpr (PF) ik = word_tap(twc, k); else ik = idx[k];
+          const unsigned base = (unsigned)ik * (unsigned)in_ld_b + lane_off;
 #pragma unroll
           for (int c = 0; c < UN; ++c)
 #pragma unroll
@@ -87,10 +141,22 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
         }
       }
     };
+    if constexpr (TM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    tick(0);                                           // 0: rulebook entries (behind the previous tile's stores: vmcnt is in-order)
     issue(0, a[0]);
+    tick(1);                                           // 1: issuing the first group of gathers
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) issue(g + 1, a[(g + 1) & 1]);
+      if constexpr (PF) {
+        if (g == (NG >= 2 ? NG - 2 : 0)) {                      // all gathers of this tile are out: next rulebook words, this residual
+          const int lt2 = lt + nblk * WAVES;
+          load_words(lt2 < t8 ? tbase + lt2 : ntiles, twn);
+        }
+      }
+      tick(1);
+      if constexpr (TM) { if (g + 1 < NG) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * UN * NJ) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      tick(2);                                         // 2: waiting for group g
 #pragma unroll
       for (int t = 0; t < G; ++t) {
         const int k = g * G + t;
@@ -108,6 +174,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
             }
         }
       }
+      tick(3);                                         // 3: LDS weight fragments + MFMAs
     }
 
     // epilogue (wave-private): acc -> LDS fp32 -> rows as 8-channel vectors
@@ -117,7 +184,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
       for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + nb * 32 + fi] = acc[nb][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    constexpr int VROW = NB * 4;
     for (int e = lane; e < 32 * VROW; e += 64) {
       const int rr = e / VROW, cvv = e % VROW;
       const int64_t orow = (int64_t)tile * 32 + rr;
@@ -129,6 +195,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    tick(4);                                           // 4: epilogue (LDS transposition, residual read, stores issued)
+    if constexpr (TM) tm[5] += 1;
+  }
+  if constexpr (TM) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) atomicAdd(&g_tmd[i], tm[i]);
+    }
   }
 }
 
@@ -206,6 +280,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   }
 }
 
+int g_direct_walk = 0;
+
 template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false>
 int launch(const ConvP& p, hipStream_t s) {
   constexpr int UB = BF16 ? 64 : 128;
@@ -222,7 +298,7 @@ int launch(const ConvP& p, hipStream_t s) {
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT><<<grid, WAVES * 64, lds, s>>>(p, ntiles);
+  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -243,6 +319,7 @@ int dispatch(const ConvP& p, hipStream_t s) {
         case 7: return launch<true, 27, 1, 1, 3, 8>(p, s);
         case 8: return launch<true, 27, 1, 1, 9, 16>(p, s);
         case 9: return launch<true, 27, 1, 1, 1, 16>(p, s);
+        case 10: return launch<true, 27, 1, 1, 3, 16, 16>(p, s);     // segment timers
       }
     }
   }
@@ -250,6 +327,7 @@ int dispatch(const ConvP& p, hipStream_t s) {
   if constexpr (BF16 && K == 27) {
     // column-form rulebook: 32 -> 32 only (measured: 0.243 -> 0.226 ms per conv; the 64 -> 32 shape got slower, 0.39 -> 0.47)
     if (p.ctab && g_direct_abl == 0 && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 0, true>(p, s);
+    if (p.ctab && g_direct_abl == 13 && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 32, true>(p, s);   // rulebook words not requested ahead
   }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \
@@ -264,7 +342,13 @@ int dispatch(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int tl_dev_direct_abl(int mode) { g_direct_abl = mode; return TL_OK; }   // developer hook, not part of the C ABI
+// developer hook, not part of the C ABI: mode 0..99 = ablation variant of the 32->32 kernel, 1000 / 1001 = tile walk of every direct launch
+extern "C" int tl_dev_direct_abl(int mode) { if (mode >= 1000) g_direct_walk = mode - 1000; else g_direct_abl = mode; return TL_OK; }
+extern "C" int tl_dev_direct_tm(unsigned long long* out8) {          // read and clear the segment timers of ablation mode 10
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tmd), sizeof(g_tmd)) != hipSuccess) return TL_ERR_LAUNCH;
+  unsigned long long z[8] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tmd), z, sizeof(z)) == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
 
 // Eligibility (beyond the tile kernel's alignment rules): no gather-side prologue, whole weight tensor + epilogue
 // scratch within LDS, input view below 4 GB.  Returns TL_ERR_UNSUPPORTED when the shape is not covered.
