@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
 // 27 x 4 = 108 -> seven 32x32x16 MFMA steps.  Lane (i, h) of step s holds channels 0..3 of taps 4s+2h and 4s+2h+1 of
 // row i: two 8-byte bounds-checked gathers; the weight fragments (7 x 16 B per lane) live in registers for the whole
 // kernel.  HBM-bound on the 108 B/voxel rulebook read and the output writes.
-template <int WAVES>
+// CT: rulebook in column form (p.ctab), the ten words of the next tile requested while this tile's gathers are in flight.
+template <int WAVES, bool CT = false>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   constexpr int EP = 36;
   __shared__ float Es[WAVES][32][EP];
@@ -232,19 +233,43 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + 8;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
   float* ew = &Es[wv][0][0];
+  [[maybe_unused]] int twn[10];
+  auto load_words = [&](int tile_) __attribute__((always_inline)) {
+    const int64_t row = (int64_t)tile_ * 32 + fi;
+    const bool rvalid = tile_ < ntiles && row < p.n_out;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) twn[k] = rvalid ? p.ctab[(int64_t)k * p.n_out + row] : (k < 9 ? -1 : 0);
+  };
+  if constexpr (CT) load_words(blockIdx.x * WAVES + wv);
   for (int tile = blockIdx.x * WAVES + wv; tile < ntiles; tile += gridDim.x * WAVES) {
     const int64_t row = (int64_t)tile * 32 + fi;
     const bool rvalid = row < p.n_out;
     int idx[14];
+    if constexpr (CT) {
+      auto tap = [&](int k) __attribute__((always_inline)) {          // k is a compile-time constant after unrolling
+        if (k >= 27) return -1;
+        const uint32_t m = ((uint32_t)twn[9] >> (3 * (k / 3))) & 7u;
+        const int d = k % 3;
+        return ((m >> d) & 1u) ? twn[k / 3] + __builtin_popcount(m & ((1u << d) - 1u)) : -1;
+      };
 #pragma unroll
-    for (int q = 0; q < 14; ++q) {
-      const int t = 4 * (q >> 1) + 2 * fh + (q & 1);
-      idx[q] = (rvalid && t < p.K) ? p.table[(int64_t)t * p.n_out + row] : -1;
+      for (int q = 0; q < 14; ++q) {
+        const int t0 = 4 * (q >> 1) + (q & 1);
+        const int a0 = tap(t0), a1 = tap(t0 + 2);
+        idx[q] = fh ? a1 : a0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 14; ++q) {
+        const int t = 4 * (q >> 1) + 2 * fh + (q & 1);
+        idx[q] = (rvalid && t < p.K) ? p.table[(int64_t)t * p.n_out + row] : -1;
+      }
     }
     u32x2 g[14];
 #pragma unroll
     for (int q = 0; q < 14; ++q)
       g[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((unsigned)idx[q] * (unsigned)in_ld_b), 0, 0));
+    if constexpr (CT) load_words(tile + gridDim.x * WAVES);          // after this tile's gathers: no gather wait includes it
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -308,7 +333,7 @@ template <bool BF16, int K, int G>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
   if constexpr (BF16 && K == 27) {
-    if (g_direct_abl && nb == 1 && un == 1) {
+    if (g_direct_abl && g_direct_abl < 14 && nb == 1 && un == 1) {
       switch (g_direct_abl) {
         case 1: return launch<true, 27, 1, 1, 3, 16, 1>(p, s);
         case 2: return launch<true, 27, 1, 1, 3, 16, 2>(p, s);
@@ -325,8 +350,10 @@ int dispatch(const ConvP& p, hipStream_t s) {
   }
   const size_t wbytes = (size_t)K * p.Cout * p.Cin * (BF16 ? 2 : 4);
   if constexpr (BF16 && K == 27) {
-    // column-form rulebook: 32 -> 32 only (measured: 0.243 -> 0.226 ms per conv; the 64 -> 32 shape got slower, 0.39 -> 0.47)
-    if (p.ctab && g_direct_abl == 0 && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 0, true>(p, s);
+    // column-form rulebook (level 1), its words requested one tile ahead: 32 -> 32 0.200 -> 0.195 ms on top of the 0.243 -> 0.226 of
+    // the 40-B form itself; 64 -> 32 0.51 -> 0.33 ms (without the look-ahead the decode in front of its gathers had made it slower)
+    if (p.ctab && (g_direct_abl == 0 || g_direct_abl >= 14) && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 0, true>(p, s);
+    if (p.ctab && g_direct_abl != 14 && nb == 1 && un == 2) return launch<true, 27, 1, 2, G, 8, 0, true>(p, s);
     if (p.ctab && g_direct_abl == 13 && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 32, true>(p, s);   // rulebook words not requested ahead
   }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
@@ -359,7 +386,8 @@ int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s) {
     const int ntiles = (int)tl_cdiv(p.n_out, 32);
     int grid = (int)tl_cdiv(ntiles, 8);
     if (grid > 2048) grid = 2048;
-    k_conv_in4<8><<<grid, 512, 0, s>>>(p, ntiles);
+    if (p.ctab && p.K == 27 && g_direct_abl != 15) k_conv_in4<8, true><<<grid, 512, 0, s>>>(p, ntiles);
+    else k_conv_in4<8><<<grid, 512, 0, s>>>(p, ntiles);
     return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
   }
   if (p.Cin % 32 || p.Cout % 32) return TL_ERR_UNSUPPORTED;
