@@ -1,7 +1,7 @@
 # Collect the per-round profile set on the GPU box (run through gpurun: `gpurun -- bash tools/profile_round.sh`), then
-# `python tools/summarize_profile.py gpurun_out/prof_v7 profiles/<tag>` here.
+# `python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<tag>` here (tag = first argument, default v8).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_v7; mkdir -p $O
+O=gpurun_out/prof_${1:-v8}; mkdir -p $O
 python bench.py > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-mode --no-power-probe > $O/bench_line.json 2> $O/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-power-probe > /dev/null 2> $O/fetch.err
