@@ -127,12 +127,13 @@ def pmc_traffic(dtype, workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
+    ap.add_argument("--tiles-in-flight", type=int, default=3, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
@@ -171,18 +172,26 @@ def main():
         with torch.no_grad():
             return model(gbatch, return_loss=False)
 
+    # Tiles in flight: consecutive steps (independent tiles) go to NF streams round-robin, so the stretches of one forward that
+    # leave most CUs idle (36 small launches of the deep levels, geometry kernels + their two host syncs) are filled by the big
+    # convs of the neighbouring steps -- what the production tile loop (util/pipeline.get_pointwise_preds) does.  Every step still
+    # does all of its work inside the timed region; `value` is throughput.  --tiles-in-flight 1 gives the one-after-the-other time.
+    nfl = max(1, args.tiles_in_flight)
+    streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else []
+
     def run_steps(k):
-        """k tiles through the two-phase tile loop: voxel hashing + rulebooks of tile i+1 (side stream) overlap the
-        convs of tile i; every tile still does ALL of its work (k prepares + k infers) inside the timed region."""
-        if os.environ.get("TL_BENCH_PIPELINE", "0") == "0":        # A/B on MI355X: the GPU is already saturated by the convs, the sequential form is ~1 % faster
+        if not streams:
             for _ in range(k):
                 out = step()
             return out
-        h = model.prepare(gbatch)
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
         for i in range(k):
-            out = model.infer(h)
-            if i + 1 < k:
-                h = model.prepare(gbatch)
+            with torch.cuda.stream(streams[i % nfl]):
+                out = step()
+        for st in streams:
+            cur.wait_stream(st)
         return out
 
     run_steps(max(args.warmup, 1))
@@ -244,8 +253,15 @@ def main():
                    dtype=args.dtype, data="synthetic",
                    config=dict(workload=f"{args.workload}: single {cfg['extent']:.0f}x{cfg['extent']:.0f} m tile, voxel {cfg['voxel']} m, "
                                         f"{n_pts} points/tile, 7-level 32-ch sparse U-Net fwd (30.1 M params, random init), 1 tile per GPU",
-                               points_per_tile=n_pts, tiles_per_step=world),
+                               points_per_tile=n_pts, tiles_per_step=world, tiles_in_flight=nfl),
                    roofline=roof)
+        if nfl > 1:                                                    # the same forward strictly one tile after the other, for reference
+            with torch.no_grad():
+                for _ in range(2): step()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(8): step()
+                torch.cuda.synchronize(); d1 = (time.perf_counter() - t1) / 8
+            res["one_tile_at_a_time"] = dict(value=n_pts / d1 / 1e6, unit="Mpoints/s", ms_per_step=d1 * 1e3)
         if world == 1 and args.dtype == "bf16" and not args.no_fp32_mode:
             # the fp32 parity mode (the precision the 1e-3 parity gate is checked in), same tile, for reference
             m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype=torch.float32)
