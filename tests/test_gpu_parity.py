@@ -262,6 +262,36 @@ def test_conv_fwd_bf16_vs_oracle(cin, cout, K, n_out):
     assert rel_err(out.float().cpu().numpy(), ref) < 8e-3          # one bf16 rounding of the output (2^-8)
 
 
+@pytest.mark.parametrize("device_tiles", [False, True])
+def test_tile_loop_same_results_with_tiles_in_flight(device_tiles, monkeypatch):
+    """The production tile loop with 1 / 2 / 3 tiles in flight (compute streams round-robin, read-back on its own stream) over
+    tiles of unequal size returns exactly the same arrays and per-tile row counts, both through numpy and left on the device --
+    nothing may depend on which stream a tile ran on or on when its buffers were recycled."""
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.util import get_pointwise_preds
+    tiles = []
+    for s_, ext in enumerate((14.0, 9.0, 16.0, 11.0, 13.0, 8.0, 15.0)):
+        t = make_tile(extent=ext, voxel=0.1, n_trees=4 + s_, fill=0.08, seed=20 + s_)
+        t["center"] = np.array([3.0 * s_, 0.0, 0.0])
+        b = make_batch([t], inner_square_edge_length=6.0)
+        tiles.append({k: (v.cuda() if (device_tiles and torch.is_tensor(v)) else v) for k, v in b.items()})
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
+    model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+    ref = None
+    for nf in ("1", "3", "2", "3"):
+        monkeypatch.setenv("TL_TILES_IN_FLIGHT", nf)
+        for keep in (False, True):
+            res, rows = get_pointwise_preds(model, tiles, dict(voxel_size=0.1), return_tile_rows=True, keep_on_device=keep)
+            res = [r.cpu().numpy() if torch.is_tensor(r) else r for r in res]
+            if ref is None:
+                ref = (res, rows)
+                assert len(rows) == len(tiles) and sum(n for _, n in rows) == len(res[0]) > 0
+                continue
+            assert rows == ref[1], (nf, keep)
+            for a, b_ in zip(res, ref[0]):
+                np.testing.assert_array_equal(a, b_, err_msg=f"tiles in flight {nf}, keep_on_device {keep}")
+
+
 def test_forward_bf16_close_to_fp32():
     """Throughput mode (bf16 features/weights, fp32 accumulate) stays close to the fp32 parity path."""
     from treelearn_amd.model import TreeLearn

@@ -68,11 +68,13 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
         if done is not None:
             with torch.cuda.stream(rb_stream):
                 rb_stream.wait_event(done)
-                return _read_back(batch, gbatch, output)
+                return _read_back(batch, gbatch, output, True)
         return _read_back(batch, gbatch, output)
 
-    def _read_back(batch, gbatch, output):
+    def _read_back(batch, gbatch, output, done_on_other_stream=False):
         dev = output['offset_predictions'].device
+        if done_on_other_stream and gbatch['masks_inner'].is_cuda:
+            gbatch['masks_inner'].record_stream(torch.cuda.current_stream())
         idx = torch.nonzero(gbatch['masks_inner'].to(dev)).squeeze(1)          # one small sync; 4-5 % of the rows survive
         ci = None
 
@@ -80,6 +82,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             """Inner rows of a per-point array: gathered on the device if it lives there, else on the host."""
             nonlocal ci
             if t.is_cuda:
+                if done_on_other_stream:
+                    t.record_stream(torch.cuda.current_stream())       # allocated on a compute stream, read here on the read-back stream
                 return t.index_select(0, idx)
             if ci is None:
                 ci = idx.cpu()
@@ -135,6 +139,10 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                 cs.wait_stream(main_stream)                            # inputs produced on the caller's stream are visible
             try:
                 with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
+                    if cs is not None:                                 # inputs allocated on the copy / tiler / caller's stream, consumed on this one
+                        for v in gbatch.values():
+                            if torch.is_tensor(v) and v.is_cuda:
+                                v.record_stream(cs)
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                     if gbatch.get('_ready_event') is not None:          # device-resident tile produced on another stream (PlotTiler)
