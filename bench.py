@@ -194,6 +194,7 @@ def main():
             cur.wait_stream(st)
         return out
 
+    step(); torch.cuda.synchronize()                                   # builds the inference plan (packed weights) before steps spread over streams
     run_steps(max(args.warmup, 1))
     torch.cuda.synchronize()
     if dist: dist.barrier()

@@ -278,7 +278,7 @@ def test_tile_loop_same_results_with_tiles_in_flight(device_tiles, monkeypatch):
     model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
     model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
     ref = None
-    for nf in ("1", "3", "2", "3"):
+    for nf in ("3", "1", "2", "3"):          # three in flight first: the fresh model's plan (packed weights) must be ready for every stream
         monkeypatch.setenv("TL_TILES_IN_FLIGHT", nf)
         for keep in (False, True):
             res, rows = get_pointwise_preds(model, tiles, dict(voxel_size=0.1), return_tile_rows=True, keep_on_device=keep)

@@ -58,6 +58,14 @@ class TreeLearn(nn.Module):
             elif isinstance(m, MLP):
                 m.init_weights()
 
+    def ensure_plan(self):
+        """Build the fused inference plan (folded BatchNorms, packed weights) now, on the current stream.  Callers that spread
+        forwards over several streams do this first: the plan is otherwise built by the first forward, on that forward's stream,
+        and a forward on another stream could read weights that are still being packed."""
+        if not self.training and (self._plan is None or self._plan.dtype != self.compute_dtype):
+            self._plan = InferencePlan(self, self.compute_dtype)
+        return self
+
     def invalidate_plan(self):
         """Drop the folded-BN / packed-weight cache (call after mutating parameters in place)."""
         self._plan = None

@@ -123,6 +123,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     cstreams = _compute_streams(nf) if (use_gpu and nf > 1) else []
     with torch.no_grad():
         model.eval()
+        if cstreams and hasattr(model, "ensure_plan"):
+            model.ensure_plan()                                        # on the caller's stream, which every compute stream waits for
         it = iter(dataloader)
         nxt = next(it, None)
         staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
