@@ -280,9 +280,17 @@ def main():
                 res["power"] = dict(pw, note="rocm-smi sample while the same forward loops for 2.5 s (untimed)")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
     if dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise come
+        # out at exit, after the result: flush it first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                    # noqa: BLE001
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
