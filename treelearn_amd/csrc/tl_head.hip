@@ -6,6 +6,8 @@
 #include "tl_common.h"
 #include <hip/hip_bf16.h>
 
+int g_head_mode = 0;      // developer A/B (tl_set_tuning "head_mode"): 1 = the scalar-weight kernel also for bf16 C = 32
+
 namespace {
 
 template <int C, typename T>
@@ -58,10 +60,131 @@ __global__ void __launch_bounds__(256) k_head(const T* __restrict__ feats, int64
   }
 }
 
+// bf16 features, C = 32 (the production shape): both hidden layers on the matrix cores.  The scalar-weight kernel above is
+// VALU-bound (2 112 FMAs per point: 130 us of its 160 us on the config-2 tile); here a wave takes 32 points at a time and computes
+// H^T = W1 X^T with 32x32x16 bf16 MFMAs -- A = the hidden layer's weights (hidden unit x channel, constant fragments in
+// registers), B = the points' BatchNorm+ReLU'd feature rows (point x channel: lane (n, h) gathers 16-byte pieces h and 2 + h of
+// row v2p[n]) -- so that afterwards lane (n, h) holds 16 hidden units of point n; the output layer is 16 FMAs per output on
+// those, and one cross-half add.  Activations and W1 are rounded to bf16 for the MFMA (the backbone output stays fp32).
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef float hf32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t hu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t head_pack_bf16x2(float lo, float hi) {      // round-to-nearest-even
+  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+  a += 0x7FFFu + ((a >> 16) & 1u);
+  b += 0x7FFFu + ((b >> 16) & 1u);
+  return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+__global__ void __launch_bounds__(256) k_head_mfma32(const __hip_bfloat16* __restrict__ feats, int64_t ld, const int64_t* __restrict__ v2p, int64_t N,
+                                                     const float* __restrict__ psc, const float* __restrict__ psh,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ backbone, float* __restrict__ logits, float* __restrict__ offsets) {
+  constexpr int C = 32;
+  __shared__ float4 Tb[2][2][16];                            // [h][head][r] = {b1[j], w2[k0][j], w2[k1][j], w2[k2][j]}, j = (r&3) + 8 (r>>2) + 4 h
+  __shared__ float4 Fs[4][32][9];                            // per wave: the tile's fp32 rows, [point][8 float4 + 1 pad], for whole-row stores
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  for (int e = threadIdx.x; e < 64; e += 256) {
+    const int hh_ = e >> 5, r = e & 15, h_ = (e >> 4) & 1;
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * h_;
+    Tb[h_][hh_][r] = hh_ == 0 ? make_float4(b1[j], w2[0 * C + j], w2[1 * C + j], 0.f)
+                              : make_float4(b1[C + j], w2[2 * C + j], w2[3 * C + j], w2[4 * C + j]);
+  }
+  // A fragments: lane (m = hidden unit, h) of k-step s holds W1[head][m][16 s + 8 h .. + 8]
+  hu32x4 afrag[2][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float* wr = w1 + ((int64_t)hh * C + n) * C + 16 * s + 8 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) afrag[hh][s][q] = head_pack_bf16x2(wr[2 * q], wr[2 * q + 1]);
+    }
+  // the lane's 16 channels (16 s + 8 h + q) of the output_layer affine
+  float sc[2][8], sh[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sc[s][q] = psc ? psc[16 * s + 8 * h + q] : 1.f; sh[s][q] = psc ? psh[16 * s + 8 * h + q] : 0.f; }
+  const float bo0 = b2[0], bo1 = b2[1], bo2 = b2[2], bo3 = b2[3], bo4 = b2[4];
+  __syncthreads();
+
+  const int64_t ntiles = (N + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    const int64_t p = tile * 32 + n;
+    const bool pv = p < N;
+    const int64_t row = pv ? v2p[p] : 0;
+    const uint4* src = reinterpret_cast<const uint4*>(feats + row * ld + 8 * h);
+    hu32x4 bfrag[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint4 v = src[2 * s];                            // channels 16 s + 8 h .. + 8
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      float f[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(u[q] << 16); f[2 * q + 1] = __uint_as_float(u[q] & 0xFFFF0000u); }
+      if (psc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = fmaxf(fmaf(f[q], sc[s][q], sh[s][q]), 0.f);
+      }
+      if (backbone) {
+        float4* fs = &Fs[threadIdx.x >> 6][n][4 * s + 2 * h];
+        fs[0] = make_float4(f[0], f[1], f[2], f[3]); fs[1] = make_float4(f[4], f[5], f[6], f[7]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bfrag[s][q] = head_pack_bf16x2(f[2 * q], f[2 * q + 1]);
+    }
+    if (backbone) {                                          // eight lanes write one point's 128 B: every store instruction covers 8 whole rows
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = 8 * i + (lane >> 3), sl = lane & 7;
+        const int64_t q = tile * 32 + rr;
+        if (q < N) reinterpret_cast<float4*>(backbone + q * C)[sl] = Fs[threadIdx.x >> 6][rr][sl];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f, y4 = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      hf32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, afrag[hh][s]), __builtin_bit_cast(hbf16x8, bfrag[s]), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 t = Tb[h][hh][r];
+        const float hv = fmaxf(acc[r] + t.x, 0.f);
+        if (hh == 0) { y0 = fmaf(t.y, hv, y0); y1 = fmaf(t.z, hv, y1); }
+        else { y2 = fmaf(t.y, hv, y2); y3 = fmaf(t.z, hv, y3); y4 = fmaf(t.w, hv, y4); }
+      }
+    }
+    y0 += __shfl_xor(y0, 32); y1 += __shfl_xor(y1, 32); y2 += __shfl_xor(y2, 32); y3 += __shfl_xor(y3, 32); y4 += __shfl_xor(y4, 32);
+    if (pv) {
+      if (h == 0) { logits[p * 2] = y0 + bo0; logits[p * 2 + 1] = y1 + bo1; }
+      else { offsets[p * 3] = y2 + bo2; offsets[p * 3 + 1] = y3 + bo3; offsets[p * 3 + 2] = y4 + bo4; }
+    }
+  }
+}
+
 template <int C>
 int launch_head(const void* feats, int64_t ld, int dtype, const int64_t* v2p, int64_t N, const float* psc, const float* psh,
                 const float* w1, const float* b1, const float* w2, const float* b2, float* bb, float* lg, float* of, hipStream_t s) {
   const unsigned g = tl_grid(N, 256);
+  if constexpr (C == 32) {
+    if (dtype == TL_BF16 && g_head_mode != 1) {
+      const int64_t need = tl_cdiv(tl_cdiv(N, 32), 4);
+      k_head_mfma32<<<(unsigned)(need < 2048 ? need : 2048), 256, 0, s>>>((const __hip_bfloat16*)feats, ld, v2p, N, psc, psh, w1, b1, w2, b2, bb, lg, of);
+      return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+    }
+  }
   if (dtype == TL_F32) k_head<C, float><<<g, 256, 0, s>>>((const float*)feats, ld, v2p, N, psc, psh, w1, b1, w2, b2, bb, lg, of);
   else k_head<C, __hip_bfloat16><<<g, 256, 0, s>>>((const __hip_bfloat16*)feats, ld, v2p, N, psc, psh, w1, b1, w2, b2, bb, lg, of);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
