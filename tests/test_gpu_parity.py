@@ -292,6 +292,36 @@ def test_tile_loop_same_results_with_tiles_in_flight(device_tiles, monkeypatch):
                 np.testing.assert_array_equal(a, b_, err_msg=f"tiles in flight {nf}, keep_on_device {keep}")
 
 
+@pytest.mark.parametrize("n_pts", [1, 31, 32, 33, 4097, 70001])
+def test_head_kernels_vs_torch(n_pts):
+    """tl_head_mlp (v2p gather + output_layer BN/ReLU + both MLPs, tree_learn.py:93-103, blocks.py:8-26) against plain torch fp32:
+    the fp32 kernel to 1e-5, the bf16 C = 32 kernel (hidden layers on bf16 MFMAs) to bf16 accuracy; the optional backbone
+    output is the fp32 relu(bn(x)) of the gathered row in both; ragged point counts around the 32-point MFMA tile."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(n_pts)
+    M, C = max(n_pts // 3, 5), 32
+    x = torch.from_numpy(rng.normal(size=(M, C)).astype(np.float32)).cuda()
+    v2p = torch.from_numpy(rng.integers(0, M, size=n_pts)).cuda()
+    so = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda(); ho = torch.from_numpy(rng.normal(0, 0.2, C).astype(np.float32)).cuda()
+    w1 = torch.from_numpy((rng.normal(size=(2, C, C)) / np.sqrt(C)).astype(np.float32)).cuda(); b1 = torch.from_numpy(rng.normal(0, 0.1, (2, C)).astype(np.float32)).cuda()
+    w2 = torch.from_numpy((rng.normal(size=(5, C)) / np.sqrt(C)).astype(np.float32)).cuda(); b2 = torch.from_numpy(rng.normal(0, 0.1, 5).astype(np.float32)).cuda()
+
+    def ref(xf):
+        f = torch.relu(xf[v2p] * so + ho)
+        h0 = torch.relu(f @ w1[0].T + b1[0]); h1 = torch.relu(f @ w1[1].T + b1[1])
+        return f, h0 @ w2[:2].T + b2[:2], h1 @ w2[2:].T + b2[2:]
+
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)):
+        xin = x.to(dt)
+        f, lg, of = ref(xin.float())
+        bb, lo, off = ops.head_mlp(xin, v2p, so, ho, w1, b1, w2, b2, True)
+        assert torch.allclose(bb, f, rtol=1e-6, atol=1e-6)          # one fma + max per element (torch rounds the product first)
+        scale = float(torch.cat([lg, of], 1).abs().max()) + 1e-6
+        assert float((lo - lg).abs().max()) / scale < tol and float((off - of).abs().max()) / scale < tol, dt
+        _, lo2, off2 = ops.head_mlp(xin, v2p, so, ho, w1, b1, w2, b2, False)
+        assert torch.equal(lo2, lo) and torch.equal(off2, off)
+
+
 def test_forward_bf16_close_to_fp32():
     """Throughput mode (bf16 features/weights, fp32 accumulate) stays close to the fp32 parity path."""
     from treelearn_amd.model import TreeLearn
