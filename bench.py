@@ -3,8 +3,12 @@
 (BASELINE.json configs[1]).  One step = model(batch, return_loss=False) on one tile whose points are
 already resident in HBM: voxel hashing, all 13 rulebooks, 65 sparse convs, heads.
 
-    python bench.py --gpus 1 --steps K --warmup W [--dtype bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--workload config2|config4|config5]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) this process only SPAWNS the N ranks
+(`python -m torch.distributed.run`, a child process -- the parent never touches the GPU), relays rank 0's
+JSON line and exits with the children's status.
 
 Multi-GPU: tiles are independent -> every rank runs its own tile, no data-path
 collective; weak scaling; value = points processed by all ranks / max-over-ranks time.
@@ -124,6 +128,63 @@ def pmc_traffic(dtype, workload):
     return best
 
 
+def sharded_plot(model, dist, rank, world, n_tiles, steps, warmup):
+    """BASELINE config 4: `n_tiles` overlapping-tile forwards of one plot sharded over the ranks (round-robin = LPT on equal
+    tiles), every rank materialising only its own tiles, inputs resident in HBM; one step = the whole plot through
+    util.sharding.get_pointwise_preds_sharded: per-rank tile loop (inner-square filter on the device) + the two collectives of
+    the record gather INSIDE the timed region.  Returns (seconds per plot (max over ranks), total points, gathered rows)."""
+    from treelearn_amd.synth import CONFIGS, make_batch, plot_tiles
+    from treelearn_amd.util.sharding import TileList, assign_tiles, get_pointwise_preds_sharded
+    mine = assign_tiles([1] * n_tiles, world)[rank]
+    cache = {}
+    batches = {}
+    for i in mine:
+        b = make_batch(plot_tiles([i], CONFIGS["config2"], cache))
+        batches[i] = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    npts = torch.zeros(n_tiles, dtype=torch.int64, device="cuda")
+    for i in mine:
+        npts[i] = batches[i]["coords"].shape[0]
+    dist.all_reduce(npts)                                                # setup only (point counts for the metric), not timed
+    src = TileList([1] * n_tiles, lambda i: batches[i])
+    run = lambda: get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True)     # noqa: E731
+    for _ in range(max(warmup, 1)):
+        out = run()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = run()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    return float(dt) / steps, int(npts.sum()), int(out[0].shape[0])
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (fresh processes;
+    this parent never initialises the GPU and never re-execs), relay their output, print rank 0's JSON line last."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                                     # device_count() does not create a HIP context
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node; one GPU per rank is required "
+              f"(ranks never share a device).  Run with --gpus {max(have, 1)} or on a node with {n} GPUs.", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln)
+    if js:
+        print(js[-1], flush=True)
+    return r.returncode if (r.returncode or js) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,27 +195,56 @@ def main():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
     ap.add_argument("--tiles-in-flight", type=int, default=3, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
-    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config5"])
+    ap.add_argument("--plot-tiles", type=int, default=64, help="config4: tiles of the plot")
+    ap.add_argument("--no-sharded-plot", action="store_true", help="N > 1: skip the config-4 sharded tile loop + gather measurement")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker()), flush=True)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                                 # parent: no GPU call before or after this line
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.set_num_threads(max(1, host_cores() // int(os.environ.get("LOCAL_WORLD_SIZE", world))))     # ranks share the host-core quota
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if torch.cuda.device_count() <= local:                               # counting devices does not initialise the GPU
+        sys.exit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible (one GPU per rank, no sharing)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("TL_BENCH_FORCE_DIST") == "1":          # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
-    from oracle import model as om                                    # only for the deterministic random weights
     from treelearn_amd import ops
     from treelearn_amd.model import TreeLearn
-    from treelearn_amd.synth import CONFIGS, make_batch, make_tile
+    from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
+
+    if args.workload == "config4":
+        if dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1,
+                          compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+        model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
+        model = model.cuda().eval()
+        sec, total_pts, rows = sharded_plot(model, dist, rank, world, args.plot_tiles, args.steps, args.warmup)
+        if rank == 0:
+            res = dict(metric="Mpoints/sec through sparse U-Net fwd (0.1 m voxel, 40x40 m tile)", value=total_pts / sec / 1e6, unit="Mpoints/s",
+                       n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, higher_is_better=True, scaling="strong",
+                       vs_baseline=None, dtype=args.dtype, data="synthetic",
+                       config=dict(workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares) sharded "
+                                            f"round-robin over {world} GPU(s), device-resident record gather (2 collectives) inside the timed region",
+                                   tiles=args.plot_tiles, total_points=total_pts, gathered_rows=rows, ms_per_tile=sec * 1e3 / args.plot_tiles * world),
+                       roofline=None, cpu_baseline=None)
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        return
 
     cfg = CONFIGS[args.workload]
     tile = make_tile(**cfg, seed=rank)                                 # every rank its own tile
@@ -163,7 +253,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000] if cfg["voxel"] >= 0.1 else None,
                       voxel_size=cfg["voxel"], compute_dtype=dtype)
-    model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7), strict=True)
+    model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
     model = model.cuda().eval()
     model.return_backbone_feats = True
     gbatch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}     # inputs resident in HBM
@@ -280,6 +370,14 @@ def main():
                 res["power"] = dict(pw, note="rocm-smi sample while the same forward loops for 2.5 s (untimed)")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+            res["config"]["cpu_baseline_sample"] = "26x26 m tile of the same generator / voxel size / model (about 40 % of the points of the timed tile), 1 forward"
+    if dist and world > 1 and args.workload == "config2" and not args.no_sharded_plot:
+        # BASELINE config 4 alongside: 8 tiles per rank through the sharded tile loop WITH the record gather timed (weak form of the
+        # 64-tiles-on-8-GPUs plot; `--workload config4` times the fixed 64-tile plot instead)
+        sec, tp, rows = sharded_plot(model, dist, rank, world, 8 * world, 2, 1)
+        if rank == 0:
+            res["sharded_plot"] = dict(value=tp / sec / 1e6, unit="Mpoints/s", tiles=8 * world, ms_per_plot=sec * 1e3, gathered_rows=rows,
+                                       collectives_per_plot=2, note="tile loop + inner-square filter + device-resident record gather, timed together")
     if dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -860,3 +860,31 @@ def test_forward_fuzz_small_tiles_vs_oracle(seed):
     for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
         assert np.isfinite(out[k].cpu().numpy()).all()
         assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, (k, len(batch["coords"]))
+
+
+def test_handwritten_known_answers_through_the_hip_path():
+    """The hand-written spconv known-answer vectors (tests/golden/kat_spconv_handwritten.json; pencil arithmetic, no repo code)
+    through the real HIP chain: voxel hashing -> rulebooks -> tl_conv_fwd, fp32 exact and bf16 within its rounding."""
+    from kat_cases import build_weight, case_points, load_cases
+    from treelearn_amd import ops
+    d = _dev()
+    for case in load_cases():
+        pts, bids = case_points(case)
+        B = int(bids.max()) + 1
+        g = _geom(pts, bids, B, 1.0, 1 if case["kind"] == "subm" else 2, list(case["shape"]))
+        w = torch.from_numpy(build_weight(case)).to(d)
+        lv = g.levels[0]
+        for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 8e-3)):
+            wp = ops.pack_weight(w, dt)
+            if case["kind"] == "subm":
+                out = ops.conv_fwd(torch.tensor(case["feats"], device=d).to(dt), wp, lv.nbr, lv.n)
+            elif case["kind"] == "down":
+                np.testing.assert_array_equal(g.levels[1].coords.cpu().numpy(), np.asarray(case["expect_coords"]), err_msg=case["name"])
+                out = ops.conv_fwd(torch.tensor(case["feats"], device=d).to(dt), wp, lv.child, g.levels[1].n)
+            else:
+                out = ops.conv_fwd(torch.tensor(case["coarse_feats"], device=d).to(dt), wp, lv.inv, lv.n, one_hot=True)
+            got = out.float().cpu().numpy(); want = np.asarray(case["expect"], np.float32)
+            if tol == 0.0:
+                np.testing.assert_array_equal(got, want, err_msg=case["name"])
+            else:
+                assert np.abs(got - want).max() <= tol * np.abs(want).max(), (case["name"], got, want)

@@ -119,9 +119,37 @@ def tiles():
     for i in range(3):
         b = {k: torch.from_numpy(g[f"t{i}_{k}"]) for k in keys}; b["batch_size"] = 1; out.append(b)
     return out
+# count the collectives the sharded loop issues (SURVEY 8e: one count gather + one payload gather)
+calls = []
+for name in ("all_gather_into_tensor", "all_gather", "broadcast", "all_reduce"):
+    orig = getattr(dist, name)
+    setattr(dist, name, (lambda o, n: (lambda *a, **k: (calls.append(n), o(*a, **k))[1]))(orig, name))
 res = get_pointwise_preds_sharded(Fake(), tiles(), dict(voxel_size=0.2), device=torch.device("cpu"))
+assert calls == ["all_gather_into_tensor"] * 2, calls
 for i, r in enumerate(res):
     np.testing.assert_allclose(r, g[f"out{i}"], rtol=1e-6, atol=1e-6)
+    assert r.dtype == g[f"out{i}"].dtype, (i, r.dtype, g[f"out{i}"].dtype)
+# lazy source: a rank materialises only its own tiles
+from treelearn_amd.util.sharding import TileList, assign_tiles, segment_plot_sharded
+made = []
+tl = tiles()
+src = TileList([t["coords"].shape[0] for t in tl], lambda i: (made.append(i), tl[i])[1])
+res2 = get_pointwise_preds_sharded(Fake(), src, dict(voxel_size=0.2), device=torch.device("cpu"))
+assert sorted(made) == assign_tiles(src.n_points, dist.get_world_size())[dist.get_rank()], made
+for a, b in zip(res, res2):
+    np.testing.assert_array_equal(a, b)
+# whole-plot order of operations (tile loop -> gather -> ensemble -> grouping on rank 0 -> id broadcast) with CPU stand-ins
+def ens(coords, sem, seml, off, offl, instl, bb, infeat):
+    return tuple(np.asarray(x) for x in (coords, sem, seml, off, offl, instl, bb, infeat))
+def inst_fn(coords, off, sem, cfg, vert, tree_class, non_trees, not_assigned, start):
+    assert dist.get_rank() == 0
+    return (np.arange(len(coords)) % 5).astype(np.int64)
+calls.clear()
+c, ids = segment_plot_sharded(Fake(), tiles(), dict(voxel_size=0.2), {}, device=torch.device("cpu"), ensemble_fn=ens, instances_fn=inst_fn,
+                              fill_fn=lambda c, p, na: p)
+assert calls == ["all_gather_into_tensor", "all_gather_into_tensor", "broadcast"], calls
+np.testing.assert_array_equal(ids, np.arange(len(res[0])) % 5)
+np.testing.assert_allclose(c, g["out4"], rtol=1e-6, atol=1e-6)
 print("rank", dist.get_rank(), "ok")
 dist.destroy_process_group()
 '''

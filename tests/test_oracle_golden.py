@@ -118,3 +118,31 @@ def test_g11_tiles_oracle_matches_reference(golden_dir):
         for k in keys:
             ref = g[f"tile{i}_{k}"]
             assert res[i][k].dtype == ref.dtype and np.array_equal(res[i][k], ref), (i, k)
+
+
+def test_oracle_vs_handwritten_known_answers():
+    """The oracle's sparse-conv conventions (tap orientation, [Cout,kx,ky,kz,Cin] layout, odd-extent drop, un-flipped inverse)
+    against vectors written by hand from spconv's documented behaviour -- not produced by any code in this repo."""
+    import torch
+    from oracle import sparse_ops as osp
+    from oracle import voxel as ov
+    from kat_cases import build_weight, case_points, load_cases
+    for case in load_cases():
+        pts, bids = case_points(case)
+        B = int(bids.max()) + 1
+        _, vc, _, _ = ov.voxelize(pts, np.zeros((len(pts), 1), np.float32), bids, B, 1.0)
+        vc = np.asarray(vc)
+        mins = np.stack([np.asarray(case["coords"])[np.asarray(case["coords"])[:, 0] == b][:, 1:].min(0) for b in range(B)])
+        want = np.asarray(case["coords"]).copy(); want[:, 1:] -= mins[want[:, 0]]           # voxelize shifts every batch element to its minimum
+        np.testing.assert_array_equal(vc, want, err_msg=case["name"])
+        w = torch.from_numpy(build_weight(case))
+        if case["kind"] == "subm":
+            out = osp.conv_table(torch.tensor(case["feats"]), w, ov.rulebook_subm(vc))
+        elif case["kind"] == "down":
+            cc, parent, child, _ = ov.rulebook_down(vc, case["shape"])
+            np.testing.assert_array_equal(cc, np.asarray(case["expect_coords"]), err_msg=case["name"])
+            out = osp.conv_table(torch.tensor(case["feats"]), w, child)
+        else:
+            cc, parent, child, _ = ov.rulebook_down(vc, case["shape"])
+            out = osp.inverse_conv(torch.tensor(case["coarse_feats"]), w, parent, vc)
+        np.testing.assert_array_equal(out.numpy(), np.asarray(case["expect"], np.float32), err_msg=case["name"])

@@ -68,6 +68,40 @@ def make_tile(extent=40.0, voxel=0.1, n_trees=64, fill=0.10, seed=0):
                 instance_label=l.astype(np.int32), center=np.zeros(3, np.float64))
 
 
+def tile_variant(tile, sym):
+    """One of the 8 symmetries of the square applied to a tile (sym & 1: swap x/y, sym & 2: mirror x, sym & 4: mirror y).
+    Gives 8 geometrically distinct tiles per generated tile at memcpy cost: the 64 tiles of BASELINE config 4 are the
+    8 symmetries of seeds 0..7 (`plot_tiles`)."""
+    p = tile["points"].copy()
+    if sym & 1:
+        p[:, [0, 1]] = p[:, [1, 0]]
+    if sym & 2:
+        p[:, 0] = -p[:, 0]
+    if sym & 4:
+        p[:, 1] = -p[:, 1]
+    out = dict(tile); out["points"] = np.ascontiguousarray(p)
+    return out
+
+
+def plot_tile_ids(n_tiles=64):
+    """(seed, symmetry) of tile i of the config-4 plot: tile i = symmetry i // 8 of generator seed i % 8 (so a round-robin
+    shard over 2 / 4 / 8 ranks needs only 4 / 2 / 1 generated seeds per rank)."""
+    return [(i % 8, i // 8) for i in range(n_tiles)]
+
+
+def plot_tiles(indices, cfg=None, cache=None):
+    """The config-4 tiles with the given indices (only these are generated -- a rank builds only its own tiles)."""
+    cfg = cfg or CONFIGS["config2"]
+    cache = {} if cache is None else cache
+    out = []
+    for i in indices:
+        seed, sym = i % 8, i // 8
+        if seed not in cache:
+            cache[seed] = make_tile(**cfg, seed=seed)
+        out.append(tile_variant(cache[seed], sym))
+    return out
+
+
 def make_batch(tiles, inner_square_edge_length=8.0):
     """Collate tiles into the reference's batch dict (dataset.py:167-226), CPU numpy->torch.
 
@@ -100,3 +134,64 @@ def make_batch(tiles, inner_square_edge_length=8.0):
         "masks_inner": cat(m_in).bool(), "masks_off": cat(m_off).bool(), "masks_sem": cat(m_sem).bool(),
         "offset_labels": cat(offl).float(), "batch_size": len(tiles), "centers": cat(cen).float(),
     }
+
+
+# ---------------------------------------------------------------- synthetic weights (random init of the reference architecture)
+def state_dict_manifest(channels=32, num_blocks=7, dim_coord=3, dim_feat=1, kernel_size=3):
+    """(key, shape) list in the reference's registration order."""
+    m = []
+    def bn(p, c):
+        m.extend([(p + ".weight", (c,)), (p + ".bias", (c,)), (p + ".running_mean", (c,)),
+                  (p + ".running_var", (c,)), (p + ".num_batches_tracked", ())])
+    k = kernel_size
+    m.append(("input_conv.0.weight", (channels, k, k, k, dim_coord + dim_feat)))
+    planes = [channels * (i + 1) for i in range(num_blocks)]
+    def resblock(p, cin, cout):
+        if cin != cout:
+            m.append((p + ".i_branch.0.weight", (cout, 1, 1, 1, cin)))
+        bn(p + ".conv_branch.0", cin)
+        m.append((p + ".conv_branch.2.weight", (cout, k, k, k, cin)))
+        bn(p + ".conv_branch.3", cout)
+        m.append((p + ".conv_branch.5.weight", (cout, k, k, k, cout)))
+    def ub(p, pl):
+        for i in range(2):
+            resblock(f"{p}.blocks.block{i}", pl[0], pl[0])
+        if len(pl) > 1:
+            bn(p + ".conv.0", pl[0]); m.append((p + ".conv.2.weight", (pl[1], 2, 2, 2, pl[0])))
+            ub(p + ".u", pl[1:])
+            bn(p + ".deconv.0", pl[1]); m.append((p + ".deconv.2.weight", (pl[0], 2, 2, 2, pl[1])))
+            for i in range(2):
+                resblock(f"{p}.blocks_tail.block{i}", pl[0] * (2 - i), pl[0])
+    ub("unet", planes)
+    bn("output_layer.0", channels)
+    for name, co in (("semantic_linear", 2), ("offset_linear", 3)):
+        m.append((name + ".0.weight", (channels, channels))); m.append((name + ".0.bias", (channels,)))
+        bn(name + ".1", channels)
+        m.append((name + ".3.weight", (co, channels))); m.append((name + ".3.bias", (co,)))
+    return m
+
+
+def random_state_dict(seed, **cfg):
+    """Deterministic non-trivial weights/BN statistics, generated key by key from a numpy
+    Generator so tests and the golden script agree without storing 30 M parameters."""
+    import torch
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for key, shape in state_dict_manifest(**cfg):
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.tensor(7, dtype=torch.long); continue
+        if key.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif key.endswith("running_mean"):
+            v = rng.normal(0, 0.2, shape)
+        elif key.endswith(".bias"):
+            v = rng.normal(0, 0.1, shape)
+        elif len(shape) == 1:                               # BN weight
+            v = rng.uniform(0.7, 1.3, shape)
+        elif len(shape) == 5:                               # conv: keep activations O(1)
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            v = rng.normal(0, (2.0 / fan_in) ** 0.5 * 1.5, shape)
+        else:                                               # linear
+            v = rng.normal(0, (1.0 / shape[1]) ** 0.5, shape)
+        sd[key] = torch.from_numpy(np.asarray(v, np.float32))
+    return sd

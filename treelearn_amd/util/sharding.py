@@ -2,13 +2,22 @@
 
 Tiles are independent forward passes (reference tree_learn/util/pipeline.py:83-88), so the tile loop
 shards with NO data-path collective: one process per GPU, static longest-processing-time assignment
-by point count, each rank runs `get_pointwise_preds` on its tiles.  The only exchange is one
-variable-length all-gather of the inner-square results (4-5 % of the points), after which every rank
-holds what the single-GPU loop would have produced, in the single-GPU tile order.
+by point count, each rank materialises and runs ONLY its own tiles.  The exchange afterwards is
+
+    1. one all-gather of the per-rank row counts                         (world x i64)
+    2. one padded all-gather of the packed inner-square records          ([rows, W] f32, 4-5 % of the points)
+    3. (segment_plot_sharded) one broadcast of the i32 instance ids      -- the north star's "instance-id gather"
+
+with the records kept on the device from the tile loop to the collective (no host round trip); the order of
+operations after the gather -- ensemble, grouping, k-NN fill -- is the reference's
+(tools/pipeline/pipeline.py:70-94).
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+# columns of the packed record, in the order of get_pointwise_preds' 8 results; integer columns travel bit-cast (i32 in an f32 lane)
+_INT_RESULTS = (1, 5)                       # semantic_labels, instance_labels
 
 
 def assign_tiles(n_points, world_size):
@@ -23,61 +32,133 @@ def assign_tiles(n_points, world_size):
     return [sorted(x) for x in out]
 
 
-def all_gather_rows(x: torch.Tensor, group=None):
-    """All-gather tensors whose first dimension differs per rank (padded all_gather; RCCL has no
-    all_gatherv).  Returns the list of per-rank tensors."""
-    world = dist.get_world_size(group)
-    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c) for c in counts]
-    m = max(counts) if counts else 0
-    pad = torch.zeros((m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    pad[: x.shape[0]] = x
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return [b[:c] for b, c in zip(bufs, counts)]
+def _bits_f32(t):
+    """int64 labels -> f32 lanes holding the i32 bit pattern (lossless; labels are far below 2^31)."""
+    return t.to(torch.int32).contiguous().view(torch.float32)
 
 
-def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, device=None):
-    """`get_pointwise_preds` over `tiles` (a sequence of batch dicts) sharded across the process
-    group; every rank returns the full 8-array result in the original tile order."""
+def _bits_i64(t):
+    return t.contiguous().view(torch.int32).to(torch.int64)
+
+
+def pack_records(res, tile_index):
+    """The 8 per-point results of `get_pointwise_preds` (tensors, device or host) + the tile index of every row ->
+    one [n, W] f32 matrix and the column widths needed to split it again."""
+    n = res[0].shape[0]
+    cols = [_bits_f32(tile_index).reshape(n, 1)]
+    widths, is1d = [], []
+    for a, t in enumerate(res):
+        is1d.append(t.dim() == 1)
+        t2 = t.reshape(n, -1)
+        cols.append(_bits_f32(t2) if a in _INT_RESULTS else t2.float())
+        widths.append(t2.shape[1])
+    return torch.cat(cols, 1).contiguous(), widths, is1d
+
+
+def unpack_records(packed, widths, is1d):
+    parts = torch.split(packed[:, 1:], widths, dim=1)
+    out = []
+    for a, (p, one) in enumerate(zip(parts, is1d)):
+        p = _bits_i64(p) if a in _INT_RESULTS else p
+        out.append(p[:, 0] if one else p)
+    return tuple(out)
+
+
+class TileList:
+    """Lazy tile source: `n_points[i]` is known up front (e.g. from PlotTiler's occupancy count or the npz headers),
+    `make(i)` materialises tile i as a batch dict.  A rank only ever calls `make` for its own tiles."""
+
+    def __init__(self, n_points, make):
+        self.n_points = list(n_points); self.make = make
+
+    def __len__(self):
+        return len(self.n_points)
+
+
+def _as_source(tiles):
+    if isinstance(tiles, TileList):
+        return tiles
+    return TileList([t["coords"].shape[0] for t in tiles], lambda i: tiles[i])
+
+
+def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, device=None, return_device=False):
+    """`get_pointwise_preds` over `tiles` (a sequence of batch dicts or a TileList) sharded across the process group;
+    every rank returns the full 8-array result in the original tile order.  Two collectives per plot."""
     from .pipeline import get_pointwise_preds
+    src = _as_source(tiles)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = assign_tiles([t["coords"].shape[0] for t in tiles], world)[rank]
-    # one pipelined pass over this rank's tiles; the per-tile row counts restore the global tile order afterwards
-    res, rows = get_pointwise_preds(model, [tiles[i] for i in mine], config, logger, return_tile_rows=True)
-    per_tile, off = [], 0
+    mine = assign_tiles(src.n_points, world)[rank]
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+    # one pipelined pass over this rank's tiles, results left where the model put them (HBM on a GPU rank)
+    res, rows = get_pointwise_preds(model, (src.make(i) for i in mine), config, logger, return_tile_rows=True, keep_on_device=True)
+    res = tuple(torch.as_tensor(r).to(dev) for r in res)
+    n_local = res[0].shape[0]
+    tidx = torch.empty(n_local, dtype=torch.int64)
+    off = 0
     for pos, n in rows:
-        if n:                                            # skipped ("reach zero!!!") or empty-inner tiles contribute nothing
-            per_tile.append((mine[pos], tuple(r[off:off + n] for r in res)))
-        off += n
-    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
-    # header: (tile index, rows) per local tile; payload: the 8 arrays concatenated row-wise
-    hdr = torch.tensor([[i, r[0].shape[0]] for i, r in per_tile], dtype=torch.int64, device=dev).reshape(-1, 2)
-    hdrs = all_gather_rows(hdr, group)
-    outs = []
-    for a in range(8):
-        parts = [torch.from_numpy(np.ascontiguousarray(r[a])) for _, r in per_tile]
-        if parts:
-            local = torch.cat(parts, 0)
-        else:                                            # rank without tiles: empty array of the right trailing shape / dtype
-            local = torch.zeros((0,), dtype=torch.float32)
-        meta = torch.tensor([local.dim(), local.shape[1] if local.dim() > 1 else 0, int(local.dtype == torch.int64)], dtype=torch.int64, device=dev)
-        metas = [torch.zeros_like(meta) for _ in range(world)]
-        dist.all_gather(metas, meta, group=group)
-        ref = max(metas, key=lambda m: int(m[0]) * 1000 + int(m[1]))      # a rank that has data defines shape/dtype
-        dt = torch.int64 if any(int(m[2]) for m in metas) else torch.float32
-        if local.shape[0] == 0:
-            shape = (0,) if int(ref[0]) <= 1 else (0, int(ref[1]))
-            local = torch.zeros(shape, dtype=dt)
-        gathered = all_gather_rows(local.to(dev), group)
-        # re-order tile blocks into ascending tile index
-        blocks = {}
-        for rk, (h, g) in enumerate(zip(hdrs, gathered)):
-            off = 0
-            for ti, rows in h.tolist():
-                blocks[ti] = g[off:off + rows]; off += rows
-        ordered = [blocks[k] for k in sorted(blocks)]
-        outs.append((torch.cat(ordered, 0) if ordered else local).cpu().numpy())
-    return tuple(outs)
+        tidx[off:off + n] = mine[pos]; off += n
+    packed, widths, is1d = (None, None, None) if n_local == 0 else pack_records(res, tidx.to(dev))
+    # ranks with no rows learn the record layout from the others through the payload width: widths are a function of the
+    # model (2, 1, 3, 3, 3, 1, C, F); exchange them inside collective 1's message instead of a third collective
+    meta = torch.zeros(1 + 2 * 8, dtype=torch.int64, device=dev)
+    if n_local:
+        meta[0] = n_local
+        meta[1:9] = torch.tensor(widths, dtype=torch.int64); meta[9:17] = torch.tensor([int(b) for b in is1d], dtype=torch.int64)
+    metas = torch.empty(world * meta.numel(), dtype=torch.int64, device=dev)       # flat: gloo only takes the concatenated form
+    dist.all_gather_into_tensor(metas, meta, group=group)                          # collective 1 (counts + layout)
+    metas = metas.view(world, -1).tolist()
+    counts = [m[0] for m in metas]
+    if max(counts) == 0:
+        empty = tuple(np.zeros((0,), np.float32) for _ in range(8))
+        return tuple(torch.from_numpy(e) for e in empty) if return_device else empty
+    ref = next(m for m in metas if m[0] > 0)
+    widths, is1d = ref[1:9], [bool(b) for b in ref[9:17]]
+    W = 1 + sum(widths)
+    m = max(counts)
+    pad = torch.zeros((m, W), dtype=torch.float32, device=dev)
+    if n_local:
+        pad[:n_local] = packed
+    buf = torch.empty(world * m * W, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(buf, pad.view(-1), group=group)                    # collective 2 (payload)
+    buf = buf.view(world * m, W)
+    allrec = buf if all(c == m for c in counts) else torch.cat([buf[r * m:r * m + c] for r, c in enumerate(counts)], 0)
+    # single-GPU order = ascending tile index, rows of a tile in tile order: one stable sort of the tile column
+    order = torch.sort(allrec[:, 0].contiguous().view(torch.int32), stable=True).indices
+    allrec = allrec.index_select(0, order)
+    out = unpack_records(allrec, widths, is1d)
+    return out if return_device else tuple(o.cpu().numpy() for o in out)
+
+
+def segment_plot_sharded(model, tiles, config, grouping_cfg, group=None, device=None, logger=None,
+                         ensemble_fn=None, instances_fn=None, fill_fn=None,
+                         tree_class=0, non_trees_label=0, not_assigned_label=-1, start_num_preds=1):
+    """Whole-plot inference as the reference orders it (tools/pipeline/pipeline.py:70-94) with the tile loop sharded:
+    tile loop (per rank) -> record gather (2 collectives) -> ensemble -> get_instances -> k-NN fill on rank 0 ->
+    broadcast of the i32 instance ids (collective 3).  Returns (coords, instance_preds) as numpy on every rank.
+
+    `ensemble_fn` / `instances_fn` / `fill_fn` default to the HIP implementations (util.postprocess / util.pipeline);
+    CPU tests inject restatements."""
+    from . import postprocess as pp
+    from .pipeline import get_instances
+    rank = dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+    ensemble_fn = ensemble_fn or pp.ensemble
+    instances_fn = instances_fn or get_instances
+    fill_fn = fill_fn or pp.assign_remaining_points_nearest_neighbor
+    sem, seml, off, offl, coords, instl, bb, infeat = get_pointwise_preds_sharded(model, tiles, config, logger, group, dev, return_device=on_gpu)
+    # ensemble is replicated (deterministic on identical inputs: every rank knows the ensembled point count without a collective)
+    ens = ensemble_fn(coords, sem, seml, off, offl, instl, bb, infeat)
+    e_coords, e_sem, _, e_off, _, _, _, e_infeat = (np.asarray(x.cpu()) if torch.is_tensor(x) else x for x in ens)
+    n = len(e_coords)
+    ids = torch.empty(n, dtype=torch.int32, device=dev)
+    if rank == 0:
+        inst = instances_fn(e_coords, e_off, e_sem, grouping_cfg, e_infeat.reshape(n, -1)[:, -1], tree_class, non_trees_label,
+                            not_assigned_label, start_num_preds)
+        tree = inst != non_trees_label
+        if tree.any() and (inst[tree] != not_assigned_label).any() and (inst[tree] == not_assigned_label).any():
+            inst[tree] = fill_fn(e_coords[tree] + e_off[tree], inst[tree], not_assigned_label)
+        ids.copy_(torch.from_numpy(inst.astype(np.int32)))
+    dist.broadcast(ids, src=0, group=group)                                          # collective 3: the instance ids
+    return e_coords, ids.cpu().numpy().astype(np.int64)
