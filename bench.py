@@ -159,6 +159,72 @@ def sharded_plot(model, dist, rank, world, n_tiles, steps, warmup):
     return float(dt) / steps, int(npts.sum()), int(out[0].shape[0])
 
 
+def training_step_bench(args, rank, world, dist):
+    """BASELINE config 3: the step body of reference tools/training/train.py:30-44 on a batch of two 40x40 m crops, random-init
+    default model: zero_grad, forward with loss (mixed precision = the reference's autocast regime, bf16 here: no GradScaler
+    needed), the two loss .item() reads, backward, clip_grad_norm_(1.0), AdamW step (lr 3e-3, wd 1e-3: configs/training/train.yaml)."""
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
+    from treelearn_amd import ops
+    cfg = CONFIGS["config2"]
+    batch = make_batch([make_tile(**cfg, seed=2 * rank + s) for s in (0, 1)])
+    n_pts = batch["coords"].shape[0]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=cfg["voxel"], compute_dtype=dtype)
+    model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
+    model = model.cuda().train()
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3)
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def step():
+        opt.zero_grad()
+        loss, ld = model(gb, return_loss=True)
+        vals = [v.detach().cpu().item() for v in ld.values()]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0, norm_type=2)
+        opt.step()
+        return vals
+
+    for _ in range(max(args.warmup, 1)):
+        vals = step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vals = step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64); npts = torch.tensor([float(n_pts)], device="cuda", dtype=torch.float64)
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(npts, op=dist.ReduceOp.SUM)
+    dt = float(tmax)
+    if rank != 0:
+        return None
+    # algorithmic conv flops of one step: forward + dgrad + wgrad = 3 x (2 * pairs * Cin * Cout) over the 71 conv launches
+    ops.PROFILE = []
+    model.eval()
+    with torch.no_grad():
+        model(gb, return_loss=False)
+    torch.cuda.synchronize()
+    fl = sum(conv_work(m)[0] for _, _, m in ops.PROFILE); ops.PROFILE = None
+    model.train()
+    sec = dt / args.steps
+    peak = PEAK_MFMA_BF16_TFLOPS if args.dtype == "bf16" else PEAK_MFMA_F32_TFLOPS
+    ach = 3.0 * fl / sec / 1e12
+    return dict(metric="Mpoints/sec through sparse U-Net training step (fwd + bwd + AdamW; 0.1 m voxel, 2 x 40x40 m crops)",
+                value=float(npts) / sec / 1e6, unit="Mpoints/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+                config=dict(workload=f"config3: training step, batch of 2 crops of 40x40 m at 0.1 m ({n_pts} points), default 7-level 32-ch model "
+                                     f"(30.1 M params, random init), AdamW, grad-norm clip 1.0, {'bf16 mixed precision (autocast-like)' if args.dtype == 'bf16' else 'fp32'}",
+                            points_per_step=n_pts, last_losses=vals),
+                roofline=dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
+                              note="algorithmic conv flops of the step (forward + dgrad + wgrad = 3 x 2 * pairs * Cin * Cout) / whole step time"),
+                cpu_baseline=None)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (fresh processes;
     this parent never initialises the GPU and never re-execs), relay their output, print rank 0's JSON line last."""
@@ -195,7 +261,7 @@ def main():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
     ap.add_argument("--tiles-in-flight", type=int, default=3, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config5"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"])
     ap.add_argument("--plot-tiles", type=int, default=64, help="config4: tiles of the plot")
     ap.add_argument("--no-sharded-plot", action="store_true", help="N > 1: skip the config-4 sharded tile loop + gather measurement")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -223,6 +289,13 @@ def main():
     from treelearn_amd.model import TreeLearn
     from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
 
+    if args.workload == "config3":
+        res = training_step_bench(args, rank, world, dist)
+        if dist:
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        return
     if args.workload == "config4":
         if dist is None:
             import torch.distributed as dist

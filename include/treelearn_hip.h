@@ -209,6 +209,26 @@ int tl_head_mlp(const void* feats, int64_t feats_ld, int dtype, int C, const int
 int tl_affine_relu(const void* in, int64_t in_ld, void* out, int64_t out_ld, int64_t n, int C, int dtype,
                    const float* scale, const float* shift, int relu, tl_stream_t stream);
 
+/* ------------------------------------------------------------------ BatchNorm1d, training mode (+ ReLU)
+ * The `norm_fn(C), nn.ReLU()` pair in front of every conv and inside both heads in TRAINING mode (reference
+ * tree_learn/model/blocks.py:55-70,102-123, tree_learn.py:34-46: BatchNorm1d(eps=1e-4, momentum=0.1) over all active voxels of
+ * the batch; exercised by tools/training/train.py:30-44).  Replaces ATen's batch_norm / relu forward and backward kernels.
+ * Deterministic (fixed row partition, fp64 partial sums added in a fixed order, no atomics).
+ *
+ * tl_bn_train_stats: x [n, C] (f32 or bf16, row stride ld) -> mean, rstd = 1/sqrt(var_biased + eps), scale = gamma * rstd,
+ *   shift = beta - mean * scale (all f32[C]); running_mean / running_var (nullable pair) get the momentum update with the
+ *   UNBIASED variance like torch, num_batches_tracked (nullable, i64[1]) += 1.  y = relu(x * scale + shift) is then one
+ *   tl_affine_relu call.  ws f64[tl_bn_ws_doubles(n, C)].  C % 4 == 0, C <= 1024.
+ * tl_bn_train_bwd: dy [n, C] (f32 or bf16) = gradient w.r.t. y -> dx f32[n, C], dgamma, dbeta f32[C]; `relu` != 0 masks dy
+ *   where y <= 0 (y is recomputed from x). */
+int64_t tl_bn_ws_doubles(int64_t n, int C);
+int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, const float* gamma, const float* beta, float eps,
+                      float momentum, double* ws, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, tl_stream_t stream);
+int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int64_t dld, int dy_dtype, int64_t n, int C,
+                    const float* mean, const float* rstd, const float* scale, const float* shift, int relu, double* ws,
+                    float* dgamma, float* dbeta, float* dx, int64_t xld, tl_stream_t stream);
+
 /* Keep rows where mask != 0 (masks_inner filtering before D2H, util/pipeline.py:100-103).
  * in f32[n,C] -> out f32[count,C]; count i32[1] device.  Stable (input order kept).
  * ws i32[tl_compact_ws_words(n)] scratch. */

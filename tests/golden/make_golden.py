@@ -468,10 +468,54 @@ def g11_tiles(tmp="/tmp/tl_golden_plot"):
     save("g11_tiles.npz", **out)
 
 
+def g12_train7():
+    """BASELINE config 3 in miniature: the reference's DEFAULT architecture (7 levels, 32 channels, 30.1 M parameters) in
+    training mode on a batch of two crops (tools/training/train.py:30-44 step body without the optimizer), through the dense
+    stand-in.  Every level's wgrad and the transposed convs wider than 224 channels (levels >= 4 of the decoder: 2C >= 256)
+    are on the path of these gradients.  Stored: loss, BN statistics after the step, the norm of every gradient, and full /
+    sliced gradients of shallow, middle and deep parameters."""
+    cfg = dict(channels=32, num_blocks=7)
+    tiles = [small_tile(41, 11, 0.2, 4, 24.0, 0.2), small_tile(42, 9, 0.2, 3, 20.0, 0.3)]
+    sshape, vs, seed = [64, 64, 128], 0.2, 1207
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=sshape, voxel_size=vs, **cfg)
+    model.load_state_dict(random_state_dict(seed, **cfg), strict=True)
+    batch = make_batch(tiles, inner_square_edge_length=6.0)
+    out = {f"in_{k}": (v.numpy() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out["cfg"] = json.dumps(dict(cfg=cfg, spatial_shape=sshape, voxel_size=vs, seed=seed))
+    model.eval()
+    with torch.no_grad():
+        o = model(batch, return_loss=False)
+        loss, _ = model(batch, return_loss=True)
+    out["eval_loss"] = float(loss)
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        out[f"eval_{k}"] = o[k].numpy()
+    model.train(); model.zero_grad()
+    loss, ld = model(batch, return_loss=True)
+    loss.backward()
+    out["train_loss"] = float(loss); out["train_semantic_loss"] = float(ld["semantic_loss"]); out["train_offset_loss"] = float(ld["offset_loss"])
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        names.append(k); norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+    out["grad_names"] = np.array(names); out["grad_norms"] = np.array(norms, np.float64)
+    P = dict(model.named_parameters())
+    out["grad_input_conv"] = P["input_conv.0.weight"].grad.numpy()
+    out["grad_sem3"] = P["semantic_linear.3.weight"].grad.numpy()
+    deep = "unet.u.u.u.blocks_tail.block0"                       # level 4: 256 -> 128 conv and 1x1 (transposed: 128 -> 256 > 224 channels)
+    out["grad_l4_cat_conv_centre"] = P[deep + ".conv_branch.2.weight"].grad[:, 1, 1, 1, :].numpy()
+    out["grad_l4_cat_conv_corner"] = P[deep + ".conv_branch.2.weight"].grad[:, 0, 2, 1, :].numpy()
+    out["grad_l4_1x1"] = P[deep + ".i_branch.0.weight"].grad.numpy()
+    out["grad_l6_deconv"] = P["unet.u.u.u.u.u.deconv.2.weight"].grad[:, 1, 0, 1, :].numpy()      # 224 -> 192 inverse conv
+    out["grad_l7_conv_centre"] = P["unet.u.u.u.u.u.u.blocks.block0.conv_branch.2.weight"].grad[:, 1, 1, 1, :].numpy()
+    out["grad_l2_down"] = P["unet.u.conv.2.weight"].grad[:, 1, 1, 0, :].numpy()
+    out["bn_out_running_mean_after"] = getattr(model.output_layer, "0").running_mean.numpy()
+    out["bn_l5_running_var_after"] = dict(model.named_buffers())["unet.u.u.u.u.blocks.block1.conv_branch.3.running_var"].numpy()
+    save("g12_train7.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
-    fns = dict(g11=g11_tiles, g1=g1_g2_loss, g3=g3_voxelize, g4=g4_collate, g5=g5_clustering, g6=g6_g7_next_rows, g8=g8_manifest, g9=g9_tile_loop, g10=g10_forward)
+    fns = dict(g12=g12_train7, g11=g11_tiles, g1=g1_g2_loss, g3=g3_voxelize, g4=g4_collate, g5=g5_clustering, g6=g6_g7_next_rows, g8=g8_manifest, g9=g9_tile_loop, g10=g10_forward)
     for w in which:
         fns[w]()

@@ -1,0 +1,421 @@
+"""GPU tests at the BASELINE.json workloads themselves (configs 2-5), not at reduced sizes:
+
+config 2  the 1.89 M-point 40x40 m / 0.1 m tile: geometry bit-exact, conv kernels on the REAL rulebooks vs the oracle on sampled
+          rows, the fp32 forward vs the CPU oracle end to end, the bf16 headline mode on decision-level quantities
+config 3  the default 7-level / 32-channel architecture in training mode vs the reference module tree (golden g12), and a
+          full-size 2 x 40 m training step through size-independent properties
+config 4  64 tiles through the tile loop = 64 single-tile forwards; the sharded loop under a world-1 RCCL group
+config 5  the 0.05 m / 15 M-voxel stress tile: geometry vs the oracle, forward finite, kernel families agree; buffers beyond
+          2^31 and 2^32 bytes
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as om
+from oracle import sparse_ops as osp
+from oracle import voxel as ov
+from treelearn_amd.synth import CONFIGS, make_batch, make_tile, plot_tiles, random_state_dict
+
+REL_TOL = 1e-3
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+@pytest.fixture(scope="module")
+def tile2():
+    """The config-2 tile of bench.py (seed 0) as a batch dict (CPU) -- built once per module."""
+    return make_batch([make_tile(**CONFIGS["config2"], seed=0)])
+
+
+def _geometry(batch, vs, levels=7, sshape=(500, 500, 1000)):
+    from treelearn_amd.geometry import build_geometry
+    return build_geometry(batch["coords"].cuda(), batch["batch_ids"].cuda(), int(batch["batch_size"]), vs, levels,
+                          list(sshape) if sshape is not None else None)
+
+
+def _oracle_levels(batch, vs, levels, sshape):
+    pts = batch["coords"].numpy(); bids = batch["batch_ids"].numpy()
+    _, vc, v2p, ss = ov.voxelize(pts, np.zeros((len(pts), 1), np.float32), bids, int(batch["batch_size"]), vs)
+    shape = np.asarray(sshape if sshape is not None else ss, np.int64)
+    out = []
+    cur = np.asarray(vc)
+    for li in range(levels):
+        ent = dict(coords=cur, shape=shape)
+        if li + 1 < levels:
+            cc, parent, child, shape = ov.rulebook_down(cur, shape)
+            ent.update(parent=parent, child=child)
+            out.append(ent); cur = cc
+        else:
+            out.append(ent)
+    return out, np.asarray(v2p)
+
+
+def _nbr_rows(coords, rows):
+    """Oracle SubM table of the given rows only (the full-table builder is the same code over all rows)."""
+    keys = ov.pack_key(coords)
+    c = coords[rows].astype(np.int64)
+    out = np.full((len(rows), 27), -1, np.int32)
+    for a in range(3):
+        for b in range(3):
+            for d in range(3):
+                q = c.copy(); q[:, 1] += a - 1; q[:, 2] += b - 1; q[:, 3] += d - 1
+                ok = (q[:, 1:] >= 0).all(1) & (q[:, 1:] < 65536).all(1)
+                r = ov._lookup(keys, ov.pack_key(np.where(ok[:, None], q, 0)))
+                out[:, (a * 3 + b) * 3 + d] = np.where(ok, r, -1)
+    return out
+
+
+def _check_geometry_vs_oracle(geom, batch, vs, sshape, full_tables_up_to=10 ** 9, sample=200_000, seed=0):
+    """coords / v2p / parent of every level bit-exact; SubM, child and inverse tables bit-exact on all rows of levels with at most
+    `full_tables_up_to` voxels and on `sample` random rows of larger levels."""
+    levels, v2p = _oracle_levels(batch, vs, len(geom.levels), sshape)
+    np.testing.assert_array_equal(geom.v2p.cpu().numpy(), v2p)
+    rng = np.random.default_rng(seed)
+    for li, (lv, o) in enumerate(zip(geom.levels, levels)):
+        assert lv.n == len(o["coords"]), li
+        np.testing.assert_array_equal(lv.coords.cpu().numpy(), o["coords"])
+        assert tuple(lv.shape) == tuple(int(s) for s in o["shape"])
+        rows = np.arange(lv.n) if lv.n <= full_tables_up_to else np.sort(rng.choice(lv.n, sample, replace=False))
+        nbr = lv.nbr.cpu().numpy()
+        np.testing.assert_array_equal(nbr[:, rows].T, _nbr_rows(o["coords"], rows), err_msg=f"subm table level {li}")
+        ct = getattr(lv.nbr, "_tl_compact", None)
+        if ct is not None:                                     # the column form decodes to the same table
+            c = ct.cpu().numpy()[:, rows].astype(np.int64)
+            dec = np.full((len(rows), 27), -1, np.int64)
+            for col in range(9):
+                m = (c[9] >> (3 * col)) & 7
+                b0 = c[col]
+                dec[:, 3 * col] = np.where(m & 1, b0, -1)
+                dec[:, 3 * col + 1] = np.where(m & 2, b0 + (m & 1), -1)
+                dec[:, 3 * col + 2] = np.where(m & 4, b0 + (m & 1) + ((m >> 1) & 1), -1)
+            np.testing.assert_array_equal(dec, nbr[:, rows].T, err_msg=f"column-form table level {li}")
+        if "parent" in o:
+            parent = o["parent"]
+            np.testing.assert_array_equal(lv.parent.cpu().numpy(), parent)
+            np.testing.assert_array_equal(lv.child.cpu().numpy().T, o["child"])
+            cur = o["coords"]
+            inv = np.full((len(cur), 8), -1, np.int32)
+            tap = (cur[:, 1] & 1) * 4 + (cur[:, 2] & 1) * 2 + (cur[:, 3] & 1)
+            ok = parent >= 0
+            inv[np.where(ok)[0], tap[ok]] = parent[ok]
+            np.testing.assert_array_equal(lv.inv.cpu().numpy().T, inv)
+
+
+def _model(dtype=torch.float32, voxel=0.1, sshape=(500, 500, 1000), seed=7, train=False):
+    from treelearn_amd.model import TreeLearn
+    m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=list(sshape) if sshape is not None else None, voxel_size=voxel, compute_dtype=dtype)
+    m.load_state_dict(random_state_dict(seed, channels=32, num_blocks=7), strict=True)
+    m = m.cuda()
+    return m.train() if train else m.eval()
+
+
+# =============================================================================================== config 2
+def test_config2_full_tile_geometry_bit_exact(tile2):
+    """Voxel indices, v2p and all 13 rulebooks of the 1.89 M-point tile, every row of every level, against the numpy oracle."""
+    g = _geometry(tile2, 0.1)
+    assert g.levels[0].n > 1_700_000
+    _check_geometry_vs_oracle(g, tile2, 0.1, (500, 500, 1000))
+
+
+@pytest.mark.parametrize("level,cin,cout,kind", [
+    (0, 32, 32, "subm"), (0, 64, 32, "subm"), (0, 4, 32, "subm"), (0, 32, 64, "down"), (0, 64, 32, "inverse"),
+    (1, 64, 64, "subm"), (1, 128, 64, "subm"), (1, 64, 96, "down"), (1, 96, 64, "inverse"),
+    (2, 96, 96, "subm"), (2, 192, 96, "subm"), (3, 128, 128, "subm"), (3, 256, 128, "subm"), (4, 160, 160, "subm")])
+def test_config2_full_tile_convs_on_real_rulebooks(tile2, level, cin, cout, kind):
+    """Every conv shape of levels 1-5 on the REAL rulebooks of the full tile (the launches the headline number times), bf16 and
+    fp32, residual + BatchNorm/ReLU epilogue + second view as the engine uses them, against the oracle's gather-mm form on 4096
+    sampled output rows with the same (bf16-rounded) operands."""
+    from treelearn_amd import ops
+    g = _geometry(tile2, 0.1)
+    lv = g.levels[level]
+    if kind == "subm":
+        table, n_out, n_in, K = lv.nbr, lv.n, lv.n, 27
+    elif kind == "down":
+        table, n_out, n_in, K = lv.child, g.levels[level + 1].n, lv.n, 8
+    else:
+        table, n_out, n_in, K = lv.inv, lv.n, g.levels[level + 1].n, 8
+    gen = torch.Generator(device="cuda"); gen.manual_seed(level * 1000 + cin + cout)
+    k = round(K ** (1 / 3))
+    w = torch.randn((cout, k, k, k, cin), device="cuda", generator=gen) / (cin * K) ** 0.5
+    rows = torch.randperm(n_out, device="cuda", generator=gen)[:4096].sort().values
+    sub = table[:, rows].T.contiguous().cpu().numpy()
+    osc = torch.rand(cout, device="cuda", generator=gen) + 0.5; osh = torch.randn(cout, device="cuda", generator=gen) * 0.3
+    for dt, tol in ((torch.bfloat16, 1.2e-2), (torch.float32, 2e-5)):
+        x = torch.randn((n_in, cin), device="cuda", generator=gen).to(dt)
+        res = torch.randn((n_out, cout), device="cuda", generator=gen).to(dt)
+        wp = ops.pack_weight(w, dt)
+        raw = torch.empty((n_out, cout), dtype=dt, device="cuda")
+        act = ops.conv_fwd(x, wp, table, n_out, residual=res, out_scale=osc, out_shift=osh, out_relu=True, out2=(raw, None, None, False),
+                           one_hot=(kind == "inverse"))
+        xr = x.float().cpu(); wr = w.to(dt).float().cpu()
+        ref = osp.conv_table(xr, wr, sub).numpy() + res[rows].float().cpu().numpy()
+        got_raw = raw[rows].float().cpu().numpy()
+        assert rel_err(got_raw, ref) < tol, (dt, rel_err(got_raw, ref))
+        ref_act = np.maximum(ref * osc.cpu().numpy() + osh.cpu().numpy(), 0)
+        assert rel_err(act[rows].float().cpu().numpy(), ref_act) < tol, dt
+
+
+def test_config2_full_tile_forward_fp32_vs_oracle(tile2):
+    """End-to-end parity AT the headline workload: the fp32 forward of the full 1.89 M-point tile (default model, 30.1 M
+    parameters) within 1e-3 relative of the CPU oracle's forward (about a minute of host time)."""
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    model = _model(torch.float32)
+    with torch.no_grad():
+        out = model(tile2, return_loss=False)
+    ref = om.forward(random_state_dict(7, channels=32, num_blocks=7), tile2["coords"].numpy(), tile2["input_feats"].numpy(),
+                     tile2["batch_ids"].numpy(), 1, voxel_size=0.1, num_blocks=7, spatial_shape=[500, 500, 1000])
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, (k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
+def test_config2_full_tile_bf16_decision_level(tile2):
+    """The headline mode (bf16 activations between ~70 layers) against the exact-fp32 mode on the full tile, on what the
+    pipeline consumes: share of points whose tree / non-tree argmax flips, and the offset error in metres.  Weights are the
+    synthetic random ones with BatchNorm statistics re-estimated on this tile (a random-init net with arbitrary running
+    statistics saturates; re-estimated ones keep activations O(1) like a trained net's)."""
+    m32 = _model(torch.float32)
+    m32.train()
+    with torch.no_grad():
+        for _ in range(2):
+            m32(tile2, return_loss=False)                     # module-by-module path, batch statistics -> running stats move
+    m32.eval()
+    mbf = _model(torch.bfloat16); mbf.load_state_dict(m32.state_dict()); mbf = mbf.cuda().eval()
+    with torch.no_grad():
+        a = m32(tile2, return_loss=False); b = mbf(tile2, return_loss=False)
+    la, lb = a["semantic_prediction_logits"].float(), b["semantic_prediction_logits"].float()
+    flips = float((la.argmax(1) != lb.argmax(1)).float().mean())
+    margin = (la[:, 0] - la[:, 1]).abs()
+    confident = margin > 0.1 * margin.mean()
+    flips_conf = float(((la.argmax(1) != lb.argmax(1)) & confident).float().mean())
+    off_err = (a["offset_predictions"].float() - b["offset_predictions"].float()).norm(dim=1)
+    off_mag = a["offset_predictions"].float().norm(dim=1)
+    print(f"bf16 vs fp32 on {len(la)} points: argmax flips {flips:.4%} (confident points {flips_conf:.4%}); offset error "
+          f"median {float(off_err.median()):.4f} / p99 {float(off_err.quantile(0.99)):.4f} (|offset| median {float(off_mag.median()):.3f})")
+    assert flips < 0.02 and flips_conf < 0.002
+    assert float(off_err.median()) < 0.05 * max(float(off_mag.median()), 1e-6) + 1e-3
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(b[k].float().cpu().numpy(), a[k].float().cpu().numpy()) < 6e-2, k
+
+
+# =============================================================================================== config 3
+def _batch_from(g, prefix="in_"):
+    keys = ["coords", "input_feats", "batch_ids", "semantic_labels", "instance_labels", "masks_inner", "masks_off", "masks_sem", "offset_labels", "centers"]
+    b = {k: torch.from_numpy(g[prefix + k]) for k in keys}
+    b["batch_size"] = int(g[prefix + "batch_size"])
+    return b
+
+
+def test_config3_default_architecture_training_step_vs_reference(golden_dir):
+    """The reference's default architecture (7 levels, 32 channels) in training mode on a batch of two crops: loss, BatchNorm
+    statistics and gradients against the reference module tree (golden g12, tests/golden/make_golden.py:g12_train7).  The
+    transposed convs of the decoder at levels >= 4 have more than 224 output channels (column-sliced dgrad), and every level's
+    wgrad is on the path."""
+    from treelearn_amd.model import TreeLearn
+    g = np.load(os.path.join(golden_dir, "g12_train7.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=cfg["spatial_shape"], voxel_size=cfg["voxel_size"], **cfg["cfg"])
+    model.load_state_dict(random_state_dict(cfg["seed"], **cfg["cfg"]), strict=True)
+    model = model.cuda()
+    batch = _batch_from(g)
+    model.eval()
+    with torch.no_grad():
+        o = model(batch, return_loss=False)
+        loss, _ = model(batch, return_loss=True)
+    assert float(loss) == pytest.approx(float(g["eval_loss"]), rel=REL_TOL)
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(o[k].cpu().numpy(), g[f"eval_{k}"]) < REL_TOL, k
+    model.train(); model.zero_grad()
+    loss, ld = model(batch, return_loss=True)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["train_loss"]), rel=REL_TOL)
+    assert float(ld["offset_loss"].detach()) == pytest.approx(float(g["train_offset_loss"]), rel=REL_TOL)
+    P = dict(model.named_parameters()); Bf = dict(model.named_buffers())
+    names = [str(s) for s in g["grad_names"]]
+    ours = np.array([float(P[n].grad.norm()) for n in names]); ref = g["grad_norms"]
+    np.testing.assert_allclose(ours, ref, rtol=5e-3, atol=1e-6 * ref.max())
+    deep = "unet.u.u.u.blocks_tail.block0"
+    checks = {
+        "grad_input_conv": P["input_conv.0.weight"].grad,
+        "grad_sem3": P["semantic_linear.3.weight"].grad,
+        "grad_l4_cat_conv_centre": P[deep + ".conv_branch.2.weight"].grad[:, 1, 1, 1, :],
+        "grad_l4_cat_conv_corner": P[deep + ".conv_branch.2.weight"].grad[:, 0, 2, 1, :],
+        "grad_l4_1x1": P[deep + ".i_branch.0.weight"].grad,
+        "grad_l6_deconv": P["unet.u.u.u.u.u.deconv.2.weight"].grad[:, 1, 0, 1, :],
+        "grad_l7_conv_centre": P["unet.u.u.u.u.u.u.blocks.block0.conv_branch.2.weight"].grad[:, 1, 1, 1, :],
+        "grad_l2_down": P["unet.u.conv.2.weight"].grad[:, 1, 1, 0, :],
+    }
+    for k, v in checks.items():
+        assert rel_err(v.cpu().numpy(), g[k]) < 5e-3, (k, rel_err(v.cpu().numpy(), g[k]))
+    np.testing.assert_allclose(model.output_layer[0].running_mean.cpu().numpy(), g["bn_out_running_mean_after"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(Bf["unet.u.u.u.u.blocks.block1.conv_branch.3.running_var"].cpu().numpy(), g["bn_l5_running_var_after"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_config3_full_size_training_step_properties(dtype):
+    """BASELINE config 3 at full size: forward + backward of the default model on a batch of two 40x40 m crops (3.7 M points).
+    Size-independent properties: (1) with every BatchNorm frozen (eval statistics) the training path -- module by module,
+    autograd through the HIP convs -- gives the loss of the fused inference engine on the same batch; (2) the real training
+    step is finite, every parameter gets a finite gradient, the loss is reproducible run to run, and BatchNorm running
+    statistics move; (3) fp32 and the mixed-precision mode agree on the loss within bf16 distance."""
+    tiles = [make_tile(**CONFIGS["config2"], seed=s) for s in (1, 2)]
+    batch = make_batch(tiles)
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    model = _model(dtype, train=False)
+    with torch.no_grad():
+        loss_fused, _ = model(gb, return_loss=True)
+    loss_unfused, _ = model(gb, return_loss=True)              # grad enabled, BN in eval mode: the training code path on frozen statistics
+    assert float(loss_unfused.detach()) == pytest.approx(float(loss_fused), rel=2e-3 if dtype == torch.float32 else 5e-2)
+    loss_unfused.backward()
+    model.zero_grad(set_to_none=True)
+    model.train()
+    rm0 = model.output_layer[0].running_mean.clone()
+    losses = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        loss, ld = model(gb, return_loss=True)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        assert np.isfinite(losses[-1])
+        model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)      # undo the running-stat update: same step again
+    assert losses[0] == pytest.approx(losses[1], rel=1e-6)
+    bad = [n for n, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+    assert not bad, bad[:5]
+    zero = [n for n, p in model.named_parameters() if float(p.grad.abs().max()) == 0.0]
+    assert not zero, zero[:5]
+    model.zero_grad(set_to_none=True)
+    loss, _ = model(gb, return_loss=True)
+    assert not torch.equal(model.output_layer[0].running_mean, rm0)
+    if dtype == torch.bfloat16:
+        m32 = _model(torch.float32, train=True)
+        l32, _ = m32(gb, return_loss=True)
+        assert float(loss.detach()) == pytest.approx(float(l32.detach()), rel=5e-2)
+
+
+# =============================================================================================== config 4
+@pytest.fixture(scope="module")
+def plot64():
+    """The 64 tiles of BASELINE config 4 (8 symmetries x generator seeds 0..7, config-2 size), resident on the GPU."""
+    cache = {}
+    out = []
+    for i in range(64):
+        b = make_batch(plot_tiles([i], CONFIGS["config2"], cache))
+        out.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()})
+    return out
+
+
+def test_config4_64_tiles_loop_equals_single_forwards(plot64):
+    """64 config-2 tiles through the production tile loop (three tiles in flight, inner-square filter on the device) give exactly
+    what 64 separate forwards give; the sharded loop under a world-1 RCCL process group (LPT assignment, packed device-resident
+    records, two collectives) returns the same arrays."""
+    import torch.distributed as dist
+    from treelearn_amd.util.pipeline import get_pointwise_preds
+    from treelearn_amd.util.sharding import TileList, get_pointwise_preds_sharded
+    model = _model(torch.bfloat16)
+    res = get_pointwise_preds(model, plot64, dict(voxel_size=0.1), keep_on_device=True)
+    assert len(set(len(r) for r in res)) == 1 and len(res[0]) > 64 * 50_000
+    sem, off, bb, coords = [], [], [], []
+    with torch.no_grad():
+        for b in plot64:
+            o = model(b, return_loss=False)
+            m = b["masks_inner"]
+            sem.append(o["semantic_prediction_logits"][m]); off.append(o["offset_predictions"][m]); bb.append(o["backbone_feats"][m])
+            coords.append(b["coords"][m] + b["centers"][m])
+    assert torch.equal(res[0], torch.cat(sem)) and torch.equal(res[2], torch.cat(off)) and torch.equal(res[6], torch.cat(bb))
+    assert torch.equal(res[4], torch.cat(coords))
+    assert torch.equal(res[5], torch.cat([b["instance_labels"][b["masks_inner"]] for b in plot64]))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29671")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        made = []
+        src = TileList([b["coords"].shape[0] for b in plot64], lambda i: (made.append(i), plot64[i])[1])
+        sh = get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True)
+        assert made == list(range(64))
+        for a, b in zip(res, sh):
+            assert b.is_cuda and a.dtype == b.dtype and torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
+# =============================================================================================== config 5
+@pytest.fixture(scope="module")
+def tile5():
+    return make_batch([make_tile(**CONFIGS["config5"], seed=0)])
+
+
+def test_config5_stress_tile_geometry_vs_oracle(tile5):
+    """0.05 m voxels, spatial_shape None (800 > 500): 15 M voxels at level 1.  coords / v2p / parent / child / inverse tables of
+    all seven levels bit-exact; SubM tables bit-exact on every row of levels <= 2 M voxels and on 200 k sampled rows of the two
+    largest levels (the oracle's table builder over 15 M x 27 probes takes minutes)."""
+    g = _geometry(tile5, 0.05, sshape=None)
+    assert g.levels[0].n > 14_000_000
+    _check_geometry_vs_oracle(g, tile5, 0.05, None, full_tables_up_to=2_000_000)
+
+
+def test_config5_stress_tile_forward_finite_and_kernel_families_agree(tile5):
+    """The bf16 forward of the stress tile is finite, reproducible, and does not depend on which kernel family serves a layer
+    (default dispatch vs the tile-kernel fallbacks forced through tl_set_tuning); fp32 mode agrees within bf16 distance."""
+    from treelearn_amd import _hip
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in tile5.items()}
+    model = _model(torch.bfloat16, voxel=0.05, sshape=None, seed=11)
+    L = _hip.lib()
+
+    def run(**tuning):
+        for k, v in tuning.items():
+            _hip.check(L.tl_set_tuning(k.encode(), v), k)
+        try:
+            with torch.no_grad():
+                o = model(gb, return_loss=False)
+            return {k: v.float() for k, v in o.items()}
+        finally:
+            for k in tuning:
+                _hip.check(L.tl_set_tuning(k.encode(), 1), k)
+
+    ref = run(); again = run()
+    for k in ref:
+        assert bool(torch.isfinite(ref[k]).all()), k
+        assert torch.equal(ref[k], again[k]), k
+    for i, var in enumerate((run(streamq=0), run(direct=0, stream=0))):
+        for k in ("semantic_prediction_logits", "offset_predictions"):
+            e = float((var[k] - ref[k]).abs().max() / ref[k].abs().max())
+            assert e < 4e-2, (i, k, e)
+    m32 = _model(torch.float32, voxel=0.05, sshape=None, seed=11)
+    with torch.no_grad():
+        o32 = m32(gb, return_loss=False)
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        e = float((o32[k].float() - ref[k]).abs().max() / o32[k].float().abs().max())
+        assert e < 6e-2, (k, e)
+
+
+@pytest.mark.parametrize("dt,n_in,cin,cout", [(torch.bfloat16, 9_000_000, 128, 64), (torch.float32, 5_200_000, 128, 64),
+                                              (torch.float32, 9_000_000, 128, 64), (torch.bfloat16, 18_000_000, 128, 64)])
+def test_feature_buffers_beyond_2g_and_4g_bytes(dt, n_in, cin, cout):
+    """Input views of 2.3 GB (past 2^31 bytes: the signed-offset hazard), 2.7 GB, and 4.6 GB (past 2^32: 32-bit buffer offsets
+    cannot address them, the dispatcher has to pick a 64-bit-addressed kernel) -- a 27-tap conv whose table points at the LAST
+    rows of the buffer, sampled rows against the oracle."""
+    from treelearn_amd import ops
+    n_out = 40_000
+    gen = torch.Generator(device="cuda"); gen.manual_seed(n_in % 1000 + cin)
+    x = torch.empty((n_in, cin), dtype=dt, device="cuda")
+    x[-300_000:] = torch.randn((300_000, cin), device="cuda", generator=gen).to(dt)
+    x[:1000] = torch.randn((1000, cin), device="cuda", generator=gen).to(dt)
+    table = torch.randint(n_in - 300_000, n_in, (27, n_out), device="cuda", generator=gen, dtype=torch.int64).to(torch.int32)
+    table[:, ::7] = torch.randint(0, 1000, (27, len(range(0, n_out, 7))), device="cuda", generator=gen, dtype=torch.int64).to(torch.int32)
+    table[torch.rand((27, n_out), device="cuda", generator=gen) < 0.4] = -1
+    w = torch.randn((cout, 3, 3, 3, cin), device="cuda", generator=gen) / (cin * 27) ** 0.5
+    out = ops.conv_fwd(x, ops.pack_weight(w, dt), table.contiguous(), n_out)
+    rows = torch.arange(0, n_out, 13, device="cuda")
+    sub = table[:, rows].T.contiguous()
+    # oracle on the sampled rows: compact the rows they touch so the CPU never sees the multi-GB buffer
+    used, inv = torch.unique(sub[sub >= 0], return_inverse=True)
+    subc = torch.full_like(sub, -1); subc[sub >= 0] = inv.to(torch.int32)
+    ref = osp.conv_table(x[used.long()].float().cpu(), w.to(dt).float().cpu(), subc.cpu().numpy()).numpy()
+    assert rel_err(out[rows].float().cpu().numpy(), ref) < (1.2e-2 if dt == torch.bfloat16 else 2e-5)

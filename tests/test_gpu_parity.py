@@ -888,3 +888,109 @@ def test_handwritten_known_answers_through_the_hip_path():
                 np.testing.assert_array_equal(got, want, err_msg=case["name"])
             else:
                 assert np.abs(got - want).max() <= tol * np.abs(want).max(), (case["name"], got, want)
+
+
+@pytest.mark.parametrize("cin,cout,n_out,kind", [(64, 64, 70001, "shifted"), (64, 64, 3000, "random"), (128, 64, 66000, "mixed"), (96, 96, 66013, "shifted"),
+                                                 (192, 96, 5000, "mixed"), (128, 128, 66100, "shifted"), (256, 128, 2100, "random"), (32, 32, 67000, "mixed"),
+                                                 (64, 32, 1025, "shifted")])
+def test_conv_window_kernel_vs_oracle(cin, cout, n_out, kind):
+    """tl_conv_win (dz taps of a column served from one LDS-staged row window) against the oracle: 'shifted' tables keep every
+    neighbour near its output row (the in-window path, as on real rulebooks), 'random' tables put every neighbour outside the
+    window (the global-memory slow path), 'mixed' interleaves both and leaves whole (row, group) blocks absent; ragged row counts,
+    residual and three output views; same result with the 768-row window."""
+    from treelearn_amd import _hip, ops
+    rng = np.random.default_rng(cin + 3 * cout + n_out)
+    d = _dev()
+    n_in = n_out + 300
+    x = _bf16_round(rng.normal(size=(n_in, cin)).astype(np.float32))
+    w = _bf16_round((rng.normal(size=(cout, 3, 3, 3, cin)) / np.sqrt(cin * 27)).astype(np.float32))
+    rows = np.arange(n_out)[:, None]
+    shifted = rows + rng.integers(-40, 160, size=(1, 27)) + rng.integers(-2, 3, size=(n_out, 27))
+    shifted = np.clip(shifted, 0, n_in - 1)
+    rnd = rng.integers(0, n_in, size=(n_out, 27))
+    if kind == "shifted":
+        table = shifted
+    elif kind == "random":
+        table = rnd
+    else:
+        table = np.where(rng.uniform(size=(n_out, 27)) < 0.03, rnd, shifted)
+        table[(np.arange(n_out) // 700) % 3 == 1, 9:18] = -1
+    table = table.astype(np.int32)
+    table[rng.uniform(size=table.shape) < 0.4] = -1
+    res = _bf16_round(rng.normal(size=(n_out, cout)).astype(np.float32))
+    s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32); h2 = rng.normal(0, 0.3, cout).astype(np.float32)
+    y = osp.conv_table(torch.from_numpy(x), torch.from_numpy(w), table, n_out).numpy() + res
+    T = lambda a, dt=torch.float32: torch.from_numpy(a).to(d).to(dt)
+    wp = ops.pack_weight(T(w), torch.bfloat16)
+    tab = torch.from_numpy(np.ascontiguousarray(table.T)).to(d)
+    L = _hip.lib()
+    outs = {}
+    try:
+        _hip.check(L.tl_set_tuning(b"win", 2), "win"); _hip.check(L.tl_set_tuning(b"win_min_rows", 0), "win_min_rows")
+        for wr in (640, 768):
+            _hip.check(L.tl_set_tuning(b"win_rows", wr), "win_rows")
+            wide = torch.zeros((n_out, 2 * cout), dtype=torch.bfloat16, device=d)
+            o3 = torch.empty((n_out, cout), dtype=torch.bfloat16, device=d)
+            out = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, residual=T(res, torch.bfloat16),
+                               out2=(wide[:, cout:], T(s2), T(h2), True), out3=(o3, None, None, False))
+            assert rel_err(out.float().cpu().numpy(), y) < 8e-3, (wr, rel_err(out.float().cpu().numpy(), y))
+            assert rel_err(wide[:, cout:].float().cpu().numpy(), np.maximum(y * s2 + h2, 0)) < 8e-3
+            assert torch.equal(o3, out) and float(wide[:, :cout].abs().max()) == 0.0
+            outs[wr] = out
+        assert torch.equal(outs[640], outs[768])                 # the window size changes where rows come from, never the arithmetic
+        _hip.check(L.tl_set_tuning(b"win", 0), "win")
+        ref = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, residual=T(res, torch.bfloat16))
+        assert rel_err(outs[640].float().cpu().numpy(), ref.float().cpu().numpy()) < 8e-3
+    finally:
+        _hip.check(L.tl_set_tuning(b"win", 1), "win"); _hip.check(L.tl_set_tuning(b"win_min_rows", 65536), "win_min_rows")
+        _hip.check(L.tl_set_tuning(b"win_rows", 640), "win_rows")
+
+
+@pytest.mark.parametrize("n,C,relu", [(5, 32, True), (1000, 32, True), (70001, 64, True), (33333, 448, True), (4097, 96, False), (257, 224, True)])
+def test_bn_train_kernels_vs_torch(n, C, relu):
+    """tl_bn_train_stats / tl_affine_relu / tl_bn_train_bwd (the training-mode BatchNorm1d + ReLU pairs of blocks.py:55-70) against
+    torch.nn.BatchNorm1d + ReLU in float64: outputs, running statistics, and all three gradients; bit-reproducible run to run."""
+    from treelearn_amd.autograd import bn_relu_train
+    d = _dev()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(n + C)
+    x = (torch.randn((n, C), device=d, generator=gen) * 2.0 + torch.randn(C, device=d, generator=gen)).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1).to(d).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, device=d, generator=gen) + 0.5); bn.bias.copy_(torch.randn(C, device=d, generator=gen) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, device=d, generator=gen)); bn.running_var.copy_(torch.rand(C, device=d, generator=gen) + 0.5)
+    ref = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1).to(d).double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    gy = torch.randn((n, C), device=d, generator=gen)
+    y = bn_relu_train(x, bn, relu)
+    y.backward(gy)
+    xr = x.detach().double().requires_grad_(True)
+    yr = ref(xr); yr = torch.relu(yr) if relu else yr
+    yr.backward(gy.double())
+    tol = lambda a: 2e-5 * max(float(a.abs().max()), 1e-6)                          # noqa: E731
+    assert float((y.double() - yr).abs().max()) < tol(yr)
+    assert float((x.grad.double() - xr.grad).abs().max()) < 5 * tol(xr.grad)
+    assert float((bn.weight.grad.double() - ref.weight.grad).abs().max()) < 5 * tol(ref.weight.grad)
+    assert float((bn.bias.grad.double() - ref.bias.grad).abs().max()) < 5 * tol(ref.bias.grad)
+    assert float((bn.running_mean.double() - ref.running_mean).abs().max()) < 1e-5
+    assert float((bn.running_var.double() - ref.running_var).abs().max()) < 1e-4 * float(ref.running_var.max())
+    assert int(bn.num_batches_tracked) == 1
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = bn_relu_train(x2, bn, relu); y2.backward(gy)
+    assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad)
+
+
+def test_forward_unusual_width_falls_back_to_generic_kernels():
+    """channels = 48 (not a multiple of 32, no fused-head instantiation): the reference accepts any width, so the eval forward
+    must too -- generic conv kernel + the head fallback -- and still match the oracle."""
+    from treelearn_amd.model import TreeLearn
+    cfg = dict(channels=48, num_blocks=3)
+    t = make_tile(extent=6, voxel=0.2, n_trees=2, seed=5)
+    batch = make_batch([t])
+    sd = om.random_state_dict(19, **cfg)
+    model = TreeLearn(use_feats=False, use_coords=False, voxel_size=0.2, **cfg)
+    model.load_state_dict(sd, strict=True); model = model.cuda().eval()
+    with torch.no_grad():
+        out = model(batch, return_loss=False)
+    ref = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 1, voxel_size=0.2, num_blocks=3)
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, k

@@ -202,3 +202,23 @@ def test_column_form_rulebook_property_on_oracle_tables():
         base = np.where(present.any(1), np.where(present, col, np.iinfo(np.int64).max).min(1), -1)
         rank = np.cumsum(present, 1) - present                      # present neighbours below this dz
         np.testing.assert_array_equal(np.where(present, base[:, None] + rank, -1), col)
+
+
+def test_packed_weight_cache_follows_the_parameter_object():
+    """autograd._packed: one packed copy per live parameter, refreshed after an in-place update, dropped when the parameter dies
+    (no aliasing through a recycled id())."""
+    import gc
+    from unittest import mock
+    import treelearn_amd.autograd as ag
+    with mock.patch.object(ag.ops, "pack_weight", lambda w, dt: w.detach().clone()):
+        n0 = len(ag._packed_cache)
+        w = torch.nn.Parameter(torch.zeros(4, 1, 1, 1, 4))
+        a = ag._packed(w, torch.float32)
+        assert ag._packed(w, torch.float32) is a
+        with torch.no_grad():
+            w.add_(1)
+        assert ag._packed(w, torch.float32) is not a
+        assert len(ag._packed_cache) == n0 + 1
+        del w
+        gc.collect()
+        assert len(ag._packed_cache) == n0

@@ -146,3 +146,25 @@ def test_oracle_vs_handwritten_known_answers():
             cc, parent, child, _ = ov.rulebook_down(vc, case["shape"])
             out = osp.inverse_conv(torch.tensor(case["coarse_feats"]), w, parent, vc)
         np.testing.assert_array_equal(out.numpy(), np.asarray(case["expect"], np.float32), err_msg=case["name"])
+
+
+def test_g12_default_architecture_eval_and_train_loss(golden_dir):
+    """Golden g12 (the reference's default 7-level / 32-channel module tree on a batch of two crops): the oracle reproduces its
+    eval outputs and both losses."""
+    g = _load(golden_dir, "g12_train7.npz")
+    cfg = json.loads(str(g["cfg"]))
+    sd = om.random_state_dict(cfg["seed"], **cfg["cfg"])
+    keys = ["coords", "input_feats", "batch_ids", "semantic_labels", "offset_labels", "masks_off", "masks_sem"]
+    b = {k: T(g[f"in_{k}"]) for k in keys}
+    B = int(g["in_batch_size"])
+    kw = dict(voxel_size=cfg["voxel_size"], num_blocks=cfg["cfg"]["num_blocks"], spatial_shape=cfg["spatial_shape"])
+    out = om.forward(sd, b["coords"].numpy(), b["input_feats"].numpy(), b["batch_ids"].numpy(), B, **kw)
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        ref = g[f"eval_{k}"]
+        np.testing.assert_allclose(out[k].numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+    loss, _ = om.get_loss(out, b["semantic_labels"], b["offset_labels"], b["masks_off"], b["masks_sem"])
+    assert float(loss) == pytest.approx(float(g["eval_loss"]), rel=2e-4)
+    out = om.forward(sd, b["coords"].numpy(), b["input_feats"].numpy(), b["batch_ids"].numpy(), B, training=True, **kw)
+    loss, ld = om.get_loss(out, b["semantic_labels"], b["offset_labels"], b["masks_off"], b["masks_sem"])
+    assert float(loss) == pytest.approx(float(g["train_loss"]), rel=2e-4)
+    assert float(ld["offset_loss"]) == pytest.approx(float(g["train_offset_loss"]), rel=2e-4)

@@ -5,29 +5,34 @@ backward : dgrad = tl_conv_fwd over the transposed rulebook with W^T; wgrad = tl
            (reference: spconv's autograd functions behind SubMConv3d/SparseConv3d.forward,
            exercised by tools/training/train.py:40 `scaler.scale(loss).backward()`).
 """
+import weakref
+
 import torch
 
 from . import ops
 
-_packed_cache = {}
+_packed_cache = {}          # id(parameter) -> (weakref to it, (version, dtype, device, data_ptr), packed); evicted when the parameter dies
 
 
 def _packed(weight, dtype):
-    """[Cout,k,k,k,Cin] parameter -> [K,Cout,Cin] kernel layout, cached per (storage, version, dtype)."""
-    key = (weight.data_ptr(), weight._version, dtype, tuple(weight.shape))
+    """[Cout,k,k,k,Cin] parameter -> [K,Cout,Cin] kernel layout, cached per parameter OBJECT (the weak reference guards against a
+    recycled id) and invalidated by in-place updates (optimizer steps bump `_version`) or a dtype / device change."""
+    key = (weight._version, dtype, weight.device, weight.data_ptr())
     hit = _packed_cache.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2]
     w = ops.pack_weight(weight, dtype)
-    _packed_cache[id(weight)] = (key, w)
+    if hit is None or hit[0]() is not weight:
+        weakref.finalize(weight, _packed_cache.pop, id(weight), None)
+    _packed_cache[id(weight)] = (weakref.ref(weight), key, w)
     return w
 
 
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, ref):
+    def forward(ctx, feats, weight, ref, residual):
         x = feats.contiguous()
-        out = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out)
+        out = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual)
         ctx.save_for_backward(x, weight)
         ctx.ref = ref
         return out
@@ -36,13 +41,52 @@ class _SparseConvFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         from . import backward as bw
         x, weight = ctx.saved_tensors
-        gx, gw = bw.conv_backward(x, weight, ctx.ref, grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gw, None
+        grad_out = grad_out.contiguous()
+        gx, gw = bw.conv_backward(x, weight, ctx.ref, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, None, (grad_out if ctx.needs_input_grad[3] else None)      # d(out)/d(residual) = identity: no kernel
 
 
-def sparse_conv(feats, weight, ref):
-    """`ref`: treelearn_amd.backward.TableRef (rulebook + its transpose)."""
-    if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad):
-        return _SparseConvFn.apply(feats, weight, ref)
+def sparse_conv(feats, weight, ref, residual=None):
+    """`ref`: treelearn_amd.backward.TableRef (rulebook + its transpose); `residual` is added in the kernel's epilogue."""
+    if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)):
+        return _SparseConvFn.apply(feats, weight, ref, residual)
     x = feats.contiguous()
-    return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out)
+    return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual)
+
+
+class _BNReLUTrainFn(torch.autograd.Function):
+    """y = relu?(BatchNorm1d_train(x)) on the HIP kernels (tl_bn_train_stats + tl_affine_relu forward, tl_bn_train_bwd backward):
+    the `norm_fn(C), nn.ReLU()` pairs of reference blocks.py:55-70,102-123 / tree_learn.py:42-46 in training mode."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        x = x.contiguous()
+        track = bn.track_running_stats and bn.running_mean is not None
+        st = ops.bn_train_stats(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), bn.eps,
+                                0.1 if bn.momentum is None else bn.momentum,
+                                bn.running_mean if track else None, bn.running_var if track else None, bn.num_batches_tracked if track else None)
+        y = ops.affine_relu(x, st[2], st[3], relu)
+        ctx.save_for_backward(x, st)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        xx = x if x.dtype == torch.float32 else x.float()
+        dx, dgamma, dbeta = ops.bn_train_bwd(xx, dy, st, ctx.relu)
+        return dx.to(x.dtype), dgamma, dbeta, None, None
+
+
+def bn_relu_train(x, bn, relu=True):
+    """Training-mode BatchNorm1d `bn` (+ ReLU) of the feature matrix x on the HIP library."""
+    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu)
+
+
+def fusable_bn(module, x):
+    """True when `module` is a BatchNorm1d that the HIP training kernels serve for x (batch statistics, affine, CUDA, C % 4 == 0)."""
+    return (isinstance(module, torch.nn.BatchNorm1d) and module.training and module.affine and x.is_cuda and x.dim() == 2
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16))

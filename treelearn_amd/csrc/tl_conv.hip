@@ -247,6 +247,9 @@ extern int g_head_mode;                           // tl_head.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
+static int g_win = 1;                             // window kernel: 1 = levels with >= 64 channels in, 2 = also the 32-channel shapes, 0 = off
+extern int g_win_rows;                            // tl_conv_win.hip
+static int64_t g_win_min_rows = 65536;            // below this a 512-row tiling leaves most CUs idle
 
 extern "C" {
 
@@ -255,6 +258,9 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_depth")) { g_bf16_depth = (int)value; return TL_OK; }
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
+  if (!strcmp(key, "win")) { g_win = (int)value; return TL_OK; }
+  if (!strcmp(key, "win_rows")) { g_win_rows = (int)value; return TL_OK; }
+  if (!strcmp(key, "win_min_rows")) { g_win_min_rows = value; return TL_OK; }
   if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
   if (!strcmp(key, "streamq")) { g_streamq = (int)value; return TL_OK; }
   if (!strcmp(key, "stream_rb")) return tl_stream_set_rb((int)value);
@@ -317,6 +323,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   {
     if (p.one_hot && g_stream && a->K == 8) {                  // inverse convs: the stream kernel's gather-once form
       const int rc = tl_launch_conv_stream(p, TL_BF16, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
+    if (g_win && a->K == 27 && a->n_out >= g_win_min_rows && (a->Cin >= 64 && a->Cout >= 64 || g_win >= 2)) {
+      const int rc = tl_launch_conv_win(p, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (g_direct) {

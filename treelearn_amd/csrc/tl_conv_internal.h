@@ -151,6 +151,9 @@ int tl_stream_set_rb(int rb);
 // tl_conv_streamq.hip
 int tl_launch_conv_streamq(const ConvP& p, hipStream_t s);              // bf16, Cin % 64 == 0: quad-coalesced gathers + register transposition
 
+// tl_conv_win.hip
+int tl_launch_conv_win(const ConvP& p, hipStream_t s);                  // bf16, 27 taps: dz taps of a column share one LDS-staged row window
+
 // tl_conv_small.hip
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves
 int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s);   // Cin <= 8 (the 4-channel input conv)

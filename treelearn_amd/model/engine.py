@@ -71,6 +71,8 @@ class _Res:
 
 class _U:
     def __init__(self, ub, dtype):
+        assert len(ub.blocks) == 2 and (len(ub.nPlanes) == 1 or len(ub.blocks_tail) == 2), \
+            "the fused engine walks the reference's block_reps = 2 layout (tree_learn.py:41)"
         self.C = ub.nPlanes[0]
         self.blocks = [_Res(b, dtype) for b in ub.blocks._modules.values()]
         self.deeper = len(ub.nPlanes) > 1
@@ -181,4 +183,12 @@ class InferencePlan:
         else:
             x = ops.conv_fwd(vf, self.w_in, lv.nbr, lv.n)
             x = self.unet.run(x, geom, 0)
-        return ops.head_mlp(x, geom.v2p, self.so, self.ho, self.w1, self.b1, self.w2, self.b2, want_backbone)
+        if x.shape[1] in ops.HEAD_WIDTHS:
+            return ops.head_mlp(x, geom.v2p, self.so, self.ho, self.w1, self.b1, self.w2, self.b2, want_backbone)
+        # head widths the fused kernel has no instantiation for (the reference accepts any `channels`): output_layer through
+        # tl_affine_relu, the v2p gather and both folded MLPs as plain device matmuls
+        bb = ops.affine_relu(x, self.so, self.ho, True).float().index_select(0, geom.v2p)
+        h = torch.relu(torch.einsum("nc,moc->mno", bb, self.w1) + self.b1[:, None, :])              # [2, N, C]
+        logits = h[0] @ self.w2[:2].T + self.b2[:2]
+        offsets = h[1] @ self.w2[2:].T + self.b2[2:]
+        return (bb if want_backbone else None), logits, offsets

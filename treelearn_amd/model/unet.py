@@ -27,6 +27,21 @@ class MLP(nn.Sequential):
         modules.append(nn.Linear(in_channels, out_channels))
         super().__init__(*modules)
 
+    def forward(self, x):
+        from ..autograd import bn_relu_train, fusable_bn
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if fusable_bn(m, x):                               # training-mode BatchNorm1d + ReLU on the HIP kernels
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = bn_relu_train(x, m, relu)
+                i += int(relu)
+            else:
+                x = m(x)
+            i += 1
+        return x
+
     def init_weights(self):
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -64,8 +79,9 @@ class ResidualBlock(SparseModule):
 
     def forward(self, input):
         identity = input.replace_feature(input.features)
-        output = self.conv_branch(input)
-        return output.replace_feature(output.features + self.i_branch(identity).features)
+        res = self.i_branch(identity).features
+        last = len(self.conv_branch) - 1
+        return self.conv_branch[last](self.conv_branch(input, stop=last), residual=res)      # the add rides in the last conv's epilogue
 
 
 class UBlock(nn.Module):

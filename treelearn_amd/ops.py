@@ -11,6 +11,8 @@ from . import _hip
 # (start, end, meta) is appended -- bench.py's live per-kernel timing.  None = no overhead.
 PROFILE = None
 
+HEAD_WIDTHS = (8, 16, 32, 64)      # backbone widths tl_head_mlp is instantiated for
+
 
 def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Reference conv weight [Cout,k,k,k,Cin] (spconv layout) -> kernel layout [K,Cout,Cin] in `dtype`."""
@@ -133,3 +135,42 @@ def compact_rows(x: torch.Tensor, mask: torch.Tensor):
     ws = torch.empty(int(L.tl_compact_ws_words(n)), dtype=torch.int32, device=x.device)
     _hip.check(L.tl_compact_rows(_hip.ptr(x), C, _hip.ptr(m8), n, _hip.ptr(out), _hip.ptr(count), _hip.ptr(ws), _hip.stream()), "tl_compact_rows")
     return out, count
+
+
+def affine_relu(x, scale, shift, relu, out_dtype=None):
+    """y = relu?(x * scale + shift) over the rows of x (tl_affine_relu); x and y may differ in dtype only through `out_dtype`
+    == x.dtype (the kernel is single-dtype), so a bf16 result of an fp32 input is produced by the caller's cast."""
+    L = _hip.lib()
+    _hip.require_cuda(x, "x")
+    y = torch.empty_like(x)
+    _hip.check(L.tl_affine_relu(_hip.ptr(x), x.stride(0), _hip.ptr(y), y.stride(0), x.shape[0], x.shape[1], _hip.dtype_code(x.dtype),
+                                _hip.ptr(scale), _hip.ptr(shift), int(bool(relu)), _hip.stream()), "tl_affine_relu")
+    return y
+
+
+def bn_train_stats(x, gamma, beta, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """Batch statistics of x [n, C] -> (mean, rstd, scale, shift), running statistics updated in place (tl_bn_train_stats)."""
+    L = _hip.lib()
+    _hip.require_cuda(x, "x")
+    n, C = x.shape
+    dev = x.device
+    ws = torch.empty(int(L.tl_bn_ws_doubles(n, C)), dtype=torch.float64, device=dev)
+    st = torch.empty((4, C), dtype=torch.float32, device=dev)
+    _hip.check(L.tl_bn_train_stats(_hip.ptr(x), x.stride(0), n, C, _hip.dtype_code(x.dtype), _hip.ptr(gamma), _hip.ptr(beta), float(eps), float(momentum),
+                                   _hip.ptr(ws), _hip.ptr(st[0]), _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), _hip.ptr(running_mean),
+                                   _hip.ptr(running_var), _hip.ptr(num_batches_tracked), _hip.stream()), "tl_bn_train_stats")
+    return st
+
+
+def bn_train_bwd(x, dy, st, relu):
+    """(dx, dgamma, dbeta) of y = relu?(batchnorm_train(x)) given dy (tl_bn_train_bwd); st = bn_train_stats' result."""
+    L = _hip.lib()
+    n, C = x.shape
+    dev = x.device
+    ws = torch.empty(int(L.tl_bn_ws_doubles(n, C)), dtype=torch.float64, device=dev)
+    dx = torch.empty((n, C), dtype=torch.float32, device=dev)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    _hip.check(L.tl_bn_train_bwd(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(dy), dy.stride(0), _hip.dtype_code(dy.dtype), n, C,
+                                 _hip.ptr(st[0]), _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), int(bool(relu)), _hip.ptr(ws),
+                                 _hip.ptr(dgb[0]), _hip.ptr(dgb[1]), _hip.ptr(dx), dx.stride(0), _hip.stream()), "tl_bn_train_bwd")
+    return dx, dgb[0], dgb[1]

@@ -58,15 +58,27 @@ class SparseSequential(SparseModule):
     def __len__(self):
         return len(self._modules)
 
-    def forward(self, x):
-        for module in self._modules.values():
+    def forward(self, x, stop=None):
+        """`stop`: run only the first `stop` modules (the caller runs the rest itself, e.g. the last conv with its residual fused)."""
+        from .autograd import bn_relu_train, fusable_bn      # late import (autograd depends on ops)
+        mods = list(self._modules.values())[:stop]
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if isinstance(module, SparseModule):
                 x = module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.features.shape[0] != 0:
-                    x = x.replace_feature(module(x.features))
+                    if fusable_bn(module, x.features):
+                        # training-mode BatchNorm1d (+ the ReLU behind it) on the HIP kernels instead of ATen's
+                        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                        x = x.replace_feature(bn_relu_train(x.features, module, relu))
+                        i += int(relu)
+                    else:
+                        x = x.replace_feature(module(x.features))
             else:
                 x = module(x)
+            i += 1
         return x
 
 
@@ -99,14 +111,19 @@ class SparseConvolution(SparseModule):
     def _table(self, x):
         raise NotImplementedError
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` [n_out, Cout]: added to the conv result -- inside the kernel's epilogue when the dtypes allow it (the
+        `output.features + i_branch(identity).features` of reference blocks.py:76-78 without a separate add pass)."""
         from .autograd import sparse_conv                  # late import (autograd depends on ops)
         ref, out_level = self._table(x)
         amp = SparseConvolution.amp_dtype
         fin = x.features if (amp is None or x.features.dtype == amp) else x.features.to(amp)
-        feats = sparse_conv(fin, self.weight, ref)
+        fuse = residual is not None and residual.dtype == fin.dtype and residual.is_cuda
+        feats = sparse_conv(fin, self.weight, ref, residual if fuse else None)
         if amp is not None:
             feats = feats.float()
+        if residual is not None and not fuse:
+            feats = feats + residual
         if self.bias is not None:
             feats = feats + self.bias
         lv = x.geometry.levels[out_level]

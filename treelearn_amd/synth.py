@@ -113,15 +113,15 @@ def make_batch(tiles, inner_square_edge_length=8.0):
     for b, t in enumerate(tiles):
         xyz = t["points"]; il = t["instance_label"].astype(np.int64)
         sl = np.where(il == 0, 1, 0).astype(np.int64)
-        pos = np.ones_like(xyz)
-        valid = np.zeros(len(xyz), bool)
-        for i in np.unique(il):
-            if i == 0:
-                continue
-            idx = np.where(il == i)[0]
-            tp = xyz[idx]
-            lo = tp[tp[:, 2] <= tp[:, 2].min() + 0.5]
-            pos[idx] = lo.mean(axis=0); valid[idx] = True
+        # tree base per instance = mean of its points within 0.5 m of its lowest point (one grouped pass, float64 sums)
+        uniq, inv = np.unique(il, return_inverse=True)
+        zmin = np.full(len(uniq), np.inf, np.float32)
+        np.minimum.at(zmin, inv, xyz[:, 2])
+        low = xyz[:, 2] <= zmin[inv] + np.float32(0.5)
+        cnt = np.bincount(inv[low], minlength=len(uniq)).astype(np.float64)
+        base = np.stack([np.bincount(inv[low], weights=xyz[low, d].astype(np.float64), minlength=len(uniq)) / np.maximum(cnt, 1) for d in range(3)], 1)
+        valid = (il != 0)
+        pos = np.where(valid[:, None], base[inv].astype(np.float32), np.float32(1.0))
         mi = np.linalg.norm(xyz[:, :2], ord=np.inf, axis=1) <= inner_square_edge_length / 2
         xyzs.append(xyz); feats.append(t["feat"]); bids.append(np.full(len(xyz), b, np.int64))
         inst.append(il); sem.append(sl); offl.append((pos - xyz).astype(np.float32))

@@ -121,6 +121,10 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":
         nf = 1
     cstreams = _compute_streams(nf) if (use_gpu and nf > 1) else []
+    restore_bb = None
+    if hasattr(model, "return_backbone_feats") and not return_backbone_feats:
+        restore_bb = model.return_backbone_feats                        # skip the [N, 32] backbone output (never used downstream, reference
+        model.return_backbone_feats = False                             # tools/pipeline/pipeline.py only saves it); result 6 is then [n, 0]
     with torch.no_grad():
         model.eval()
         if cstreams and hasattr(model, "ensure_plan"):
@@ -171,6 +175,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     if cstreams:
         for cs in cstreams:
             main_stream.wait_stream(cs)
+    if restore_bb is not None:
+        model.return_backbone_feats = restore_bb
     if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
         res = tuple(np.zeros((0,), np.float32) for _ in outs)
     elif keep_on_device:
