@@ -8,8 +8,10 @@
  *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch-ROCm caching
  *     allocator in our host code); the library never allocates or frees device memory;
  *   - every call takes the hipStream_t to enqueue on (as void*) and returns immediately;
- *   - return value: 0 = TL_OK, negative = error (tl_error_string); no exceptions, no
- *     global state; calls on one stream must not be issued concurrently;
+ *   - return value: 0 = TL_OK, negative = error (tl_error_string); no exceptions; the only
+ *     process-wide state is the set of developer switches behind tl_set_tuning (kernel-family
+ *     selection for A/B runs and tests; results do not depend on them beyond re-association);
+ *     calls on one stream must not be issued concurrently;
  *   - "table" = rulebook in tap-major layout i32[K][n_out], entry = input row or -1
  *     (SURVEY.md Appendix F canonical form, transposed for coalesced access).
  */
@@ -34,8 +36,9 @@ enum {
 enum { TL_F32 = 0, TL_BF16 = 1 };
 
 int tl_version(void);
-/* Developer tuning knobs ("bf16_depth": register prefetch depth 1..4; "small_rows": row threshold of the
- * split-tap small-level kernel).  Not needed for correct results. */
+/* Developer tuning knobs, process-wide ("win" / "direct" / "stream" / "streamq": enable a conv kernel family; "win_rows": window
+ * rows of the window kernel; "win_min_rows" / "small_rows": row thresholds; "bf16_depth": register prefetch depth 1..4).  Not
+ * needed for correct results; the parity tests use them to force every family over the same data. */
 int tl_set_tuning(const char* key, int64_t value);
 const char* tl_error_string(int code);
 

@@ -964,7 +964,14 @@ def test_bn_train_kernels_vs_torch(n, C, relu):
     y = bn_relu_train(x, bn, relu)
     y.backward(gy)
     xr = x.detach().double().requires_grad_(True)
-    yr = ref(xr); yr = torch.relu(yr) if relu else yr
+    # ReLU as a fixed mask taken from OUR output: the kink is a discontinuity of the gradient, and an fp32 y within rounding of
+    # zero may fall on the other side than the fp64 reference's (about one element in 10^7 -- enough to move a gradient sum)
+    yl = ref(xr)
+    if relu:
+        assert float((torch.relu(yl) - yl * (y.detach() > 0)).abs().max()) < 1e-5 * float(yl.abs().max())     # masks differ only at the kink
+        yr = yl * (y.detach() > 0).double()
+    else:
+        yr = yl
     yr.backward(gy.double())
     tol = lambda a: 2e-5 * max(float(a.abs().max()), 1e-6)                          # noqa: E731
     assert float((y.double() - yr).abs().max()) < tol(yr)

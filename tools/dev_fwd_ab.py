@@ -3,7 +3,7 @@
 import sys, os, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import model as om
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd import _hip
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import CONFIGS, make_batch, make_tile
@@ -12,7 +12,7 @@ cfg = CONFIGS["config2"]
 b = make_batch([make_tile(**cfg, seed=0)])
 g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=cfg["voxel"], compute_dtype=torch.bfloat16)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 modes = [int(a) for a in sys.argv[1:]] or [0, 14, 15, 13]
 with torch.no_grad():
     for _ in range(5): model(g, return_loss=False)

@@ -1,14 +1,14 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import model as om
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import make_batch, make_tile
 t = make_tile(extent=40, voxel=0.1, n_trees=64, fill=0.10, seed=0)
 b = make_batch([t], inner_square_edge_length=8.0)
 b = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 def T(): torch.cuda.synchronize(); return time.time()
 with torch.no_grad():
     for rep in range(3):

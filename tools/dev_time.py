@@ -2,7 +2,7 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import model as om
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd import ops
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.geometry import build_geometry
@@ -19,7 +19,7 @@ cfg = CONFIGS[name]
 SS = [500, 500, 1000] if cfg["voxel"] >= 0.1 else None
 t0 = time.time(); tile = make_tile(**cfg, seed=0); batch = make_batch([tile]); print("tile", time.time() - t0, flush=True)
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=SS, voxel_size=cfg["voxel"], compute_dtype=dtype)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 torch.cuda.synchronize(); print("model ready", flush=True)
 for it in range(3):

@@ -2,7 +2,7 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import model as om
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import make_batch, make_tile
 E = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
@@ -10,7 +10,7 @@ tiles = [make_tile(extent=E, voxel=0.1, n_trees=int(64 * (E / 40) ** 2), fill=0.
 batch = make_batch(tiles)
 dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32          # bf16 = autocast-like mixed precision
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=dt)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().train()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().train()
 opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3)
 g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 print("points", g["coords"].shape[0], flush=True)

@@ -3,7 +3,7 @@ deep levels (36 small launches) and the geometry leave most CUs idle, which the 
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import model as om
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import CONFIGS, make_batch, make_tile
 cfg = CONFIGS["config2"]
@@ -12,7 +12,7 @@ for seed in range(2):
     b = make_batch([make_tile(**cfg, seed=seed)])
     gs.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()})
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=cfg["voxel"], compute_dtype=torch.bfloat16)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 NS = [int(a) for a in sys.argv[1:]] or [2, 3, 4]
 st = [torch.cuda.Stream() for _ in range(max(NS))]
 K = 48

@@ -3,7 +3,7 @@ already on the device, with (TL_LOOP_PIPELINE=1, default) and without the one-ti
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import model as om                      # deterministic random weights only
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import make_batch, make_tile
 from treelearn_amd.util import get_pointwise_preds
@@ -16,7 +16,7 @@ for s in range(6):
     b = make_batch([t], inner_square_edge_length=8.0)
     gt.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()})
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 get_pointwise_preds(model, gt, dict(voxel_size=0.1))
 for rep in range(3):
     for mode in ("1", "0"):

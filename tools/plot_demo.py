@@ -6,7 +6,7 @@ grouping -> k-NN fill -> back to the raw points.  Synthetic plot, random-init we
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import model as om                      # deterministic random weights only
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import make_tile
 from treelearn_amd.util import get_instances, get_pointwise_preds
@@ -22,7 +22,7 @@ t = make_tile(extent=E, voxel=0.1, n_trees=int(64 * (E / 40) ** 2), fill=0.10, s
 rng = np.random.default_rng(0)
 raw = np.vstack([t["points"].astype(np.float64) + rng.normal(0, 0.02, size=t["points"].shape) for _ in range(2)])
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 T = {}
 def lap(name, t0):
     torch.cuda.synchronize(); T[name] = time.time() - t0; return time.time()

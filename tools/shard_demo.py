@@ -3,7 +3,7 @@ the plain single-process loop:   python -m torch.distributed.run --nproc-per-nod
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
-from oracle import model as om                      # deterministic random weights only
+from treelearn_amd.synth import random_state_dict
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import make_batch, make_tile
 from treelearn_amd.util.pipeline import get_pointwise_preds
@@ -18,7 +18,7 @@ for s in range(5):
     t["center"] = np.array([8.0 * s, 0.0, 0.0])
     tiles.append(make_batch([t], inner_square_edge_length=6.0))
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
-model.load_state_dict(om.random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
+model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().eval()
 res = get_pointwise_preds_sharded(model, tiles, dict(voxel_size=0.1))
 if dist.get_rank() == 0:
     ref = get_pointwise_preds(model, tiles, dict(voxel_size=0.1))

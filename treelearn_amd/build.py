@@ -1,6 +1,10 @@
 """Build libtreelearn_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m treelearn_amd.build [--force]
+    python -m treelearn_amd.build [--force] [--dev]
+
+`--dev` also compiles the developer variants (ablation / segment-timer instantiations of the conv kernels, the gather
+micro-benchmarks of tl_dev.hip and their `tl_dev_*` hooks, which tools/dev_*.py drive); the default (release) library contains
+none of them.
 
 The library is built IN-TREE (treelearn_amd/lib/) so it travels with the repo snapshot to the
 GPU box; it is git-ignored.
@@ -18,8 +22,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+def sources(dev=False):
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (dev or f != "tl_dev.hip"))
 
 
 def _stale(target, deps):
@@ -29,19 +33,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, dev=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj_dev" if dev else "obj")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "treelearn_hip.h"))
-    srcs = sources()
+    srcs = sources(dev)
+    flags = FLAGS + (["-DTL_DEV"] if dev else [])
+    stamp = os.path.join(LIBDIR, ".flavour")
+    flavour = "dev" if dev else "release"
+    relink = not os.path.exists(stamp) or open(stamp).read() != flavour
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
 
     def compile_one(so):
         s, o = so
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -50,13 +58,14 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         changed = list(ex.map(compile_one, zip(srcs, objs)))
-    if force or any(changed) or _stale(LIB, objs):
+    if force or relink or any(changed) or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        open(stamp, "w").write(flavour)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

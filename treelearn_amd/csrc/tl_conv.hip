@@ -14,6 +14,7 @@
 // lands on 16 different 16-B slots (36*r mod 64 is a permutation of multiples of 4 for r mod 16),
 // i.e. conflict-free for the b128 lane groups of MI355X_MICROARCH.md §LDS.
 #include "tl_conv_internal.h"
+#include <atomic>
 #include <string.h>
 
 namespace {
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
 template <int NB>
 int launch_mfma_f32(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)p.K * TM * 4 + 16 + 2 * (size_t)TM * LDA * 4 + 2 * (size_t)NB * 32 * LDA * 4;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma_f32<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;

@@ -16,6 +16,7 @@
 //  * Epilogue: accumulators are transposed through LDS (fp32) so that residual loads and output stores
 //    are full 16-B vectors along the row; one rounding to bf16.
 #include "tl_conv_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -279,7 +280,7 @@ int launch_b(const ConvP& p, hipStream_t s) {
   const size_t epi_b = 4 * (size_t)32 * (NB * 32 + 4) * 4;
   const size_t lds = (size_t)p.K * TM * 4 + 128 + (size_t)p.Cin * 8 + (main_b > epi_b ? main_b : epi_b);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<NB, U, D, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;

@@ -14,6 +14,7 @@
 //     < 10 % of the kernel time, and skipping would need divergent control flow around the loads.
 // Deterministic (fixed summation order).  Epilogue: LDS transposition, 16-B stores, residual, up to three views.
 #include "tl_conv_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -312,7 +313,7 @@ int launch(const ConvP& p, hipStream_t s) {
   constexpr int UB = BF16 ? 64 : 128;
   const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
@@ -332,6 +333,7 @@ int g_direct_abl = 0;
 template <bool BF16, int K, int G>
 int dispatch(const ConvP& p, hipStream_t s) {
   const int nb = p.Cout / 32, un = p.Cin / 32;
+#ifdef TL_DEV
   if constexpr (BF16 && K == 27) {
     if (g_direct_abl && g_direct_abl < 14 && nb == 1 && un == 1) {
       switch (g_direct_abl) {
@@ -348,13 +350,16 @@ int dispatch(const ConvP& p, hipStream_t s) {
       }
     }
   }
+#endif
   const size_t wbytes = (size_t)K * p.Cout * p.Cin * (BF16 ? 2 : 4);
   if constexpr (BF16 && K == 27) {
     // column-form rulebook (level 1), its words requested one tile ahead: 32 -> 32 0.200 -> 0.195 ms on top of the 0.243 -> 0.226 of
     // the 40-B form itself; 64 -> 32 0.51 -> 0.33 ms (without the look-ahead the decode in front of its gathers had made it slower)
     if (p.ctab && (g_direct_abl == 0 || g_direct_abl >= 14) && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 0, true>(p, s);
     if (p.ctab && g_direct_abl != 14 && nb == 1 && un == 2) return launch<true, 27, 1, 2, G, 8, 0, true>(p, s);
+#ifdef TL_DEV
     if (p.ctab && g_direct_abl == 13 && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 32, true>(p, s);   // rulebook words not requested ahead
+#endif
   }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \
@@ -369,13 +374,15 @@ int dispatch(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-// developer hook, not part of the C ABI: mode 0..99 = ablation variant of the 32->32 kernel, 1000 / 1001 = tile walk of every direct launch
+#ifdef TL_DEV
+// developer hook (dev build only), not part of the C ABI: mode 0..99 = ablation variant of the 32->32 kernel, 1000 / 1001 = tile walk of every direct launch
 extern "C" int tl_dev_direct_abl(int mode) { if (mode >= 1000) g_direct_walk = mode - 1000; else g_direct_abl = mode; return TL_OK; }
 extern "C" int tl_dev_direct_tm(unsigned long long* out8) {          // read and clear the segment timers of ablation mode 10
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tmd), sizeof(g_tmd)) != hipSuccess) return TL_ERR_LAUNCH;
   unsigned long long z[8] = {0};
   return hipMemcpyToSymbol(HIP_SYMBOL(g_tmd), z, sizeof(z)) == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
+#endif
 
 // Eligibility (beyond the tile kernel's alignment rules): no gather-side prologue, whole weight tensor + epilogue
 // scratch within LDS, input view below 4 GB.  Returns TL_ERR_UNSUPPORTED when the shape is not covered.

@@ -13,6 +13,7 @@
 // 4 SIMDs x 1 KB / 32 clk = 128 B/clk = the whole LDS read rate of a CU.  With RB = 2 each weight fragment feeds two
 // MFMAs (two row blocks), halving the LDS traffic per flop.
 #include "tl_conv_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -210,7 +211,7 @@ int launch(ConvP p, hipStream_t s) {
   const size_t wt = 2 * (size_t)NB * 32 * (UN * 32 * EB + 16), ep = (size_t)WAVES * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
@@ -262,6 +263,7 @@ int dispatch(const ConvP& p, hipStream_t s) {
 int tl_stream_set_rb(int rb) { if (rb >= 100) g_stream_da = rb - 100; else g_stream_rb = rb; return TL_OK; }
 
 // Developer hook (not part of the C ABI): switch the per-segment cycle counters on/off, read and clear them.
+#ifdef TL_DEV
 extern "C" int tl_dev_stream_tm(int enable, unsigned long long* out8) {
   g_stream_tm = enable;
   if (out8) {
@@ -271,6 +273,7 @@ extern "C" int tl_dev_stream_tm(int enable, unsigned long long* out8) {
   }
   return TL_OK;
 }
+#endif
 
 int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s) {
   if (p.in_scale || p.in_relu) return TL_ERR_UNSUPPORTED;

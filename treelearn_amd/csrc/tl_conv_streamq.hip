@@ -20,6 +20,7 @@
 // Weight streaming, double buffering, request order (weights of tap t at step t - WA before that step's gathers) and the
 // epilogue are those of tl_conv_stream.hip.  Deterministic; all K taps contracted.
 #include "tl_conv_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -253,7 +254,7 @@ int launch(ConvP p, hipStream_t s) {
   const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)W * K * 32 * RB * 4, ep = (size_t)W * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
@@ -264,11 +265,15 @@ int launch(ConvP p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
+#ifdef TL_DEV
 int g_tm_on = 0;
+#endif
 
 }  // namespace
 
-// Developer hook (not part of the C ABI): per-segment cycle counters of the 64->64 shape on/off, read and clear.
+#ifdef TL_DEV
+// Developer hook (dev build only, `python -m treelearn_amd.build --dev`; not part of the C ABI): per-segment cycle counters of
+// the 64->64 shape on/off, read and clear.
 extern "C" int tl_dev_streamq_tm(int enable, unsigned long long* out8) {
   g_tm_on = enable;
   if (out8) {
@@ -278,6 +283,7 @@ extern "C" int tl_dev_streamq_tm(int enable, unsigned long long* out8) {
   }
   return TL_OK;
 }
+#endif
 
 int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
   if (p.in_scale || p.in_relu || p.Cin % 64 || p.Cout % 32) return TL_ERR_UNSUPPORTED;
@@ -285,6 +291,7 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll)) return TL_ERR_UNSUPPORTED;
   const int nb = p.Cout / 32, pn = p.Cin / 64;
   if (p.K == 27) {
+#ifdef TL_DEV
     if (g_tm_on && nb == 2 && pn == 1) {
       switch (g_tm_on) {
         case 1: return launch<27, 2, 1, 2, 8, 1, 16>(p, s);
@@ -302,6 +309,7 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
         case 15: return launch<27, 2, 1, 2, 4, 2, 2>(p, s);
       }
     }
+#endif
     if (nb == 2 && pn == 1) return launch<27, 2, 1, 2>(p, s);
     if (nb == 2 && pn == 2) return launch<27, 2, 2, 2>(p, s);
     if (nb == 4 && pn == 2) return launch<27, 4, 2, 2>(p, s);

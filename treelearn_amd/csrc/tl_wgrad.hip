@@ -212,7 +212,9 @@ static int g_wgrad_bf16_mfma = 1;          // developer A/B (tl_dev_wgrad_mode):
 
 extern "C" {
 
+#ifdef TL_DEV
 int tl_dev_wgrad_mode(int bf16_mfma) { g_wgrad_bf16_mfma = bf16_mfma; return TL_OK; }
+#endif
 
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
   const int64_t nparts = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves) * kWaves;
