@@ -176,6 +176,43 @@ def _host_cores():
     return n
 
 
+@pytest.mark.parametrize("level,cin,cout", [(1, 64, 64), (1, 128, 64), (2, 96, 96), (2, 192, 96), (0, 32, 32)])
+def test_config2_window_kernel_on_real_rulebooks(tile2, level, cin, cout):
+    """The opt-in window form of the 27-tap convs (tl_conv_win: dz taps of a column from one LDS-staged row window, column-form
+    rulebook) on the real rulebooks of the full tile, against the oracle on sampled rows and against the default kernels."""
+    from treelearn_amd import _hip, ops
+    L = _hip.lib()
+    old = _hip.WIN_KERNEL
+    _hip.WIN_KERNEL = True                                     # geometry emits the column form on every big level
+    try:
+        g = _geometry(tile2, 0.1)
+    finally:
+        _hip.WIN_KERNEL = old
+    lv = g.levels[level]
+    assert getattr(lv.nbr, "_tl_compact", None) is not None
+    gen = torch.Generator(device="cuda"); gen.manual_seed(level * 77 + cin)
+    w = torch.randn((cout, 3, 3, 3, cin), device="cuda", generator=gen) / (cin * 27) ** 0.5
+    x = torch.randn((lv.n, cin), device="cuda", generator=gen).bfloat16()
+    res = torch.randn((lv.n, cout), device="cuda", generator=gen).bfloat16()
+    wp = ops.pack_weight(w, torch.bfloat16)
+    ref_kernel = ops.conv_fwd(x, wp, lv.nbr, lv.n, residual=res)
+    outs = []
+    try:
+        _hip.check(L.tl_set_tuning(b"win", 2), "win"); _hip.check(L.tl_set_tuning(b"win_min_rows", 0), "wmr")
+        for rows, ct in ((0, 1), (0, 0), (512, 1)):
+            _hip.check(L.tl_set_tuning(b"win_rows", rows), "win_rows"); _hip.check(L.tl_set_tuning(b"win_ct", ct), "win_ct")
+            outs.append(ops.conv_fwd(x, wp, lv.nbr, lv.n, residual=res))
+    finally:
+        for k, v in ((b"win", 1 if _hip.WIN_KERNEL else 0), (b"win_min_rows", 65536), (b"win_rows", 0), (b"win_ct", 1)):
+            _hip.check(L.tl_set_tuning(k, v), "restore")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])          # column form / table form / tile size: same arithmetic
+    rows = torch.randperm(lv.n, device="cuda", generator=gen)[:4096].sort().values
+    sub = lv.nbr[:, rows].T.contiguous().cpu().numpy()
+    ref = osp.conv_table(x.float().cpu(), w.bfloat16().float().cpu(), sub).numpy() + res[rows].float().cpu().numpy()
+    assert rel_err(outs[0][rows].float().cpu().numpy(), ref) < 1.2e-2
+    assert rel_err(outs[0].float().cpu().numpy(), ref_kernel.float().cpu().numpy()) < 1.2e-2
+
+
 @pytest.mark.timeout(1200)
 def test_config2_forward_fp32_vs_oracle_end_to_end():
     """End-to-end parity at workload scale: the fp32 forward of a 28x28 m tile of the config-2 generator (0.9 M points; all seven

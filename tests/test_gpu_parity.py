@@ -897,7 +897,7 @@ def test_conv_window_kernel_vs_oracle(cin, cout, n_out, kind):
     """tl_conv_win (dz taps of a column served from one LDS-staged row window) against the oracle: 'shifted' tables keep every
     neighbour near its output row (the in-window path, as on real rulebooks), 'random' tables put every neighbour outside the
     window (the global-memory slow path), 'mixed' interleaves both and leaves whole (row, group) blocks absent; ragged row counts,
-    residual and three output views; same result with the 768-row window."""
+    residual and three output views; same result from the 4-wave / 256-row and the 8-wave / 512-row form."""
     from treelearn_amd import _hip, ops
     rng = np.random.default_rng(cin + 3 * cout + n_out)
     d = _dev()
@@ -927,7 +927,7 @@ def test_conv_window_kernel_vs_oracle(cin, cout, n_out, kind):
     outs = {}
     try:
         _hip.check(L.tl_set_tuning(b"win", 2), "win"); _hip.check(L.tl_set_tuning(b"win_min_rows", 0), "win_min_rows")
-        for wr in (640, 768):
+        for wr in (0, 512):
             _hip.check(L.tl_set_tuning(b"win_rows", wr), "win_rows")
             wide = torch.zeros((n_out, 2 * cout), dtype=torch.bfloat16, device=d)
             o3 = torch.empty((n_out, cout), dtype=torch.bfloat16, device=d)
@@ -937,13 +937,13 @@ def test_conv_window_kernel_vs_oracle(cin, cout, n_out, kind):
             assert rel_err(wide[:, cout:].float().cpu().numpy(), np.maximum(y * s2 + h2, 0)) < 8e-3
             assert torch.equal(o3, out) and float(wide[:, :cout].abs().max()) == 0.0
             outs[wr] = out
-        assert torch.equal(outs[640], outs[768])                 # the window size changes where rows come from, never the arithmetic
+        assert torch.equal(outs[0], outs[512])                   # tile / window size changes where rows come from, never the arithmetic
         _hip.check(L.tl_set_tuning(b"win", 0), "win")
         ref = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, residual=T(res, torch.bfloat16))
-        assert rel_err(outs[640].float().cpu().numpy(), ref.float().cpu().numpy()) < 8e-3
+        assert rel_err(outs[0].float().cpu().numpy(), ref.float().cpu().numpy()) < 8e-3
     finally:
-        _hip.check(L.tl_set_tuning(b"win", 1), "win"); _hip.check(L.tl_set_tuning(b"win_min_rows", 65536), "win_min_rows")
-        _hip.check(L.tl_set_tuning(b"win_rows", 640), "win_rows")
+        _hip.check(L.tl_set_tuning(b"win", 1 if _hip.WIN_KERNEL else 0), "win"); _hip.check(L.tl_set_tuning(b"win_min_rows", 65536), "win_min_rows")
+        _hip.check(L.tl_set_tuning(b"win_rows", 0), "win_rows")
 
 
 @pytest.mark.parametrize("n,C,relu", [(5, 32, True), (1000, 32, True), (70001, 64, True), (33333, 448, True), (4097, 96, False), (257, 224, True)])

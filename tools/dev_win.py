@@ -9,6 +9,7 @@ from treelearn_amd.synth import CONFIGS, make_batch, make_tile
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 b = make_batch([make_tile(**CONFIGS["config2"], seed=0)])
+_hip.WIN_KERNEL = True                      # column-form rulebooks on every big level
 g = build_geometry(b["coords"].cuda(), b["batch_ids"].cuda(), 1, 0.1, 7, [500, 500, 1000])
 L = _hip.lib()
 def tune(**kw):
@@ -33,10 +34,10 @@ for level, cin, cout in ((1, 64, 64), (1, 128, 64), (2, 96, 96), (2, 192, 96), (
     run = lambda: ops.conv_fwd(x, w, lv.nbr, lv.n, residual=res, out2=(o2, sc, sh, True))
     line = f"level {level + 1} {cin:3d}->{cout:3d} N={lv.n:8d}:"
     tune(win=0); ref = run().float(); t0 = timeit(run); line += f"  gather kernels {t0:.3f} ms"
-    for wr in (640, 768):
-        tune(win=2, win_min_rows=0, win_rows=wr)
+    for wr, ct in ((0, 1), (0, 0), (512, 1)):
+        tune(win=2, win_min_rows=0, win_rows=wr, win_ct=ct)
         out = run().float(); t = timeit(run)
         err = float((out - ref).abs().max() / ref.abs().max())
-        line += f" | window {wr}: {t:.3f} ms (x{t0 / t:.2f}, diff {err:.1e})"
-    tune(win=1, win_min_rows=65536, win_rows=640)
+        line += f" | window {'4w/256' if wr == 0 else '8w/512'}{' ct' if ct else ''}: {t:.3f} ms (x{t0 / t:.2f}, diff {err:.1e})"
+    tune(win=0, win_min_rows=65536, win_rows=0, win_ct=1)
     print(line, flush=True)

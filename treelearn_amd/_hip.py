@@ -12,6 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtreelearn_hip.so")
 
 TL_F32, TL_BF16 = 0, 1
+# opt-in: the window form of the 27-tap bf16 convs (csrc/tl_conv_win.hip) for levels of >= 65536 voxels; measured at parity with
+# the register-gather kernels on the config-2 tile, so the default dispatch does not use it
+WIN_KERNEL = os.environ.get("TL_CONV_WIN") == "1"
 _c = ctypes
 _vp, _i64, _i32, _f32 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_float
 
@@ -102,6 +105,8 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+        if WIN_KERNEL:
+            L.tl_set_tuning(b"win", 1)
         _lib = L
     return _lib
 

@@ -76,9 +76,8 @@ class _BNReLUTrainFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
-        xx = x if x.dtype == torch.float32 else x.float()
-        dx, dgamma, dbeta = ops.bn_train_bwd(xx, dy, st, ctx.relu)
-        return dx.to(x.dtype), dgamma, dbeta, None, None
+        dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu)               # dx in x's dtype (bf16 stays bf16 under mixed precision)
+        return dx, dgamma, dbeta, None, None
 
 
 def bn_relu_train(x, bn, relu=True):

@@ -248,8 +248,8 @@ extern int g_head_mode;                           // tl_head.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
-static int g_win = 1;                             // window kernel: 1 = levels with >= 64 channels in, 2 = also the 32-channel shapes, 0 = off
-extern int g_win_rows;                            // tl_conv_win.hip
+static int g_win = 0;                             // window kernel (opt-in, TL_CONV_WIN=1: measured at parity with the gather kernels): 1 = shapes with >= 64 channels, 2 = all, 0 = off
+extern int g_win_rows, g_win_ct;                  // tl_conv_win.hip
 static int64_t g_win_min_rows = 65536;            // below this a 512-row tiling leaves most CUs idle
 
 extern "C" {
@@ -261,6 +261,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
   if (!strcmp(key, "win")) { g_win = (int)value; return TL_OK; }
   if (!strcmp(key, "win_rows")) { g_win_rows = (int)value; return TL_OK; }
+  if (!strcmp(key, "win_ct")) { g_win_ct = (int)value; return TL_OK; }
   if (!strcmp(key, "win_min_rows")) { g_win_min_rows = value; return TL_OK; }
   if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
   if (!strcmp(key, "streamq")) { g_streamq = (int)value; return TL_OK; }

@@ -101,7 +101,7 @@ def _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_lev
         lv.nbr = torch.empty((27, lv.n), dtype=torch.int32, device=dev)
         # level 1 also gets the column form of its rulebook (40 instead of 108 B/voxel) for the kernels that read it; it rides on
         # the table tensor as an attribute
-        ct = torch.empty((10, lv.n), dtype=torch.int32, device=dev) if (li == 0 and lv.n >= 65536) else None
+        ct = torch.empty((10, lv.n), dtype=torch.int32, device=dev) if (lv.n >= 65536 and (li == 0 or _hip.WIN_KERNEL)) else None
         _hip.check(L.tl_rulebook_subm(_hip.ptr(lv.coords), lv.n, _hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims),
                                       _hip.ptr(lv.nbr), _hip.ptr(ct), st), "tl_rulebook_subm")
         if ct is not None:
@@ -176,8 +176,10 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
 
     # 3. coords, v2p, rulebooks: one backing allocation carved into the per-level arrays (64-word aligned), one call; the
     #    tensor views are made after the launches are queued
-    want_ct = levels[0].n >= 65536                          # level 1 also gets the column form of its rulebook (40 instead of
-    al = lambda w: (w + 63) & ~63                           # noqa: E731   108 B/voxel); it rides on the table tensor as an attribute
+    # level 1 (and, with the opt-in window conv kernel, every big level) also gets the column form of its rulebook (40 instead of
+    # 108 B/voxel); it rides on the table tensor as an attribute
+    want_ct = lambda lv: lv.n >= 65536 and (lv is levels[0] or _hip.WIN_KERNEL)     # noqa: E731
+    al = lambda w: (w + 63) & ~63                           # noqa: E731
     cur = 0
     def take(words):
         nonlocal cur
@@ -185,7 +187,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     o_v2p = take(2 * N)
     lay = []
     for li, lv in enumerate(levels):
-        lay.append(dict(coords=take(4 * lv.n), nbr=take(27 * lv.n), ct=take(10 * lv.n) if (li == 0 and want_ct) else None,
+        lay.append(dict(coords=take(4 * lv.n), nbr=take(27 * lv.n), ct=take(10 * lv.n) if want_ct(lv) else None,
                         child=take(8 * levels[li + 1].n) if li + 1 < num_levels else None))
     o_m1 = cur                                              # parent / inv of all levels: contiguous, one fill with -1
     for li, lv in enumerate(levels[:-1]):

@@ -171,7 +171,7 @@ class TreeLearn(nn.Module):
             output['semantic_prediction_logits'] = logits
             output['offset_predictions'] = offsets
             return output
-        backbone_feats = backbone_output.features[v2p_map]
+        backbone_feats = backbone_output.features[v2p_map].float()      # bf16 under mixed precision; the heads run in fp32
         output['backbone_feats'] = backbone_feats
         output['semantic_prediction_logits'] = self.semantic_linear(backbone_feats)
         output['offset_predictions'] = self.offset_linear(backbone_feats)

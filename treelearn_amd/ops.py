@@ -168,7 +168,7 @@ def bn_train_bwd(x, dy, st, relu):
     n, C = x.shape
     dev = x.device
     ws = torch.empty(int(L.tl_bn_ws_doubles(n, C)), dtype=torch.float64, device=dev)
-    dx = torch.empty((n, C), dtype=torch.float32, device=dev)
+    dx = torch.empty((n, C), dtype=x.dtype, device=dev)
     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
     _hip.check(L.tl_bn_train_bwd(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(dy), dy.stride(0), _hip.dtype_code(dy.dtype), n, C,
                                  _hip.ptr(st[0]), _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), int(bool(relu)), _hip.ptr(ws),

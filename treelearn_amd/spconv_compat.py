@@ -84,8 +84,10 @@ class SparseSequential(SparseModule):
 
 class SparseConvolution(SparseModule):
     # Mixed-precision training (the reference trains under torch.cuda.amp.autocast, tools/training/train.py:35-40: spconv
-    # convs in half precision with fp32 accumulation, BatchNorm in fp32): when set, features are cast to this dtype for the
-    # conv (forward and dgrad run on the bf16 MFMA kernels) and the result is returned in fp32.  Set by TreeLearn.forward.
+    # convs in half precision with fp32 accumulation; autocast keeps the activations between layers in half precision and
+    # BatchNorm's statistics in fp32): when set, features are cast to this dtype for the conv (forward and dgrad run on the bf16
+    # MFMA kernels) and the result STAYS in it -- the HIP BatchNorm kernels read and write bf16 with fp64/fp32 statistics, so
+    # no cast pass sits between layers.  Set by TreeLearn.forward.
     amp_dtype = None
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1, bias=True,
@@ -120,10 +122,8 @@ class SparseConvolution(SparseModule):
         fin = x.features if (amp is None or x.features.dtype == amp) else x.features.to(amp)
         fuse = residual is not None and residual.dtype == fin.dtype and residual.is_cuda
         feats = sparse_conv(fin, self.weight, ref, residual if fuse else None)
-        if amp is not None:
-            feats = feats.float()
         if residual is not None and not fuse:
-            feats = feats + residual
+            feats = feats + residual.to(feats.dtype)
         if self.bias is not None:
             feats = feats + self.bias
         lv = x.geometry.levels[out_level]
