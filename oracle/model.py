@@ -139,3 +139,25 @@ def get_loss(model_output, semantic_labels, offset_labels, masks_off, masks_sem)
 # The deterministic synthetic weights live with the other synthetic inputs (treelearn_amd/synth.py) so that
 # bench.py's GPU process imports nothing from oracle/; re-exported here for the tests and the golden script.
 from treelearn_amd.synth import random_state_dict, state_dict_manifest  # noqa: E402,F401
+
+
+def train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype=torch.float64):
+    """Loss and the gradient of every parameter for one training-mode forward (batch-statistics BatchNorm), by torch autograd
+    through this restatement in `dtype` (float64: a round-off-free second opinion next to the reference-generated golden).
+    Reference: the step body of tools/training/train.py:30-44 up to `.backward()`.  Returns (loss, {name: grad})."""
+    p = {k: (v.detach().to(dtype).requires_grad_(True) if (v.is_floating_point() and not k.endswith(("running_mean", "running_var")))
+             else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
+    T = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))                # noqa: E731
+    vfeats, vcoords, v2p, sshape = voxel.voxelize(T(batch["coords"]).numpy(), T(batch["input_feats"]).numpy(), T(batch["batch_ids"]).numpy(),
+                                                  int(batch["batch_size"]), voxel_size, False, False, 3)
+    if spatial_shape is not None:
+        sshape = np.asarray(spatial_shape, np.int64)
+    levels = build_levels(vcoords, sshape, num_blocks)
+    x = sparse_ops.conv_table(torch.from_numpy(vfeats).to(dtype), p["input_conv.0.weight"], levels[0].nbr)
+    x = bn_relu(ublock(x, p, "unet", levels, 0, True), p, "output_layer.0", True)
+    bf = x[torch.from_numpy(v2p)]
+    sem, off = point_wise_loss(mlp(bf, p, "semantic_linear", True), mlp(bf, p, "offset_linear", True), T(batch["masks_sem"]), T(batch["masks_off"]),
+                               T(batch["semantic_labels"]), T(batch["offset_labels"]).to(dtype))
+    loss = sem * LOSS_MULTIPLIER_SEMANTIC + off
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.detach() for k, v in p.items() if v.is_floating_point() and v.grad is not None}

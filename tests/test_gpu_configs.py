@@ -303,9 +303,15 @@ def test_config3_default_architecture_training_step_vs_reference(golden_dir):
     P = dict(model.named_parameters()); Bf = dict(model.named_buffers())
     names = [str(s) for s in g["grad_names"]]
     ours = np.array([float(P[n].grad.norm()) for n in names]); ref = g["grad_norms"]
-    # 213 gradient norms through ~70 fp32 layers each way: the reference side is itself an fp32 computation (dense conv3d on the CPU,
-    # another summation order); measured worst 6e-3, typical 1e-4
-    np.testing.assert_allclose(ours, ref, rtol=1e-2, atol=1e-6 * ref.max())
+    # (1) against float64 autograd through the oracle (round-off-free second opinion): EVERY gradient tensor in full
+    _, g64 = om.train_step_grads(random_state_dict(cfg["seed"], **cfg["cfg"]), {k: batch[k] for k in batch}, cfg["voxel_size"],
+                                 cfg["cfg"]["num_blocks"], cfg["spatial_shape"])
+    worst = max((rel_err(P[n].grad.cpu().numpy(), g64[n].numpy()), n) for n in names if float(g64[n].abs().max()) > 1e-9 * float(ref.max()))
+    assert worst[0] < 2e-3, worst
+    # (2) against the reference-generated golden.  Its deep-level gradients sit a systematic 1-2 % (max-norm) away from float64
+    # autograd of the same function (tests/test_oracle_golden.py::test_g12_gradients_float64_second_opinion: the dense stand-in's
+    # conv3d backward on the CPU), so the bound here is 2.5e-2; loss, statistics and shallow gradients agree far tighter
+    np.testing.assert_allclose(ours, ref, rtol=2.5e-2, atol=1e-6 * ref.max())
     assert np.median(np.abs(ours / np.maximum(ref, 1e-30) - 1)) < 1e-3
     deep = "unet.u.u.u.blocks_tail.block0"
     checks = {
@@ -319,7 +325,8 @@ def test_config3_default_architecture_training_step_vs_reference(golden_dir):
         "grad_l2_down": P["unet.u.conv.2.weight"].grad[:, 1, 1, 0, :],
     }
     for k, v in checks.items():
-        assert rel_err(v.cpu().numpy(), g[k]) < 1e-2, (k, rel_err(v.cpu().numpy(), g[k]))
+        assert rel_err(v.cpu().numpy(), g[k]) < 2.5e-2, (k, rel_err(v.cpu().numpy(), g[k]))
+    assert rel_err(checks["grad_sem3"].cpu().numpy(), g["grad_sem3"]) < 1e-4 and rel_err(checks["grad_input_conv"].cpu().numpy(), g["grad_input_conv"]) < 5e-3
     np.testing.assert_allclose(model.output_layer[0].running_mean.cpu().numpy(), g["bn_out_running_mean_after"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(Bf["unet.u.u.u.u.blocks.block1.conv_branch.3.running_var"].cpu().numpy(), g["bn_l5_running_var_after"], rtol=1e-3, atol=1e-6)
 

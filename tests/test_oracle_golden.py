@@ -168,3 +168,27 @@ def test_g12_default_architecture_eval_and_train_loss(golden_dir):
     loss, ld = om.get_loss(out, b["semantic_labels"], b["offset_labels"], b["masks_off"], b["masks_sem"])
     assert float(loss) == pytest.approx(float(g["train_loss"]), rel=2e-4)
     assert float(ld["offset_loss"]) == pytest.approx(float(g["train_offset_loss"]), rel=2e-4)
+
+
+def test_g12_gradients_float64_second_opinion(golden_dir):
+    """Golden g12's gradients (reference module tree through the dense stand-in, fp32 on the CPU) against float64 autograd through
+    the oracle's rulebook formulation: same loss to 1e-7, gradient norms agree to 4e-4 in the median, but the deep levels differ by
+    a systematic 1-2 % (max-norm) that is identical in float32 and float64 autograd of the oracle -- i.e. it belongs to the dense
+    stand-in's backward (conv3d / conv_transpose3d gradients on the CPU), not to round-off here.  The GPU test therefore pins the
+    HIP gradients to the float64 oracle at 2e-3 and to the golden at 2.5e-2."""
+    g = _load(golden_dir, "g12_train7.npz")
+    cfg = json.loads(str(g["cfg"]))
+    sd = om.random_state_dict(cfg["seed"], **cfg["cfg"])
+    batch = {k: g[f"in_{k}"] for k in ("coords", "input_feats", "batch_ids", "semantic_labels", "offset_labels", "masks_off", "masks_sem")}
+    batch["batch_size"] = int(g["in_batch_size"])
+    loss, grads = om.train_step_grads(sd, batch, cfg["voxel_size"], cfg["cfg"]["num_blocks"], cfg["spatial_shape"])
+    assert loss == pytest.approx(float(g["train_loss"]), rel=1e-6)
+    names = [str(s) for s in g["grad_names"]]
+    n64 = np.array([float(grads[n].norm()) for n in names]); ref = g["grad_norms"]
+    big = ref > 1e-6 * ref.max()
+    assert np.median(np.abs(ref[big] / n64[big] - 1)) < 1e-3 and np.abs(ref[big] / n64[big] - 1).max() < 2.5e-2
+    deep = "unet.u.u.u.blocks_tail.block0"
+    for key, val in (("grad_input_conv", grads["input_conv.0.weight"]), ("grad_l4_cat_conv_centre", grads[deep + ".conv_branch.2.weight"][:, 1, 1, 1, :]),
+                     ("grad_l6_deconv", grads["unet.u.u.u.u.u.deconv.2.weight"][:, 1, 0, 1, :]), ("grad_sem3", grads["semantic_linear.3.weight"])):
+        a = val.numpy(); b = g[key].astype(np.float64)
+        assert np.abs(a - b).max() / np.abs(a).max() < 2.5e-2, key
