@@ -1,10 +1,15 @@
-# Collect the per-round profile set on the GPU box (run through gpurun: `gpurun -- bash tools/profile_round.sh`), then
-# `python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<tag>` here (tag = first argument, default v8).
+# Collect the per-round profile set on the GPU box (run through gpurun: `gpurun -- bash tools/profile_round.sh <tag>`), then
+# `python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<tag>` here.  Two un-profiled default lines (three tiles in
+# flight = the headline configuration; one tile at a time), kernel-trace stats for BOTH, and the three PMC passes (one tile at a
+# time: cleaner per-kernel attribution; counters never combined with trace domains other than the kernel trace).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_${1:-v8}; mkdir -p $O
+O=gpurun_out/prof_${1:-r2}; mkdir -p $O
+Q="--no-cpu-baseline --no-fp32-mode --no-power-probe"
 python bench.py > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-mode --no-power-probe > $O/bench_line.json 2> $O/stats.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-power-probe > /dev/null 2> $O/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-power-probe > /dev/null 2> $O/write.err
-timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-power-probe > /dev/null 2> $O/sq.err
-tail -c 600 $O/bench_unprofiled.json; ls $O/*
+python bench.py --tiles-in-flight 1 $Q > $O/bench_unprofiled_1_in_flight.json 2>> $O/bench_unprofiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --steps 6 --warmup 2 $Q > $O/bench_line.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o p -- python3 bench.py --steps 6 --warmup 2 --tiles-in-flight 1 $Q > $O/bench_line_1_in_flight.json 2> $O/stats1.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 $Q > /dev/null 2> $O/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 $Q > /dev/null 2> $O/write.err
+timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o p -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 $Q > /dev/null 2> $O/sq.err
+tail -c 400 $O/bench_unprofiled.json; ls $O/*

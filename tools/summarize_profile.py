@@ -59,10 +59,13 @@ def sq():
             per[key]["dispatches"] += 1
             per[key]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     with open(os.path.join(dst, "pmc_sq.csv"), "w") as f:
+        # the clock estimate GRBM_GUI_ACTIVE / 8 / duration is unreliable for dispatches below ~40 us (it returned 3.5-4.7 GHz for the
+        # small-level kernels in round 1): left blank there
         f.write("kernel,dispatches,avg_us,sclk_ghz,mfma_util_pct,wave_cycles_issuing_pct,wave_cycles_parked_pct,wave_cycles_issue_stall_pct\n")
         for k, c in sorted(per.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
             cyc, wc = max(c["GRBM_GUI_ACTIVE"] / 8, 1.0), max(c["SQ_WAVE_CYCLES"], 1.0)
-            f.write('"%s",%d,%.1f,%.2f,%.1f,%.1f,%.1f,%.1f\n' % (k, c["dispatches"], c["ns"] / c["dispatches"] / 1e3, cyc / max(c["ns"], 1.0),
+            avg_us = c["ns"] / c["dispatches"] / 1e3
+            f.write('"%s",%d,%.1f,%s,%.1f,%.1f,%.1f,%.1f\n' % (k, c["dispatches"], avg_us, ("%.2f" % (cyc / max(c["ns"], 1.0))) if avg_us >= 40 else "",
                     100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),
                     100 * c["SQ_ACTIVE_INST_ANY"] / wc, 100 * c["SQ_WAIT_ANY"] / wc, 100 * c["SQ_WAIT_INST_ANY"] / wc))
 
@@ -70,14 +73,17 @@ def sq():
 sq()
 fetch = pmc("fetch", "FETCH_SIZE", "pmc_fetch_size.csv")
 write = pmc("write", "WRITE_SIZE", "pmc_write_size.csv")
-bl = os.path.join(src, "bench_line.json")
-if os.path.exists(bl):
-    shutil.copy(bl, os.path.join(dst, "bench_line.json"))
+for name in ("bench_line.json", "bench_line_1_in_flight.json", "bench_unprofiled.json", "bench_unprofiled_1_in_flight.json"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+ks1 = glob.glob(os.path.join(src, "stats1", "**", "*kernel_stats.csv"), recursive=True)
+if ks1:
+    shutil.copy(ks1[0], os.path.join(dst, "bf16_kernel_stats_1_in_flight.csv"))
 if fetch is not None and write is not None:
     t = {"dtype": "bf16", "workload": "config2", "forwards_profiled": forwards,
          "fetch_size_kb_per_step": fetch / forwards["fetch"], "write_size_kb_per_step": write / forwards["write"],
          "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled (MI355X_MICROARCH.md HBM section); units KB",
          "hbm_gb_per_step": (2 * fetch / forwards["fetch"] + write / forwards["write"]) * 1024 / 1e9,
-         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-power-probe"}
+         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 --no-cpu-baseline --no-fp32-mode --no-power-probe"}
     json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(t, indent=1))

@@ -4,7 +4,7 @@
 //
 // HBM-bound elementwise / reduction work.  Everything is deterministic: a block owns a fixed contiguous range of rows, every
 // thread accumulates its 4 channels over its rows in fp64, the row lanes of a block are added in lane order through LDS, and the
-// finishing kernel adds the block partials in block order (no atomics).
+// finishing kernel adds the block partials in a fixed order (no atomics).
 //
 //   forward :  tl_bn_train_stats   x -> per-channel mean / biased variance (one read of x, fp64 sum and sum of squares),
 //                                  scale = gamma * rstd, shift = beta - mean * scale, running statistics updated in place
@@ -87,16 +87,26 @@ __global__ void __launch_bounds__(kThreads) k_bn_stats(const T* __restrict__ x, 
   block_reduce_store<2>(acc, pt, C, part);
 }
 
-// one thread per channel: block partials in block order -> mean, biased var, scale / shift, running statistics
-__global__ void k_bn_stats_finish(const double* __restrict__ part, int blocks, int64_t n, int C, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                  float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// fixed-order sum of the block partials of one (quantity, channel): lane l adds partials l, l + 64, ... in that order, then the 64
+// lane sums go through a fixed xor tree -- deterministic, and 64 loads in flight instead of one dependent chain of `blocks` loads
+static __device__ __forceinline__ double sum_partials(const double* __restrict__ part, int blocks, int64_t stride, int64_t off) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 64) s += part[(int64_t)b * stride + off];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+// one wave per channel: block partials -> mean, biased var, scale / shift, running statistics
+__global__ void __launch_bounds__(64) k_bn_stats_finish(const double* __restrict__ part, int blocks, int64_t n, int C, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        int64_t* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x;
+  const double s = sum_partials(part, blocks, 2 * (int64_t)C, c), ss = sum_partials(part, blocks, 2 * (int64_t)C, C + c);
+  if (threadIdx.x != 0) return;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < blocks; ++b) { s += part[(int64_t)b * 2 * C + c]; ss += part[(int64_t)b * 2 * C + C + c]; }
   const double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0.0) var = 0.0;
@@ -140,12 +150,10 @@ __global__ void __launch_bounds__(kThreads) k_bn_bwd_reduce(const TX* __restrict
   block_reduce_store<2>(acc, pt, C, part);
 }
 
-__global__ void k_bn_bwd_finish(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int b = 0; b < blocks; ++b) { s += part[(int64_t)b * 2 * C + c]; sx += part[(int64_t)b * 2 * C + C + c]; }
-  dbeta[c] = (float)s; dgamma[c] = (float)sx;
+__global__ void __launch_bounds__(64) k_bn_bwd_finish(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
+  const double s = sum_partials(part, blocks, 2 * (int64_t)C, c), sx = sum_partials(part, blocks, 2 * (int64_t)C, C + c);
+  if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)sx; }
 }
 
 template <typename TX, typename TG>
@@ -196,7 +204,7 @@ int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, co
   else if (dtype == TL_BF16) k_bn_stats<__hip_bfloat16><<<blocks, kThreads, lds, s>>>((const __hip_bfloat16*)x, ld, n, C, pt, ws);
   else return TL_ERR_ARG;
   TL_CHECK_LAUNCH();
-  k_bn_stats_finish<<<(C + 63) / 64, 64, 0, s>>>(ws, blocks, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
+  k_bn_stats_finish<<<C, 64, 0, s>>>(ws, blocks, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
                                                  num_batches_tracked);
   TL_CHECK_LAUNCH();
   return TL_OK;
@@ -217,7 +225,7 @@ int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int6
   do {                                                                                                                                 \
     k_bn_bwd_reduce<TX, TG><<<blocks, kThreads, lds, s>>>((const TX*)x, ld, (const TG*)dy, dld, n, C, pt, mean, rstd, scale, shift, relu, ws); \
     TL_CHECK_LAUNCH();                                                                                                                 \
-    k_bn_bwd_finish<<<(C + 63) / 64, 64, 0, s>>>(ws, blocks, C, dgamma, dbeta);                                                        \
+    k_bn_bwd_finish<<<C, 64, 0, s>>>(ws, blocks, C, dgamma, dbeta);                                                        \
     TL_CHECK_LAUNCH();                                                                                                                 \
     k_bn_bwd_apply<TX, TG><<<g, kThreads, 0, s>>>((const TX*)x, ld, (const TG*)dy, dld, n, C, mean, rstd, scale, shift, relu, dgamma, dbeta, (TX*)dx, xld); \
     TL_CHECK_LAUNCH();                                                                                                                 \

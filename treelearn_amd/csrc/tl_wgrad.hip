@@ -105,7 +105,10 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad(const void* __restrict__ 
 // (NB*4 lanes per row), parks them row-major in LDS and reads the operand columns back as 2-byte elements (32 consecutive
 // channels of one row per half-wave: conflict-free).  Accumulation stays fp32; partial tiles and the ordered reduction are those
 // of the fp32 kernel.  NBO, NBI in {1, 2}; channel counts must be multiples of 8 (16-B pieces).
-template <int NBO, int NBI>
+// TR: the operand columns come back from LDS through ds_read_b64_tr_b16 (gfx950's transposing read: a 16-lane group reads a
+// [4 pairs][16 channels] block, lane i supplying the address of 8-byte chunk i = (pair i >> 2, channels 4 (i & 3) ..) and
+// receiving channel i of the four pairs): 2 reads per 32-channel operand block instead of 8 two-byte reads + 4 packs.
+template <int NBO, int NBI, bool TR = true>
 __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
                                                             const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
                                                             int nbi_blocks, float* __restrict__ ws) {
@@ -166,16 +169,38 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
       __builtin_amdgcn_wave_barrier();
       // operand columns: lane (m = fi, h = fh) takes pairs 8h .. 8h+7 of channel m of its block
       u32x4 A[NBO], B[NBI];
+      if constexpr (TR) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) s16x4* lds4;
+        const int ti = lane & 15, tg = (lane >> 4) & 1;                       // lane in its 16-lane group; which 16-channel half of the block
+        const int prow = 8 * fh + (ti >> 2), pcol = 16 * tg + 4 * (ti & 3);
 #pragma unroll
-      for (int a = 0; a < NBO; ++a)
+        for (int a = 0; a < NBO; ++a)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          A[a][t] = (uint32_t)Gs[wv][8 * fh + 2 * t][a * 32 + fi] | ((uint32_t)Gs[wv][8 * fh + 2 * t + 1][a * 32 + fi] << 16);
+          for (int q = 0; q < 2; ++q) {
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Gs[wv][prow + 4 * q][a * 32 + pcol])));
+            A[a][2 * q] = v[0]; A[a][2 * q + 1] = v[1];
+          }
 #pragma unroll
-      for (int b = 0; b < NBI; ++b)
+        for (int b = 0; b < NBI; ++b)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          B[b][t] = (uint32_t)Xs[wv][8 * fh + 2 * t][b * 32 + fi] | ((uint32_t)Xs[wv][8 * fh + 2 * t + 1][b * 32 + fi] << 16);
+          for (int q = 0; q < 2; ++q) {
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Xs[wv][prow + 4 * q][b * 32 + pcol])));
+            B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
+          }
+      } else {
+#pragma unroll
+        for (int a = 0; a < NBO; ++a)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            A[a][t] = (uint32_t)Gs[wv][8 * fh + 2 * t][a * 32 + fi] | ((uint32_t)Gs[wv][8 * fh + 2 * t + 1][a * 32 + fi] << 16);
+#pragma unroll
+        for (int b = 0; b < NBI; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            B[b][t] = (uint32_t)Xs[wv][8 * fh + 2 * t][b * 32 + fi] | ((uint32_t)Xs[wv][8 * fh + 2 * t + 1][b * 32 + fi] << 16);
+      }
 #pragma unroll
       for (int a = 0; a < NBO; ++a)
 #pragma unroll
