@@ -42,3 +42,24 @@ for (a, b, c) in ((1, 1, 1), (0, 2, 1)):
     o = ours[:, a, b, c, :].double()
     print(f"tap {a}{b}{c}: ours vs float64 of our own activations: {float((o - ref).abs().max() / ref.abs().max()):.3e};  golden vs that: "
           f"{rel(g['grad_l4_cat_conv_centre' if k == 13 else 'grad_l4_cat_conv_corner'], ref.cpu().numpy()):.3e}")
+
+# every gradient against float64 autograd through the oracle
+from oracle import model as om
+_, g64 = om.train_step_grads(random_state_dict(cfg["seed"], **cfg["cfg"]), batch, cfg["voxel_size"], cfg["cfg"]["num_blocks"], cfg["spatial_shape"])
+errs = sorted(((rel(P[n].grad.cpu().numpy(), g64[n].numpy()), n) for n in g64 if n in P and P[n].grad is not None), reverse=True)
+for e, n in errs[:12]:
+    print(f"{e:.3e}  {n}  shape {tuple(P[n].shape)}  |g|max {float(g64[n].abs().max()):.3e}")
+e, n = next((e, n) for e, n in errs if P[n].dim() == 5)
+print('per tap:', n)
+a = P[n].grad.cpu().numpy().astype(np.float64); b = g64[n].numpy()
+if a.ndim == 5:
+    for t in range(27):
+        i, j, kk = t // 9, (t // 3) % 3, t % 3
+        aa, bb = a[:, i, j, kk, :], b[:, i, j, kk, :]
+        print(f"  tap {i}{j}{kk}: max-rel {np.abs(aa - bb).max() / max(np.abs(bb).max(), 1e-30):.3e}  |ref|max {np.abs(bb).max():.3e}  |ours|max {np.abs(aa).max():.3e}")
+print("levels n:", [lv.n for lv in saved["geom"].levels])
+d = np.abs(a - b); w = np.unravel_index(np.argsort(d.ravel())[-8:], d.shape)
+for q in range(8):
+    ix = tuple(int(x[q]) for x in w); print("  worst element", ix, "ours", a[ix], "f64", b[ix])
+names = [str(s_) for s_ in g["grad_names"]]; j = names.index(n)
+print("norms: ours", float(P[n].grad.norm()), "f64", float(g64[n].norm()), "golden", float(g["grad_norms"][j]))

@@ -15,6 +15,7 @@ namespace {
 
 constexpr int kRowsPerWave = 4096;
 constexpr int kWaves = 4;
+constexpr int kSG = 256;           // bf16 kernel: rows whose present pairs are compacted into one list
 
 // BF16: x and gout are bf16 (mixed-precision training); they are widened to fp32 in registers, the products and sums stay fp32
 template <int NBO, int NBI, bool BF16>
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
   constexpr int GP = NBO * 32 + 8, XP = NBI * 32 + 8;        // LDS row pitch in elements (+16 B: the 16-B row writes of 8 rows per instruction spread over the banks)
   __shared__ __attribute__((aligned(16))) uint16_t Gs[kWaves][16][GP];
   __shared__ __attribute__((aligned(16))) uint16_t Xs[kWaves][16][XP];
-  __shared__ int2 Ls[kWaves][64];                             // compacted (row, input row) pairs of the current 64-row group
+  __shared__ int2 Ls[kWaves][kSG];                            // compacted (row, input row) pairs of the current super-group of rows
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int fi = lane & 31, fh = lane >> 5;
   const int k = blockIdx.y;
@@ -139,76 +140,118 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
-    const int64_t row = r0 + lane;
-    int idx = -1;
-    if (row < r_end) idx = table ? table[(int64_t)k * n_out + row] : (int)row;
-    const unsigned long long m = __ballot(idx >= 0);
-    const int cnt = __builtin_popcountll(m);
-    if (cnt == 0) continue;
-    if (idx >= 0) Ls[wv][__builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2((int)(row - r_begin), idx);
+  // 16 pair rows of gout and of x, batch starting at list position p0 -> registers (absent pairs / channels past the end read as zeros)
+  constexpr int NG = 16 / RG, NX = 16 / RX;
+  auto fetch = [&](int p0, int cnt, u32x4 (&gq)[NG], u32x4 (&xq)[NX]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int p = p0 + g_row + i * RG;
+      const int2 e = Ls[wv][p < cnt ? p : 0];
+      const unsigned base = (p < cnt && g_coff != 0xFFFFFFFFu) ? (unsigned)((r_begin + e.x) * g_ld * 2) + g_coff : 0xFFFFFFFFu;
+      gq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)base, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int p = p0 + x_row + i * RX;
+      const int2 e = Ls[wv][p < cnt ? p : 0];
+      const unsigned base = (p < cnt && x_coff != 0xFFFFFFFFu) ? (unsigned)((int64_t)e.y * x_ld * 2) + x_coff : 0xFFFFFFFFu;
+      xq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)base, 0, 0));
+    }
+  };
+  // one batch: registers -> LDS (row-major), operand columns back (transposed), NBO x NBI MFMAs
+  auto contract = [&](const u32x4 (&gq)[NG], const u32x4 (&xq)[NX]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) *reinterpret_cast<u32x4*>(&Gs[wv][g_row + i * RG][g_piece * 8]) = gq[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<u32x4*>(&Xs[wv][x_row + i * RX][x_piece * 8]) = xq[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int p0 = 0; p0 < cnt; p0 += 16) {
-      // 16 pair rows of gout and x -> LDS (absent pairs and channels past the end read as zeros)
-#pragma unroll
-      for (int i = 0; i < 16 / RG; ++i) {
-        const int pl = g_row + i * RG, p = p0 + pl;
-        const int2 e = Ls[wv][p < cnt ? p : 0];
-        const unsigned base = (p < cnt && g_coff != 0xFFFFFFFFu) ? (unsigned)((r_begin + e.x) * g_ld * 2) + g_coff : 0xFFFFFFFFu;
-        *reinterpret_cast<u32x4*>(&Gs[wv][pl][g_piece * 8]) = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)base, 0, 0));
-      }
-#pragma unroll
-      for (int i = 0; i < 16 / RX; ++i) {
-        const int pl = x_row + i * RX, p = p0 + pl;
-        const int2 e = Ls[wv][p < cnt ? p : 0];
-        const unsigned base = (p < cnt && x_coff != 0xFFFFFFFFu) ? (unsigned)((int64_t)e.y * x_ld * 2) + x_coff : 0xFFFFFFFFu;
-        *reinterpret_cast<u32x4*>(&Xs[wv][pl][x_piece * 8]) = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)base, 0, 0));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // operand columns: lane (m = fi, h = fh) takes pairs 8h .. 8h+7 of channel m of its block
-      u32x4 A[NBO], B[NBI];
-      if constexpr (TR) {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(3))) s16x4* lds4;
-        const int ti = lane & 15, tg = (lane >> 4) & 1;                       // lane in its 16-lane group; which 16-channel half of the block
-        const int prow = 8 * fh + (ti >> 2), pcol = 16 * tg + 4 * (ti & 3);
-#pragma unroll
-        for (int a = 0; a < NBO; ++a)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Gs[wv][prow + 4 * q][a * 32 + pcol])));
-            A[a][2 * q] = v[0]; A[a][2 * q + 1] = v[1];
-          }
-#pragma unroll
-        for (int b = 0; b < NBI; ++b)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Xs[wv][prow + 4 * q][b * 32 + pcol])));
-            B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
-          }
-      } else {
-#pragma unroll
-        for (int a = 0; a < NBO; ++a)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            A[a][t] = (uint32_t)Gs[wv][8 * fh + 2 * t][a * 32 + fi] | ((uint32_t)Gs[wv][8 * fh + 2 * t + 1][a * 32 + fi] << 16);
-#pragma unroll
-        for (int b = 0; b < NBI; ++b)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            B[b][t] = (uint32_t)Xs[wv][8 * fh + 2 * t][b * 32 + fi] | ((uint32_t)Xs[wv][8 * fh + 2 * t + 1][b * 32 + fi] << 16);
-      }
+    // operand columns: lane (m = fi, h = fh) takes pairs 8h .. 8h+7 of channel m of its block
+    u32x4 A[NBO], B[NBI];
+    if constexpr (TR) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      typedef __attribute__((address_space(3))) s16x4* lds4;
+      const int ti = lane & 15, tg = (lane >> 4) & 1;                       // lane in its 16-lane group; which 16-channel half of the block
+      const int prow = 8 * fh + (ti >> 2), pcol = 16 * tg + 4 * (ti & 3);
 #pragma unroll
       for (int a = 0; a < NBO; ++a)
 #pragma unroll
-        for (int b = 0; b < NBI; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 2; ++q) {
+          const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Gs[wv][prow + 4 * q][a * 32 + pcol])));
+          A[a][2 * q] = v[0]; A[a][2 * q + 1] = v[1];
+        }
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Xs[wv][prow + 4 * q][b * 32 + pcol])));
+          B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < NBO; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          A[a][t] = (uint32_t)Gs[wv][8 * fh + 2 * t][a * 32 + fi] | ((uint32_t)Gs[wv][8 * fh + 2 * t + 1][a * 32 + fi] << 16);
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          B[b][t] = (uint32_t)Xs[wv][8 * fh + 2 * t][b * 32 + fi] | ((uint32_t)Xs[wv][8 * fh + 2 * t + 1][b * 32 + fi] << 16);
     }
+#pragma unroll
+    for (int a = 0; a < NBO; ++a)
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // Rows are walked in super-groups of kSG: their present pairs are compacted into ONE wave-private list (fewer partly filled
+  // 16-pair batches than per 64-row group), and the batches run through a two-deep register pipeline: while batch b is staged
+  // through LDS and contracted, the rows of batches b+1 and b+2 are already in flight (the chain global load -> LDS -> MFMA of one
+  // batch is otherwise a full memory latency per 16 pairs).
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += kSG) {
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < kSG / 64; ++q) {
+      const int64_t row = r0 + q * 64 + lane;
+      int idx = -1;
+      if (row < r_end) idx = table ? table[(int64_t)k * n_out + row] : (int)row;
+      const unsigned long long m = __ballot(idx >= 0);
+      if (idx >= 0) Ls[wv][cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2((int)(row - r_begin), idx);
+      cnt += __builtin_popcountll(m);
+    }
+    if (cnt == 0) continue;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 g0[NG], x0[NX], g1[NG], x1[NX];
+    fetch(0, cnt, g0, x0);
+    if (cnt > 16) fetch(16, cnt, g1, x1);
+    for (int p0 = 0; p0 < cnt; p0 += 32) {
+      {
+        u32x4 gc[NG], xc[NX];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gc[i] = g0[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x0[i];
+        if (p0 + 32 < cnt) fetch(p0 + 32, cnt, g0, x0);
+        contract(gc, xc);
+      }
+      if (p0 + 16 < cnt) {
+        u32x4 gc[NG], xc[NX];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gc[i] = g1[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x1[i];
+        if (p0 + 48 < cnt) fetch(p0 + 48, cnt, g1, x1);
+        contract(gc, xc);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                    // the list is rebuilt by the next super-group
   }
 
   float* wp = ws + ((part * K + k) * (int64_t)Cout) * Cin;
