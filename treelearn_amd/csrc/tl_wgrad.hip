@@ -114,9 +114,12 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
                                                             const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
                                                             int nbi_blocks, float* __restrict__ ws) {
   constexpr int GP = NBO * 32 + 8, XP = NBI * 32 + 8;        // LDS row pitch in elements (+16 B: the 16-B row writes of 8 rows per instruction spread over the banks)
-  __shared__ __attribute__((aligned(16))) uint16_t Gs[kWaves][16][GP];
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[kWaves][16][XP];
-  __shared__ int2 Ls[kWaves][kSG];                            // compacted (row, input row) pairs of the current super-group of rows
+  constexpr int kStage = kWaves * 16 * (GP + XP) * 2 + kWaves * kSG * 8, kRed = NBO * 32 * (NBI * 32 + 1) * 4;
+  __shared__ __attribute__((aligned(16))) char smem_w[kStage > kRed ? kStage : kRed];
+  uint16_t (*Gs)[16][GP] = reinterpret_cast<uint16_t (*)[16][GP]>(smem_w);
+  uint16_t (*Xs)[16][XP] = reinterpret_cast<uint16_t (*)[16][XP]>(smem_w + kWaves * 16 * GP * 2);
+  int2 (*Ls)[kSG] = reinterpret_cast<int2 (*)[kSG]>(smem_w + kWaves * 16 * (GP + XP) * 2);       // compacted (row, input row) pairs of the current super-group of rows
+  float (*Rs)[NBI * 32 + 1] = reinterpret_cast<float (*)[NBI * 32 + 1]>(smem_w);                  // after the main loop: the workgroup's tile sum
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int fi = lane & 31, fh = lane >> 5;
   const int k = blockIdx.y;
@@ -254,16 +257,27 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
     __builtin_amdgcn_wave_barrier();                    // the list is rebuilt by the next super-group
   }
 
-  float* wp = ws + ((part * K + k) * (int64_t)Cout) * Cin;
+  // the four waves' tiles are added in wave order through LDS (deterministic) -> ONE partial tile per workgroup:
+  // workspace [row chunk][K][Cout][Cin], a quarter of the traffic and of the reduction kernel's work
+  __syncthreads();
+  float* wp = ws + (((int64_t)blockIdx.x * K + k) * (int64_t)Cout) * Cin;
+  for (int w = 0; w < kWaves; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int a = 0; a < NBO; ++a)
+      for (int a = 0; a < NBO; ++a)
 #pragma unroll
-    for (int b = 0; b < NBI; ++b)
+        for (int b = 0; b < NBI; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ci = ci0 + b * 32 + fi;
-        if (co < Cout && ci < Cin) wp[(int64_t)co * Cin + ci] = acc[a][b][r];
-      }
+          for (int r = 0; r < 16; ++r) {
+            const int col = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, cil = b * 32 + fi;
+            float v = acc[a][b][r];
+            if (w > 0) v += Rs[col][cil];
+            if (w < kWaves - 1) Rs[col][cil] = v;
+            else if (co0 + col < Cout && ci0 + cil < Cin) wp[(int64_t)(co0 + col) * Cin + ci0 + cil] = v;
+          }
+    }
+    __syncthreads();
+  }
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t nparts, int64_t per, float* __restrict__ gw) {
@@ -298,8 +312,9 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   if (n_in * x_ld * eb > 0x7FFFFFFFll || n_out * g_ld * eb > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   hipStream_t s = tl_s(stream);
   const int64_t nchunks = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves);
-  if (dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)gout) % 16 == 0 &&
-      g_wgrad_bf16_mfma) {
+  const bool bf16_mfma = dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 &&
+                         ((uintptr_t)gout) % 16 == 0 && g_wgrad_bf16_mfma;
+  if (bf16_mfma) {
     // bf16 matrix cores: blocks of at most 64 x 64 channels (partially filled blocks are masked)
     const int to = Cout > 32 ? 2 : 1, ti = Cin > 32 ? 2 : 1;
     const int nbo = (int)tl_cdiv(Cout, 32 * to), nbi = (int)tl_cdiv(Cin, 32 * ti);
@@ -329,7 +344,7 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
 #undef TL_W
   }
   const int64_t per = (int64_t)K * Cout * Cin;
-  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nchunks * kWaves, per, gw);
+  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, bf16_mfma ? nchunks : nchunks * kWaves, per, gw);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
