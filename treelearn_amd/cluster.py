@@ -21,15 +21,22 @@ def dbscan_min2(xy, eps, device="cuda"):
     return labels.cpu().numpy().astype(np.int64)
 
 
-def hdbscan(xy, min_cluster_size, device="cuda"):
+MAX_MIN_SAMPLES = 128          # kMaxK of csrc/tl_hdbscan.hip: the k-best list of the core-distance pass lives in registers / scratch
+
+
+def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False):
     """sklearn HDBSCAN(min_cluster_size=m).fit(xy).labels_ (min_samples = m, EOM): core distances + Prim MST
-    on the GPU (tl_hdbscan_mst), hierarchy condensation on the host (tl_hdbscan_labels_host)."""
+    on the GPU (tl_hdbscan_mst), hierarchy condensation on the host (tl_hdbscan_labels_host).
+    return_mst=True also returns the MST of the mutual-reachability graph as (src, dst, weight) numpy arrays in Prim order."""
     L = _hip.lib()
     t = torch.as_tensor(np.ascontiguousarray(xy, dtype=np.float32)) if not torch.is_tensor(xy) else xy.float().contiguous()
     n = t.shape[0]
     m = int(min_cluster_size)
     if n < m:
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {m}, n_samples_fit = {n}")   # as sklearn
+    if m > MAX_MIN_SAMPLES:
+        raise ValueError(f"min_cluster_size = {m} exceeds the {MAX_MIN_SAMPLES} neighbours the HIP core-distance kernel keeps per point "
+                         f"(tau_min of the reference's grouping config is 50); use a smaller tau_min or DBSCAN grouping")
     t = t.to(device)
     e_src = torch.empty(n - 1, dtype=torch.int32, device=t.device)
     e_dst = torch.empty(n - 1, dtype=torch.int32, device=t.device)
@@ -39,4 +46,4 @@ def hdbscan(xy, min_cluster_size, device="cuda"):
     hs, hd, hw = e_src.cpu().numpy(), e_dst.cpu().numpy(), e_w.cpu().numpy()
     labels = np.empty(n, np.int32)
     _hip.check(L.tl_hdbscan_labels_host(hs.ctypes.data, hd.ctypes.data, hw.ctypes.data, n, m, labels.ctypes.data), "tl_hdbscan_labels_host")
-    return labels.astype(np.int64)
+    return (labels.astype(np.int64), (hs, hd, hw)) if return_mst else labels.astype(np.int64)
