@@ -320,6 +320,15 @@ int tl_hdbscan_labels_host(const int32_t* e_src, const int32_t* e_dst, const dou
  * q_xyz f32[nq,3] -> out_label i64[nq]; k in {1,3,5}; ties -> smallest label; fp64 distances. */
 int tl_knn_vote(const float* ref_xyz, const int64_t* ref_label, int64_t nr, const float* q_xyz, int64_t nq, int k,
                 int64_t* out_label, tl_stream_t stream);
+/* The same vote over a uniform cell grid (exact; bit-identical to tl_knn_vote): the caller bins the reference points
+ * (cell = floor((p - lo) * (1.0f / h)) per axis in fp32, key = (cx * dims[1] + cy) * dims[2] + cz), sorts them by key and passes the
+ * sorted coordinates / labels / ORIGINAL indices, the ncells distinct keys ascending and their row ranges cell_start[ncells + 1].
+ * A query walks Chebyshev rings of cells until its k-th best distance beats anything an unvisited ring can hold; ties are broken
+ * by (distance, original index) as in the brute-force form.  O(nq * points near the query) instead of O(nq * nr). */
+int tl_knn_vote_grid(const float* ref_sorted_xyz, const int64_t* ref_sorted_label, const int64_t* ref_sorted_index, int64_t nr,
+                     const int64_t* cell_keys, const int64_t* cell_start, int64_t ncells, const float lo[3], float h, const int32_t dims[3],
+                     const float* q_xyz, int64_t nq, int k, int64_t* out_label, tl_stream_t stream);
+
 
 #ifdef __cplusplus
 }

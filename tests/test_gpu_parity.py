@@ -1014,3 +1014,30 @@ def test_forward_unusual_width_falls_back_to_generic_kernels():
     ref = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 1, voxel_size=0.2, num_blocks=3)
     for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
         assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, k
+
+
+@pytest.mark.parametrize("kind,nr,nq,k", [("uniform", 50_000, 20_000, 5), ("clustered", 200_000, 30_000, 5), ("ties", 30_000, 10_000, 3), ("flat", 40_000, 5_000, 1),
+                                           ("clustered", 6_000, 2_000, 8)])
+def test_knn_vote_grid_equals_brute_force(kind, nr, nq, k):
+    """tl_knn_vote_grid (cell grid, ring search) returns exactly what the brute-force tl_knn_vote returns: same k nearest by
+    (distance, reference index), same vote -- on uniform points, on trunk-like dense clusters with queries far outside the box, on
+    duplicated points (distance ties between different labels) and on a degenerate flat cloud."""
+    from treelearn_amd.util.postprocess import knn_vote
+    rng = np.random.default_rng(nr + nq + k)
+    if kind == "uniform":
+        ref = rng.uniform(-20, 20, size=(nr, 3)); qry = rng.uniform(-22, 22, size=(nq, 3))
+    elif kind == "clustered":
+        c = rng.uniform(-30, 30, size=(40, 3)); c[:, 2] *= 0.1
+        ref = c[rng.integers(0, 40, nr)] + rng.normal(size=(nr, 3)) * rng.choice([0.02, 0.1, 0.5], size=(nr, 1))
+        qry = np.concatenate([c[rng.integers(0, 40, nq - 500)] + rng.normal(size=(nq - 500, 3)) * 0.3, rng.uniform(-80, 80, size=(500, 3))])
+    elif kind == "ties":
+        base = np.round(rng.uniform(-5, 5, size=(nr // 3, 3)), 1)
+        ref = np.concatenate([base, base, base]); qry = np.round(rng.uniform(-5, 5, size=(nq, 3)), 1)
+    else:
+        ref = rng.uniform(-20, 20, size=(nr, 3)); ref[:, 2] = 1.25; qry = rng.uniform(-20, 20, size=(nq, 3)); qry[:, 2] = 1.25
+    lab = rng.integers(1, 30, size=len(ref))
+    d = _dev()
+    R = torch.from_numpy(ref.astype(np.float32)).to(d); Lb = torch.from_numpy(lab.astype(np.int64)).to(d); Q = torch.from_numpy(qry.astype(np.float32)).to(d)
+    a = knn_vote(R, Lb, Q, k, force="brute")
+    b = knn_vote(R, Lb, Q, k, force="grid")
+    assert torch.equal(a, b), int((a != b).sum())

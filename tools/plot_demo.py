@@ -40,7 +40,7 @@ coords, sem, off, infeat = (ens[i].cpu().numpy() for i in (0, 1, 3, 7)); t0 = la
 cfg = dict(tree_conf_thresh=0.5, tau_vert=0.0, tau_off=1e9, tau_group=0.3, tau_min=20, use_hdbscan=False)
 inst = get_instances(coords, off, sem, cfg, infeat[:, -1], 0, 0, -1, 1); t0 = lap("grouping (DBSCAN)", t0)
 tree = inst != 0
-if tree.any() and (inst[tree] != -1).any() and (inst[tree] == -1).sum() < 200000:
+if tree.any() and (inst[tree] != -1).any():
     inst[tree] = assign_remaining_points_nearest_neighbor(coords[tree] + off[tree], inst[tree], -1)
 t0 = lap("k-NN fill", t0)
 print(f"plot {E:.0f} x {E:.0f} m: {len(raw)} raw points -> {len(down)} voxels, {ntiles[0]} tiles, {len(res[0])} inner predictions -> {len(coords)} ensembled points")

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "tl_hdbscan_mst": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_hdbscan_labels_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "tl_knn_vote": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "tl_knn_vote_grid": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _c.c_float * 3, _f32, _I3, _vp, _i64, _i32, _vp, _vp]),
 }
 
 _lib = None

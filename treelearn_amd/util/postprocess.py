@@ -1,5 +1,7 @@
 """SURVEY.md §8f "next" rows on the GPU: `ensemble` (reference tree_learn/util/pipeline.py:113-141) and
 `assign_remaining_points_nearest_neighbor` (:287-296)."""
+import ctypes
+
 import numpy as np
 import torch
 
@@ -50,6 +52,40 @@ def ensemble(coords, semantic_scores, semantic_labels, offset_predictions, offse
             i64(parts[4]), f32(one(parts[5], feats)), f32(one(parts[6], input_feats)))
 
 
+GRID_KNN_MIN_REF = 4096          # below this the brute-force kernel is as fast
+
+
+def knn_vote(ref, lab, qry, k, force=None):
+    """Majority label of the k nearest reference points of every query (device tensors: ref f32[nr,3], lab i64[nr], qry f32[nq,3]).
+    Large reference sets go through the cell grid (tl_knn_vote_grid: exact, bit-identical to the brute-force tl_knn_vote);
+    `force` = "grid" / "brute" pins the path (tests)."""
+    L = _hip.lib()
+    nr, nq = ref.shape[0], qry.shape[0]
+    out = torch.empty(nq, dtype=torch.int64, device=ref.device)
+    use_grid = force == "grid" or (force is None and nr >= GRID_KNN_MIN_REF)
+    if not use_grid:
+        _hip.check(L.tl_knn_vote(_hip.ptr(ref), _hip.ptr(lab), nr, _hip.ptr(qry), nq, int(k), _hip.ptr(out), _hip.stream()), "tl_knn_vote")
+        return out
+    lo = ref.min(dim=0).values
+    ext = (ref.max(dim=0).values - lo).clamp_min(1e-3)
+    lo_h, ext_h = lo.cpu().numpy().astype(np.float32), ext.cpu().numpy().astype(np.float64)
+    # cell edge: about 8 reference points per cell of the bounding box, at least 5 cm, at most 2^20 cells per axis
+    h = np.float32(max(0.05, float((ext_h.prod() * 8.0 / nr) ** (1.0 / 3.0)), float(ext_h.max()) / (1 << 20)))
+    inv_h = np.float32(1.0) / h                                        # the kernel computes 1.0f / h the same way
+    cell = ((ref - lo) * float(inv_h)).floor().to(torch.int64)
+    dims = (cell.max(dim=0).values + 1).cpu().numpy().astype(np.int64)
+    key = (cell[:, 0] * int(dims[1]) + cell[:, 1]) * int(dims[2]) + cell[:, 2]
+    skey, order = torch.sort(key, stable=True)
+    ukeys, counts = torch.unique_consecutive(skey, return_counts=True)
+    starts = torch.zeros(len(ukeys) + 1, dtype=torch.int64, device=ref.device)
+    starts[1:] = torch.cumsum(counts, 0)
+    rs, ls = ref.index_select(0, order).contiguous(), lab.index_select(0, order).contiguous()
+    _hip.check(L.tl_knn_vote_grid(_hip.ptr(rs), _hip.ptr(ls), _hip.ptr(order), nr, _hip.ptr(ukeys), _hip.ptr(starts), len(ukeys),
+                                  (ctypes.c_float * 3)(*[float(v) for v in lo_h]), float(h), _hip.dims3(dims), _hip.ptr(qry), nq, int(k),
+                                  _hip.ptr(out), _hip.stream()), "tl_knn_vote_grid")
+    return out
+
+
 def assign_remaining_points_nearest_neighbor(coords, predictions, remaining_points_idx, n_neighbors=5, device="cuda"):
     """Unassigned points (label == remaining_points_idx) take the majority label of their k nearest assigned points
     (exact brute-force k-NN on the GPU, tl_knn_vote)."""
@@ -63,9 +99,7 @@ def assign_remaining_points_nearest_neighbor(coords, predictions, remaining_poin
     ref = torch.from_numpy(np.ascontiguousarray(coords[ri], dtype=np.float32)).to(device)
     lab = torch.from_numpy(np.ascontiguousarray(predictions[ri]).astype(np.int64)).to(device)
     qry = torch.from_numpy(np.ascontiguousarray(coords[qi], dtype=np.float32)).to(device)
-    out = torch.empty(len(qi), dtype=torch.int64, device=ref.device)
-    _hip.check(L.tl_knn_vote(_hip.ptr(ref), _hip.ptr(lab), len(ri), _hip.ptr(qry), len(qi), int(n_neighbors), _hip.ptr(out), _hip.stream()), "tl_knn_vote")
-    predictions[qi] = out.cpu().numpy()
+    predictions[qi] = knn_vote(ref, lab, qry, n_neighbors).cpu().numpy()
     return predictions.astype(np.int64)
 
 
@@ -76,6 +110,4 @@ def propagate_preds(source_coords, source_preds, target_coords, n_neighbors, n_j
     ref = torch.from_numpy(np.ascontiguousarray(source_coords, dtype=np.float32)).to(device)
     lab = torch.from_numpy(np.ascontiguousarray(source_preds).astype(np.int64)).to(device)
     qry = torch.from_numpy(np.ascontiguousarray(target_coords, dtype=np.float32)).to(device)
-    out = torch.empty(len(qry), dtype=torch.int64, device=ref.device)
-    _hip.check(L.tl_knn_vote(_hip.ptr(ref), _hip.ptr(lab), len(ref), _hip.ptr(qry), len(qry), int(n_neighbors), _hip.ptr(out), _hip.stream()), "tl_knn_vote")
-    return out.cpu().numpy()
+    return knn_vote(ref, lab, qry, n_neighbors).cpu().numpy()
