@@ -270,8 +270,9 @@ def main():
         print(json.dumps(cpu_baseline_worker()), flush=True)
         return
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or os.environ.get("TL_BENCH_FORCE_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))                                 # parent: no GPU call before or after this line
+                                                                         # (TL_BENCH_FORCE_SPAWN=1: take this path with --gpus 1 too, for testing)
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
