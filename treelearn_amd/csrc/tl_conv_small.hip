@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
   constexpr int PF = 4;                                       // steps per batch and wave (their independent loads are issued together)
   constexpr int KMAX = 27;
-  __shared__ float red[WV][NBB][16][64];
+  __shared__ float red[WV][16][64];                           // partial accumulators of ONE column block at a time
   __shared__ int Is[KMAX * 32];                               // the block's slice of the rulebook, [k][row]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rt = blockIdx.x / ncolblk, cb = blockIdx.x % ncolblk;
@@ -118,25 +118,25 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   Batch B0;
   for (int s0 = wv; s0 < nsteps; s0 += WV * PF) { request(s0, B0); contract(B0); }
 
-#pragma unroll
-  for (int nb = 0; nb < NBB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wv][nb][r][lane] = acc[nb][r];
-  __syncthreads();
-  // wave w finishes registers r = (16/WV) w .. of every column block (fixed summation order => deterministic)
+  // wave w finishes registers r = (16/WV) w .. of every column block (fixed summation order => deterministic); the column blocks
+  // go through the reduction buffer one after the other (a full-width workgroup has up to 7 of them)
   const int col = lane & 31;
   constexpr int RPW = 16 / WV;
 #pragma unroll
   for (int nb = 0; nb < NBB; ++nb) {
+    if (nb > 0) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[nb][r];
+    __syncthreads();
     const int j = col0 + nb * 32 + col;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int r = wv * RPW + rr;
       const int64_t orow = (int64_t)rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
       if (orow >= p.n_out) continue;
-      float v = red[0][nb][r][lane];
+      float v = red[0][r][lane];
 #pragma unroll
-      for (int w = 1; w < WV; ++w) v += red[w][nb][r][lane];
+      for (int w = 1; w < WV; ++w) v += red[w][r][lane];
       if constexpr (BF16) {
         if (p.res) v += __uint_as_float((uint32_t)((const uint16_t*)p.res)[orow * p.res_ld + j] << 16);
       } else {
@@ -207,13 +207,29 @@ int launch_tiny(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
-int g_small_mode = 0;   // developer A/B (tl_set_tuning "small_mode"): 0 = by size, 1 = always 4 waves, 2 = always 8 waves x 32 columns, 3 = ignore the fragment-order weights
+int g_small_mode = 0;   // developer A/B (tl_set_tuning "small_mode"): 0 = by size, 1 = always 4 waves (no full-width blocks), 2 = always 8 waves x 32 columns, 3 = ignore the fragment-order weights
 
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
   const int nrt = (int)tl_cdiv(p.n_out, 32);
   // few row tiles: 8 waves split the (tap, chunk) steps of a 32 x 32 output block (more, shorter dependent chains);
   // otherwise 4 waves per 32 x 64 (or 32 x 32) block
   const bool eight = g_small_mode == 2 || (g_small_mode == 0 && nrt * (p.Cout / 32) <= 512 && p.K * (p.Cin / 32) >= 32);   // measured: l=6,7 1.5x, l=5 equal, 1x1 slower
+  // full width (bf16, 96..224 output channels, enough row tiles to occupy the chip): ONE workgroup per 32-row tile computes every
+  // column block, so the gathered rows are read once instead of once per column block (level 5 of config 2, 160 -> 160: the 980
+  // 32 x 32 blocks pulled 541 MB through L2 per conv, which is what bounded it; 196 full-width blocks pull 160 MB)
+  const int cbt = p.Cout / 32;
+  // measured (tools/dev_small.py): 160 -> 160 at 6 264 rows 37.6 -> 31.1 us, 320 -> 160 82.6 -> 51.2, 96 -> 96 at 16 k rows 34.4 -> 26.8;
+  // widths that are multiples of 64 already run 32 x 64 blocks and lose (128 -> 128: 34.6 -> 43.1 us), so: odd multiples of 32 only
+  const bool full = g_small_mode == 0 && dtype == TL_BF16 && (cbt == 3 || cbt == 5 || cbt == 7) && nrt >= 128 && p.w_frag != nullptr &&
+                    ((uintptr_t)p.w_frag) % 16 == 0;
+  if (full) {
+    switch (cbt) {
+      case 3: k_conv_small<true, 3, 4, true><<<nrt, 256, 0, s>>>(p, 1); break;
+      case 5: k_conv_small<true, 5, 4, true><<<nrt, 256, 0, s>>>(p, 1); break;
+      case 7: k_conv_small<true, 7, 4, true><<<nrt, 256, 0, s>>>(p, 1); break;
+    }
+    return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+  }
   const bool two = !eight && (p.Cout % 64 == 0);
   const int ncb = p.Cout / (two ? 64 : 32);
   const unsigned g = (unsigned)(nrt * ncb);
