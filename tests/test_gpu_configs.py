@@ -435,6 +435,40 @@ def test_config4_64_tiles_loop_equals_single_forwards(plot64):
         dist.destroy_process_group()
 
 
+def test_config4_whole_plot_order_of_operations_under_rccl():
+    """`segment_plot_sharded` (tile loop -> two-collective record gather -> ensemble -> get_instances -> k-NN fill on rank 0 ->
+    instance-id broadcast; the order of reference tools/pipeline/pipeline.py:70-94) under a world-1 RCCL group, with the real HIP
+    ensemble / DBSCAN grouping / k-NN fill, against the same chain run single-process on the plain tile loop."""
+    import torch.distributed as dist
+    from treelearn_amd.util import get_instances, get_pointwise_preds
+    from treelearn_amd.util.postprocess import assign_remaining_points_nearest_neighbor, ensemble
+    from treelearn_amd.util.sharding import segment_plot_sharded
+    tiles = []
+    for s_ in range(5):                                            # overlapping tiles of one strip: duplicates for the ensemble
+        t = make_tile(extent=12.0, voxel=0.1, n_trees=5, fill=0.10, seed=50)
+        keep = np.abs(t["points"][:, 0] - (s_ - 2) * 2.0) < 4.0
+        t = {k: (v[keep] if k != "center" else v) for k, v in t.items()}
+        tiles.append(make_batch([t], inner_square_edge_length=7.0))
+    model = _model(torch.bfloat16, seed=3)
+    cfg = dict(tree_conf_thresh=0.5, tau_vert=0.0, tau_off=1e9, tau_group=0.3, tau_min=20, use_hdbscan=False)
+    res = get_pointwise_preds(model, tiles, dict(voxel_size=0.1))
+    e = ensemble(res[4], res[0], res[1], res[2], res[3], res[5], res[6], res[7])
+    coords, sem, off, infeat = e[0], e[1], e[3], e[7]
+    inst = get_instances(coords, off, sem, cfg, infeat.reshape(len(coords), -1)[:, -1], 0, 0, -1, 1)
+    tree = inst != 0
+    if tree.any() and (inst[tree] != -1).any() and (inst[tree] == -1).any():
+        inst[tree] = assign_remaining_points_nearest_neighbor(coords[tree] + off[tree], inst[tree], -1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29673")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c2, ids = segment_plot_sharded(model, tiles, dict(voxel_size=0.1), cfg)
+    finally:
+        dist.destroy_process_group()
+    assert len(c2) < len(res[0]) and len(c2) > 1000               # the ensemble merged duplicates
+    np.testing.assert_array_equal(c2, coords)
+    np.testing.assert_array_equal(ids, inst)
+
+
 # =============================================================================================== config 5
 @pytest.fixture(scope="module")
 def tile5():
