@@ -25,7 +25,8 @@ def timeit(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 names = {0: "full kernel", 1: "no window DMA", 16: "no weight DMA", 17: "no DMA at all", 2: "no MFMA", 4: "no LDS fragment reads", 6: "no MFMA, no fragment reads",
-         8: "no output stores", 32: "no index loads", 64: "no step barrier", 23: "no DMA, no MFMA, no fragment reads", 55: "only loop + index math + epilogue"}
+         8: "no output stores", 32: "no index loads", 64: "no step barrier", 23: "no DMA, no MFMA, no fragment reads", 55: "only loop + index math + epilogue",
+         128: "no decode / address arithmetic / minima", 136: "... and no output stores"}
 for mode, name in names.items():
     hook(mode)
     for variant, fn in (("residual + 1 view", lambda: ops.conv_fwd(x, w, lv.nbr, lv.n, residual=res)), ("plain", lambda: ops.conv_fwd(x, w, lv.nbr, lv.n))):

@@ -48,7 +48,8 @@ static __device__ __forceinline__ int wave_min(int v) {
 // WR window ring size (window DMA runs WR - 1 steps ahead), CT: row indices come from the column-form rulebook (p.ctab: one base
 // per (dx, dy) group + presence mask, 8 B per row and step instead of 12).
 // ABL (dev builds only; results are wrong on purpose): 1 no window DMA, 2 no MFMA, 4 no LDS fragment reads, 8 no output stores,
-// 16 no weight DMA, 32 no index loads (identity rows), 64 no step barrier
+// 16 no weight DMA, 32 no index loads (identity rows), 64 no step barrier, 128 no index decode / window-relative address arithmetic /
+// minima exchange (fragments read at a lane-constant offset, window base = tile start): everything else as in the full kernel
 template <int NB, int SP, int WIN, int RB, int W, int WR, bool CT, int ABL = 0>
 __global__ void __launch_bounds__(W * 64, 2) k_conv_win(ConvP p, int ntiles) {
   constexpr int COUT = NB * 32, CIN = SP * 32, RBYT = 64;
@@ -227,9 +228,10 @@ __global__ void __launch_bounds__(W * 64, 2) k_conv_win(ConvP p, int ntiles) {
             }
       }
     }
-    load_raw(t_pf, va[WR], raw[WR]);
+    if constexpr ((ABL & 128) == 0) load_raw(t_pf, va[WR], raw[WR]);
     const int wpd = wr + PD >= WR ? wr + PD - WR : wr + PD;                                // (s + PD) % WR
-    lo_q[PD] = read_lo(wpd);
+    if constexpr (ABL & 128) lo_q[PD] = (int)min(t_pf, p.n_in - 1);
+    else lo_q[PD] = read_lo(wpd);
     dma_weights(va[1], br ^ 1);
     dma_window(va[PD], lo_q[PD], wpd);
     __builtin_amdgcn_sched_barrier(0);
@@ -256,7 +258,8 @@ __global__ void __launch_bounds__(W * 64, 2) k_conv_win(ConvP p, int ntiles) {
           outl[rb] = present && !inwin;
           anyout |= outl[rb];
           // logical piece 2 j + fh of window row rel sits at physical piece (2 j + fh) ^ ((rel >> 2) & 3): j = 1 is j = 0 with bit 5 flipped
-          const int off0 = (present && inwin) ? ((rel * RBYT + swz) ^ (((rel >> 2) & 3) * 16)) : ZOFF;
+          int off0 = (present && inwin) ? ((rel * RBYT + swz) ^ (((rel >> 2) & 3) * 16)) : ZOFF;
+          if constexpr (ABL & 128) off0 = ((fi + 32 * rb + 8 * t) * RBYT + swz) ^ (((fi >> 2) & 3) * 16);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int off = off0 ^ (j * 32);
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(W * 64, 2) k_conv_win(ConvP p, int ntiles) {
 
     // 3. partial minimum of the indices WR steps ahead into the ring slot the current step's base came from; then everything but
     //    the youngest window request has landed (vmcnt retires in order; WR == 2: that request is the next step's window); barrier
-    {
+    if constexpr ((ABL & 128) == 0) {
       const int mn = min_raw(raw[WR], t_pf, va[WR]);
       if (lane == 0) lox[wr * 8 + wv] = mn;
     }
@@ -409,7 +412,7 @@ int tl_launch_conv_win(const ConvP& p0, hipStream_t s) {
   if (g_win_abl && nb == 2 && sp == 2) {
     switch (g_win_abl) {
 #define TL_A(M_) case M_: return launch<2, 2, 352, 2, 4, 2, M_>(p, s);
-      TL_A(1) TL_A(2) TL_A(4) TL_A(8) TL_A(16) TL_A(17) TL_A(32) TL_A(64) TL_A(6) TL_A(23) TL_A(55)
+      TL_A(1) TL_A(2) TL_A(4) TL_A(8) TL_A(16) TL_A(17) TL_A(32) TL_A(64) TL_A(6) TL_A(23) TL_A(55) TL_A(128) TL_A(136)
 #undef TL_A
     }
   }
