@@ -314,6 +314,32 @@ int tl_hdbscan_mst(const float* xy, int64_t n, int min_samples, int32_t* e_src, 
 int tl_hdbscan_labels_host(const int32_t* e_src, const int32_t* e_dst, const double* e_w, int64_t n,
                            int min_cluster_size, int32_t* labels);
 
+/* The same device stage for large inputs (csrc/tl_hdbscan_grid.hip): core distances and the mutual-reachability MST through a
+ * quadtree over a uniform cell grid -- grid k-NN for the core distances, Boruvka rounds for the tree -- instead of two O(n^2)
+ * passes.  Same arithmetic (fp64 on the fp32 points), so core distances are bit-identical to tl_hdbscan_mst and the MST has the
+ * same weight multiset; among equal-weight edges it takes the one that is smallest under (weight, smaller index, larger index)
+ * instead of Prim's insertion order, and it returns the edges unordered (e_src < e_dst; pass them through
+ * tl_hdbscan_prim_order_host before tl_hdbscan_labels_host).
+ *   tl_hdbscan_grid_plan: picks the grid (bounding box; leaf level such that an occupied cell holds about eight points); ws of
+ *     tl_hdbscan_grid_plan_ws_bytes(); SYNCHRONISES the stream (two small read-backs).
+ *   tl_hdbscan_mst_grid: ws of tl_hdbscan_grid_ws_bytes(n, grid); SYNCHRONISES the stream once per Boruvka round (<= ~20). */
+typedef struct TlHdbGrid {
+  double lo[2];     /* lower corner of the bounding box */
+  double h;         /* leaf cell edge */
+  int32_t levels;   /* leaf grid = 2^levels x 2^levels cells, 0..13 */
+  int32_t reserved;
+} TlHdbGrid;
+int64_t tl_hdbscan_grid_plan_ws_bytes(void);
+int tl_hdbscan_grid_plan(const float* xy, int64_t n, TlHdbGrid* grid, void* ws, tl_stream_t stream);
+int64_t tl_hdbscan_grid_ws_bytes(int64_t n, const TlHdbGrid* grid);
+int tl_hdbscan_mst_grid(const float* xy, int64_t n, int min_samples, const TlHdbGrid* grid, int32_t* e_src, int32_t* e_dst,
+                        double* e_w, double* core, void* ws, tl_stream_t stream);
+/* HOST stage: spanning-tree edges in any order / orientation -> the order and orientation Prim's algorithm started at point 0
+ * gives them (lightest frontier edge, smallest new index among equal weights, src = the end already in the tree), which is what
+ * tl_hdbscan_labels_host's tie-breaking and cluster numbering key on.  All arrays i32/f64[n-1], host memory. */
+int tl_hdbscan_prim_order_host(const int32_t* e_src, const int32_t* e_dst, const double* e_w, int64_t n, int32_t* o_src,
+                               int32_t* o_dst, double* o_w);
+
 /* ------------------------------------------------------------------ next-row helpers
  * k-NN majority vote: replaces KNeighborsClassifier(n_neighbors=k).fit(ref, labels).predict(query) in
  * assign_remaining_points_nearest_neighbor (tree_learn/util/pipeline.py:287-296).  ref_xyz f32[nr,3], ref_label i64[nr],

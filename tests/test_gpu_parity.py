@@ -448,6 +448,110 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
         hdbscan(xy, 200)
 
 
+def _hdb_device_stage(xy, k, grid):
+    """(core f64[n], sorted MST weights) straight through the C ABI, Prim form or quadtree/Boruvka form"""
+    import ctypes as C
+    from treelearn_amd import _hip
+    L = _hip.lib(); t = torch.from_numpy(np.ascontiguousarray(xy, np.float32)).cuda(); n = len(xy)
+    es = torch.empty(n - 1, dtype=torch.int32, device="cuda"); ed = torch.empty_like(es)
+    ew = torch.empty(n - 1, dtype=torch.float64, device="cuda"); core = torch.empty(n, dtype=torch.float64, device="cuda")
+    if grid:
+        g = _hip.HdbGrid(); pws = torch.empty(int(L.tl_hdbscan_grid_plan_ws_bytes()), dtype=torch.uint8, device="cuda")
+        _hip.check(L.tl_hdbscan_grid_plan(_hip.ptr(t), n, C.addressof(g), _hip.ptr(pws), _hip.stream()), "plan")
+        ws = torch.empty(int(L.tl_hdbscan_grid_ws_bytes(n, C.addressof(g))), dtype=torch.uint8, device="cuda")
+        _hip.check(L.tl_hdbscan_mst_grid(_hip.ptr(t), n, k, C.addressof(g), _hip.ptr(es), _hip.ptr(ed), _hip.ptr(ew), _hip.ptr(core), _hip.ptr(ws), _hip.stream()), "grid")
+    else:
+        ws = torch.empty(int(L.tl_hdbscan_ws_bytes(n)), dtype=torch.uint8, device="cuda")
+        _hip.check(L.tl_hdbscan_mst(_hip.ptr(t), n, k, _hip.ptr(es), _hip.ptr(ed), _hip.ptr(ew), _hip.ptr(core), _hip.ptr(ws), _hip.stream()), "prim")
+    torch.cuda.synchronize()
+    return core.cpu().numpy(), es.cpu().numpy(), ed.cpu().numpy(), ew.cpu().numpy()
+
+
+def _hdb_cases():
+    rng = np.random.default_rng(11)
+    c = rng.uniform(0, 60, (25, 2))
+    blobs = (c[rng.integers(0, 25, 30000)] + rng.normal(0, 0.15, (30000, 2))).astype(np.float32)
+    blobs[:1500] = rng.uniform(0, 60, (1500, 2))
+    quant = (np.round((c[rng.integers(0, 12, 6000)] + rng.normal(0, 0.3, (6000, 2))) * 20) / 20).astype(np.float32)      # 0.05 m lattice: duplicates, tied weights
+    return {
+        "blobs + scattered noise, 30 k": (blobs, 50, True),
+        "quantised blobs": (quant, 50, True),
+        "uniform": (rng.uniform(0, 10, (8000, 2)).astype(np.float32), 50, True),
+        "line": (np.stack([np.linspace(0, 50, 4000), np.zeros(4000)], 1).astype(np.float32), 20, True),
+        "far outliers": (np.concatenate([rng.normal(0, 0.1, (3000, 2)), rng.normal(0, 0.1, (3000, 2)) + 5, [[1e4, 1e4], [-1e4, 3e3]]]).astype(np.float32), 50, True),
+        "all identical": (np.full((500, 2), 3.5, np.float32), 5, True),
+        "two points": (np.array([[0, 0], [1, 1]], np.float32), 2, True),
+        "n == min_samples": (rng.normal(size=(50, 2)).astype(np.float32), 50, True),
+        # every edge of a perfect lattice has the same weight: any spanning tree is minimal and the labels are whatever the tie
+        # order makes them (sklearn's too); only the tree's weights are comparable
+        "perfect lattice": (np.stack(np.meshgrid(np.arange(40), np.arange(40)), -1).reshape(-1, 2).astype(np.float32) * 0.1, 10, False),
+    }
+
+
+@pytest.mark.parametrize("case", list(_hdb_cases()))
+def test_hdbscan_grid_form_equals_prim_form(case):
+    """tl_hdbscan_mst_grid (quadtree k-NN + Boruvka) against tl_hdbscan_mst (the O(n^2) restatement of sklearn's two stages): core
+    distances to the bit, a spanning tree with the same weight multiset (= minimal), each edge's weight equal to the mutual
+    reachability of its ends, and -- after tl_hdbscan_prim_order_host -- identical labels including the numbering."""
+    from treelearn_amd.cluster import hdbscan
+    xy, k, labels_too = _hdb_cases()[case]
+    n = len(xy)
+    core_p, _, _, w_p = _hdb_device_stage(xy, k, grid=False)
+    core_g, s_g, d_g, w_g = _hdb_device_stage(xy, k, grid=True)
+    np.testing.assert_array_equal(core_g, core_p)
+    np.testing.assert_array_equal(np.sort(w_g), np.sort(w_p))
+    X = xy.astype(np.float64)
+    dist = np.sqrt(((X[s_g] - X[d_g]) ** 2).sum(1))
+    np.testing.assert_array_equal(w_g, np.maximum(np.maximum(core_g[s_g], core_g[d_g]), dist))
+    parent = np.arange(n)                                      # the n-1 edges span the points
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]; a = parent[a]
+        return a
+    for a, b in zip(s_g.tolist(), d_g.tolist()):
+        ra, rb = find(a), find(b)
+        assert ra != rb
+        parent[ra] = rb
+    w2 = _hdb_device_stage(xy, k, grid=True)                   # deterministic: the same edge set on a second run
+    assert sorted(zip(s_g.tolist(), d_g.tolist())) == sorted(zip(w2[1].tolist(), w2[2].tolist()))
+    if labels_too:
+        np.testing.assert_array_equal(hdbscan(xy, k, algorithm="grid"), hdbscan(xy, k, algorithm="prim"))
+
+
+def test_hdbscan_grid_form_vs_sklearn_and_goldens(golden_dir):
+    from sklearn.cluster import HDBSCAN
+    from treelearn_amd import cluster
+    from treelearn_amd.util.pipeline import get_instances
+    for seed in range(3):
+        r = np.random.default_rng(seed); c = r.uniform(0, 40, (10, 2))
+        xy = (c[r.integers(0, 10, 5000)] + r.normal(0, 0.2, (5000, 2))).astype(np.float32)
+        np.testing.assert_array_equal(cluster.hdbscan(xy, 50, algorithm="grid"), HDBSCAN(min_cluster_size=50).fit(xy.astype(np.float64)).labels_)
+    g = np.load(os.path.join(golden_dir, "g5_clustering.npz"))
+    cfg = dict(tree_conf_thresh=0.5, tau_vert=0.6, tau_off=4, tau_group=0.15, tau_min=50, use_hdbscan=True)
+    old = cluster.GRID_MIN_POINTS
+    cluster.GRID_MIN_POINTS = 0                                # the reference-generated goldens through the grid form as well
+    try:
+        for case in "ab":
+            pred = get_instances(g[f"{case}_coords"], g[f"{case}_offsets"], g[f"{case}_logits"], cfg, g[f"{case}_vert"], 0, 0, -1, 1)
+            np.testing.assert_array_equal(pred, g[f"{case}_hdbscan_pred"])
+    finally:
+        cluster.GRID_MIN_POINTS = old
+
+
+def test_hdbscan_grid_form_400k_points_under_half_a_second():
+    import time
+    from treelearn_amd.cluster import hdbscan
+    rng = np.random.default_rng(0); n = 400000; k = n // 2500
+    c = rng.uniform(0, 100, (k, 2))
+    xy = (c[rng.integers(0, k, n)] + rng.normal(0, 0.15, (n, 2))).astype(np.float32)
+    xy[: n // 20] = rng.uniform(0, 100, (n // 20, 2))
+    hdbscan(xy[:5000], 50, algorithm="grid")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    lab = hdbscan(xy, 50)
+    dt = time.perf_counter() - t0
+    assert lab.max() + 1 >= k * 0.9 and dt < 0.5, (lab.max() + 1, dt)
+
+
 def test_training_step_mixed_precision(golden_dir):
     """compute_dtype = bf16 in training = the reference's autocast regime (convs in half precision, BatchNorm / loss fp32,
     tools/training/train.py:35-40): loss and gradients stay within bf16 distance of the fp32 golden."""

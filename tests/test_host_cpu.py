@@ -222,3 +222,36 @@ def test_packed_weight_cache_follows_the_parameter_object():
         del w
         gc.collect()
         assert len(ag._packed_cache) == n0
+
+
+def test_hdbscan_host_stage_prim_order_of_a_shuffled_tree():
+    """tl_hdbscan_prim_order_host (host code of the library, no GPU): a spanning tree handed over in any order / orientation comes back
+    in the order Prim's algorithm from point 0 walks it (numpy restatement below), and tl_hdbscan_labels_host then labels it the same."""
+    from treelearn_amd import _hip
+    L = _hip.lib()
+    rng = np.random.default_rng(3)
+    n = 400
+    X = np.concatenate([rng.normal(0, 0.3, (200, 2)), rng.normal(4, 0.3, (200, 2))])
+    D = np.sqrt(((X[:, None] - X[None]) ** 2).sum(-1))
+    core = np.sort(D, 1)[:, 9]
+    M = np.maximum(np.maximum(core[:, None], core[None]), D)
+    reach = np.full(n, np.inf); src = np.zeros(n, np.int64); intree = np.zeros(n, bool); intree[0] = True; cur = 0
+    ps, pd, pw = [], [], []
+    for _ in range(n - 1):                                   # Prim on the complete graph, smallest index among equal reachabilities
+        upd = (M[cur] < reach) & ~intree
+        reach[upd] = M[cur][upd]; src[upd] = cur
+        j = int(np.argmin(np.where(intree, np.inf, reach)))
+        ps.append(src[j]); pd.append(j); pw.append(reach[j]); intree[j] = True; cur = j
+    ps, pd, pw = np.array(ps, np.int32), np.array(pd, np.int32), np.array(pw, np.float64)
+    perm = rng.permutation(n - 1); flip = rng.random(n - 1) < 0.5
+    s = np.ascontiguousarray(np.where(flip, pd, ps)[perm]); d = np.ascontiguousarray(np.where(flip, ps, pd)[perm]); w = np.ascontiguousarray(pw[perm])
+    os_, od, ow = np.empty_like(s), np.empty_like(d), np.empty_like(w)
+    assert L.tl_hdbscan_prim_order_host(s.ctypes.data, d.ctypes.data, w.ctypes.data, n, os_.ctypes.data, od.ctypes.data, ow.ctypes.data) == 0
+    np.testing.assert_array_equal(od, pd); np.testing.assert_array_equal(os_, ps); np.testing.assert_array_equal(ow, pw)
+    la, lb = np.empty(n, np.int32), np.empty(n, np.int32)
+    assert L.tl_hdbscan_labels_host(ps.ctypes.data, pd.ctypes.data, pw.ctypes.data, n, 10, la.ctypes.data) == 0
+    assert L.tl_hdbscan_labels_host(os_.ctypes.data, od.ctypes.data, ow.ctypes.data, n, 10, lb.ctypes.data) == 0
+    np.testing.assert_array_equal(la, lb)
+    assert set(la.tolist()) >= {0, 1}
+    s[0] = s[1]; d[0] = d[1]                                  # a repeated edge: no longer a spanning tree
+    assert L.tl_hdbscan_prim_order_host(s.ctypes.data, d.ctypes.data, w.ctypes.data, n, os_.ctypes.data, od.ctypes.data, ow.ctypes.data) != 0

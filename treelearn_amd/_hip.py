@@ -41,6 +41,10 @@ class Level(_c.Structure):                 # tl_level
                 ("nbr", _c.c_void_p), ("compact", _c.c_void_p), ("child", _c.c_void_p), ("parent", _c.c_void_p), ("inv", _c.c_void_p)]
 
 
+class HdbGrid(_c.Structure):               # TlHdbGrid
+    _fields_ = [("lo", _c.c_double * 2), ("h", _c.c_double), ("levels", _c.c_int32), ("reserved", _c.c_int32)]
+
+
 _I4 = _i32 * 4
 _I3 = _i32 * 3
 
@@ -87,6 +91,11 @@ PROTOTYPES = {
     "tl_hdbscan_ws_bytes": (_i64, [_i64]),
     "tl_hdbscan_mst": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_hdbscan_labels_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "tl_hdbscan_prim_order_host": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "tl_hdbscan_grid_plan_ws_bytes": (_i64, []),
+    "tl_hdbscan_grid_plan": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "tl_hdbscan_grid_ws_bytes": (_i64, [_i64, _vp]),
+    "tl_hdbscan_mst_grid": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_knn_vote": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "tl_knn_vote_grid": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _c.c_float * 3, _f32, _I3, _vp, _i64, _i32, _vp, _vp]),
 }

@@ -1,4 +1,6 @@
 """Instance grouping on the GPU (reference tree_learn/util/pipeline.py:173-191)."""
+import ctypes as _c
+
 import numpy as np
 import torch
 
@@ -24,10 +26,15 @@ def dbscan_min2(xy, eps, device="cuda"):
 MAX_MIN_SAMPLES = 128          # kMaxK of csrc/tl_hdbscan.hip: the k-best list of the core-distance pass lives in registers / scratch
 
 
-def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False):
-    """sklearn HDBSCAN(min_cluster_size=m).fit(xy).labels_ (min_samples = m, EOM): core distances + Prim MST
-    on the GPU (tl_hdbscan_mst), hierarchy condensation on the host (tl_hdbscan_labels_host).
-    return_mst=True also returns the MST of the mutual-reachability graph as (src, dst, weight) numpy arrays in Prim order."""
+GRID_MIN_POINTS = 8192          # from here on the quadtree / Boruvka device stage replaces the two O(n^2) passes
+
+
+def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False, algorithm="auto"):
+    """sklearn HDBSCAN(min_cluster_size=m).fit(xy).labels_ (min_samples = m, EOM): core distances + MST of the mutual-reachability
+    graph on the GPU, hierarchy condensation on the host (tl_hdbscan_labels_host).
+    algorithm: "prim" = tl_hdbscan_mst (O(n^2), sklearn's edge order exactly), "grid" = tl_hdbscan_mst_grid (quadtree k-NN + Boruvka,
+    same core distances and MST weights, its own deterministic rule among equal-weight edges), "auto" = grid from GRID_MIN_POINTS points.
+    return_mst=True also returns the MST as (src, dst, weight) numpy arrays in Prim order."""
     L = _hip.lib()
     t = torch.as_tensor(np.ascontiguousarray(xy, dtype=np.float32)) if not torch.is_tensor(xy) else xy.float().contiguous()
     n = t.shape[0]
@@ -37,13 +44,29 @@ def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False):
     if m > MAX_MIN_SAMPLES:
         raise ValueError(f"min_cluster_size = {m} exceeds the {MAX_MIN_SAMPLES} neighbours the HIP core-distance kernel keeps per point "
                          f"(tau_min of the reference's grouping config is 50); use a smaller tau_min or DBSCAN grouping")
+    if algorithm not in ("auto", "prim", "grid"):
+        raise ValueError(f"unknown HDBSCAN algorithm {algorithm!r}")
     t = t.to(device)
     e_src = torch.empty(n - 1, dtype=torch.int32, device=t.device)
     e_dst = torch.empty(n - 1, dtype=torch.int32, device=t.device)
     e_w = torch.empty(n - 1, dtype=torch.float64, device=t.device)
-    ws = torch.empty(int(L.tl_hdbscan_ws_bytes(n)), dtype=torch.uint8, device=t.device)
-    _hip.check(L.tl_hdbscan_mst(_hip.ptr(t), n, m, _hip.ptr(e_src), _hip.ptr(e_dst), _hip.ptr(e_w), None, _hip.ptr(ws), _hip.stream()), "tl_hdbscan_mst")
-    hs, hd, hw = e_src.cpu().numpy(), e_dst.cpu().numpy(), e_w.cpu().numpy()
+    if algorithm == "grid" or (algorithm == "auto" and n >= GRID_MIN_POINTS):
+        if not bool(torch.isfinite(t).all()):
+            raise ValueError("hdbscan: non-finite coordinates")
+        grid = _hip.HdbGrid()
+        pws = torch.empty(int(L.tl_hdbscan_grid_plan_ws_bytes()), dtype=torch.uint8, device=t.device)
+        _hip.check(L.tl_hdbscan_grid_plan(_hip.ptr(t), n, _c.addressof(grid), _hip.ptr(pws), _hip.stream()), "tl_hdbscan_grid_plan")
+        ws = torch.empty(int(L.tl_hdbscan_grid_ws_bytes(n, _c.addressof(grid))), dtype=torch.uint8, device=t.device)
+        _hip.check(L.tl_hdbscan_mst_grid(_hip.ptr(t), n, m, _c.addressof(grid), _hip.ptr(e_src), _hip.ptr(e_dst), _hip.ptr(e_w), None, _hip.ptr(ws),
+                                         _hip.stream()), "tl_hdbscan_mst_grid")
+        gs, gd, gw = e_src.cpu().numpy(), e_dst.cpu().numpy(), e_w.cpu().numpy()
+        hs, hd, hw = np.empty_like(gs), np.empty_like(gd), np.empty_like(gw)       # the tree in Prim's order / orientation (host)
+        _hip.check(L.tl_hdbscan_prim_order_host(gs.ctypes.data, gd.ctypes.data, gw.ctypes.data, n, hs.ctypes.data, hd.ctypes.data, hw.ctypes.data),
+                   "tl_hdbscan_prim_order_host")
+    else:
+        ws = torch.empty(int(L.tl_hdbscan_ws_bytes(n)), dtype=torch.uint8, device=t.device)
+        _hip.check(L.tl_hdbscan_mst(_hip.ptr(t), n, m, _hip.ptr(e_src), _hip.ptr(e_dst), _hip.ptr(e_w), None, _hip.ptr(ws), _hip.stream()), "tl_hdbscan_mst")
+        hs, hd, hw = e_src.cpu().numpy(), e_dst.cpu().numpy(), e_w.cpu().numpy()
     labels = np.empty(n, np.int32)
     _hip.check(L.tl_hdbscan_labels_host(hs.ctypes.data, hd.ctypes.data, hw.ctypes.data, n, m, labels.ctypes.data), "tl_hdbscan_labels_host")
     return (labels.astype(np.int64), (hs, hd, hw)) if return_mst else labels.astype(np.int64)

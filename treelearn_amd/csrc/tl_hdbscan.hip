@@ -157,6 +157,48 @@ int tl_hdbscan_mst(const float* xy, int64_t n, int min_samples, int32_t* e_src, 
   return TL_OK;
 }
 
+// HOST function: re-orders a spanning tree (edges in any order and orientation) the way Prim's algorithm started at point 0 walks it
+// -- lightest frontier edge first, smallest new point index among equal weights, src = the end already in the tree -- i.e. the
+// order and orientation sklearn's Prim (and tl_hdbscan_mst) emits when the tree is the one it finds.  tl_hdbscan_labels_host breaks
+// weight ties by position and numbers clusters by orientation, so this makes the labels of a tree from tl_hdbscan_mst_grid agree
+// with the Prim form wherever equal weights do not make the trees themselves differ.
+int tl_hdbscan_prim_order_host(const int32_t* e_src, const int32_t* e_dst, const double* e_w, int64_t n, int32_t* o_src, int32_t* o_dst, double* o_w) {
+  if (!e_src || !e_dst || !e_w || !o_src || !o_dst || !o_w || n < 2) return TL_ERR_ARG;
+  const int64_t m = n - 1;
+  std::vector<int64_t> off(n + 1, 0);
+  for (int64_t e = 0; e < m; ++e) {
+    if (e_src[e] < 0 || e_src[e] >= n || e_dst[e] < 0 || e_dst[e] >= n) return TL_ERR_ARG;
+    ++off[e_src[e] + 1]; ++off[e_dst[e] + 1];
+  }
+  for (int64_t i = 0; i < n; ++i) off[i + 1] += off[i];
+  std::vector<int64_t> adj(2 * m), cur(off.begin(), off.end() - 1);
+  for (int64_t e = 0; e < m; ++e) { adj[cur[e_src[e]]++] = e; adj[cur[e_dst[e]]++] = e; }
+  struct Item { double w; int32_t v, u; };
+  auto later = [](const Item& a, const Item& b) { return a.w > b.w || (a.w == b.w && a.v > b.v); };
+  std::vector<Item> heap;
+  heap.reserve(n);
+  std::vector<char> in_tree(n, 0);
+  auto grow = [&](int32_t u) {
+    in_tree[u] = 1;
+    for (int64_t q = off[u]; q < off[u + 1]; ++q) {
+      const int64_t e = adj[q];
+      const int32_t v = e_src[e] == u ? e_dst[e] : e_src[e];
+      if (!in_tree[v]) { heap.push_back({e_w[e], v, u}); std::push_heap(heap.begin(), heap.end(), later); }
+    }
+  };
+  grow(0);
+  int64_t k = 0;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), later);
+    const Item it = heap.back(); heap.pop_back();
+    if (in_tree[it.v]) continue;
+    if (k >= m) return TL_ERR_ARG;
+    o_src[k] = it.u; o_dst[k] = it.v; o_w[k] = it.w; ++k;
+    grow(it.v);
+  }
+  return k == m ? TL_OK : TL_ERR_ARG;                          // k < m: the edges do not span the points
+}
+
 // HOST function (host pointers, no GPU work): MST edges -> HDBSCAN labels (-1 = noise, clusters 0..K-1 in
 // ascending condensed-tree id, as sklearn numbers them).  EOM selection, allow_single_cluster = False,
 // cluster_selection_epsilon = 0.
