@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad(const void* __restrict__ 
 // (rank = popcount of the lower lanes' ballot bits), fetches 16 pair rows of gout and of x at a time with full-row 16-B loads
 // (NB*4 lanes per row), parks them row-major in LDS and reads the operand columns back as 2-byte elements (32 consecutive
 // channels of one row per half-wave: conflict-free).  Accumulation stays fp32; partial tiles and the ordered reduction are those
-// of the fp32 kernel.  NBO, NBI in {1, 2}; channel counts must be multiples of 8 (16-B pieces).
+// of the fp32 kernel.  NBO, NBI in {1, 2, 3}; channel counts must be multiples of 8 (16-B pieces).
 // TR: the operand columns come back from LDS through ds_read_b64_tr_b16 (gfx950's transposing read: a 16-lane group reads a
 // [4 pairs][16 channels] block, lane i supplying the address of 8-byte chunk i = (pair i >> 2, channels 4 (i & 3) ..) and
 // receiving channel i of the four pairs): 2 reads per 32-channel operand block instead of 8 two-byte reads + 4 packs.
@@ -113,7 +113,10 @@ template <int NBO, int NBI, bool TR = true>
 __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
                                                             const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
                                                             int nbi_blocks, float* __restrict__ ws) {
-  constexpr int GP = NBO * 32 + 8, XP = NBI * 32 + 8;        // LDS row pitch in elements (+16 B: the 16-B row writes of 8 rows per instruction spread over the banks)
+  // staging pattern: LG (LX) lanes cover one row of the gout (x) block with 16-B pieces; a 96-channel block (NB = 3) takes 16 lanes per
+  // row like a 128-channel one, its last four pieces masked (they read as zeros and land in the row's padding)
+  constexpr int LG = NBO == 3 ? 16 : NBO * 4, LX = NBI == 3 ? 16 : NBI * 4, RG = 64 / LG, RX = 64 / LX;       // lanes per row, rows per load instruction
+  constexpr int GP = LG * 8 + 8, XP = LX * 8 + 8;            // LDS row pitch in elements (+16 B: the 16-B row writes of 8 rows per instruction spread over the banks)
   constexpr int kStage = kWaves * 16 * (GP + XP) * 2 + kWaves * kSG * 8, kRed = NBO * 32 * (NBI * 32 + 1) * 4;
   __shared__ __attribute__((aligned(16))) char smem_w[kStage > kRed ? kStage : kRed];
   uint16_t (*Gs)[16][GP] = reinterpret_cast<uint16_t (*)[16][GP]>(smem_w);
@@ -129,11 +132,9 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
   const int64_t r_begin = part * kRowsPerWave, r_end = min(n_out, r_begin + kRowsPerWave);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 2), 0x00020000);
-  // staging pattern: LG (LX) lanes cover one row of the gout (x) block with 16-B pieces
-  constexpr int LG = NBO * 4, LX = NBI * 4, RG = 64 / LG, RX = 64 / LX;       // lanes per row, rows per load instruction
   const int g_piece = lane % LG, g_row = lane / LG, x_piece = lane % LX, x_row = lane / LX;
-  const unsigned g_coff = (co0 + g_piece * 8 < Cout) ? (unsigned)((co0 + g_piece * 8) * 2) : 0xFFFFFFFFu;
-  const unsigned x_coff = (ci0 + x_piece * 8 < Cin) ? (unsigned)((ci0 + x_piece * 8) * 2) : 0xFFFFFFFFu;
+  const unsigned g_coff = (g_piece < NBO * 4 && co0 + g_piece * 8 < Cout) ? (unsigned)((co0 + g_piece * 8) * 2) : 0xFFFFFFFFu;
+  const unsigned x_coff = (x_piece < NBI * 4 && ci0 + x_piece * 8 < Cin) ? (unsigned)((ci0 + x_piece * 8) * 2) : 0xFFFFFFFFu;
 
   f32x16 acc[NBO][NBI];
 #pragma unroll
@@ -315,12 +316,17 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   const bool bf16_mfma = dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 &&
                          ((uintptr_t)gout) % 16 == 0 && g_wgrad_bf16_mfma;
   if (bf16_mfma) {
-    // bf16 matrix cores: blocks of at most 64 x 64 channels (partially filled blocks are masked)
-    const int to = Cout > 32 ? 2 : 1, ti = Cin > 32 ? 2 : 1;
+    // bf16 matrix cores: blocks of at most 64 x 64 channels (partially filled blocks are masked); on big levels whose widths are
+    // multiples of 96 (level 3: 96 -> 96, 192 -> 96) 96 x 96 blocks -- ONE 3 x 3 block per 96 x 96 (9 MFMAs per 16 pairs, rows
+    // gathered once) instead of four 2 x 2 blocks (16 MFMAs, rows gathered four times): 2.0 -> 1.08 ms.  Mixed 2/3 shapes and small
+    // levels lose (one wave per SIMD, fewer workgroups) and keep the 64-wide blocks.
+    const bool wide = Cout % 96 == 0 && Cin % 96 == 0 && n_out >= 100000;
+    const int to = wide ? 3 : (Cout > 32 ? 2 : 1), ti = wide ? 3 : (Cin > 32 ? 2 : 1);
     const int nbo = (int)tl_cdiv(Cout, 32 * to), nbi = (int)tl_cdiv(Cin, 32 * ti);
     const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
     const uint16_t* xb = (const uint16_t*)x; const uint16_t* gb = (const uint16_t*)gout;
-    if (to == 2 && ti == 2) k_wgrad_bf16<2, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+    if (to == 3 && ti == 3) k_wgrad_bf16<3, 3><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+    else if (to == 2 && ti == 2) k_wgrad_bf16<2, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else if (to == 2) k_wgrad_bf16<2, 1><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else if (ti == 2) k_wgrad_bf16<1, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else k_wgrad_bf16<1, 1><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
