@@ -231,9 +231,12 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
     if (cnt == 0) continue;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // branch-free: every step issues its prefetch and its contraction (past the end of the list all offsets are out of range: no
+    // memory access, zeros back, a zero contribution), so the loop body is straight-line code and the waits for a batch stay
+    // counted (vmcnt(N)) -- with `if (more) fetch(...)` the control-flow join drained the younger prefetches on every batch
     u32x4 g0[NG], x0[NX], g1[NG], x1[NX];
     fetch(0, cnt, g0, x0);
-    if (cnt > 16) fetch(16, cnt, g1, x1);
+    fetch(16, cnt, g1, x1);
     for (int p0 = 0; p0 < cnt; p0 += 32) {
       {
         u32x4 gc[NG], xc[NX];
@@ -241,16 +244,16 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
         for (int i = 0; i < NG; ++i) gc[i] = g0[i];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = x0[i];
-        if (p0 + 32 < cnt) fetch(p0 + 32, cnt, g0, x0);
+        fetch(p0 + 32, cnt, g0, x0);
         contract(gc, xc);
       }
-      if (p0 + 16 < cnt) {
+      {
         u32x4 gc[NG], xc[NX];
 #pragma unroll
         for (int i = 0; i < NG; ++i) gc[i] = g1[i];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = x1[i];
-        if (p0 + 48 < cnt) fetch(p0 + 48, cnt, g1, x1);
+        fetch(p0 + 48, cnt, g1, x1);
         contract(gc, xc);
       }
     }
@@ -281,6 +284,209 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
   }
 }
 
+// The same contraction with the gout rows SHARED: both operands of the kernel above are gathered per pair (4 KB of rows per four
+// MFMAs at 64 x 64 -- twice the forward conv's ratio, and the L1 gather rate is what bounds it), yet the gout rows of a row range
+// are the same for all 27 taps.  Here a workgroup = (row chunk, group of 4 T taps, channel block): the four waves walk the SAME rows
+// in super-groups of R, the gout tile of a super-group is staged in LDS once (coalesced, prefetched into registers one super-group
+// ahead), wave w contracts taps w, w + 4, ... against it -- the A fragments come from the shared tile through ds_read_b64_tr_b16 at
+// the pairs' own rows (every lane supplies its row address, so the compacted pair list needs no copy of gout), only the x rows are
+// gathered per pair.  gout traffic drops from one row per pair to 1 / (taps per workgroup x tap density) rows per pair; every wave
+// owns whole taps, so its tiles go to the workspace without the cross-wave reduction.
+// R = rows per super-group; DENSE: no pair compaction (absent pairs multiply zeros); MODE (developer A/B, 1 ships): 0 = prefetches under
+// `if (more)`, 1 = branch-free batch pipeline, 2 = 1 + the next super-group's tile / rulebook entries requested behind the first x rows
+template <int NBO, int NBI, int T, int R, bool DENSE = false, int MODE = 1>
+__global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16s(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
+                                                             const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int Cout,
+                                                             int nbi_blocks, int chunk_rows, float* __restrict__ ws) {
+  constexpr int LG = NBO == 3 ? 16 : NBO * 4, LX = NBI == 3 ? 16 : NBI * 4, RX = 64 / LX;
+  constexpr int GP = LG * 8 + 8, XP = LX * 8 + 8;
+  constexpr int NPT = R * LG / (kWaves * 64);                                  // 16-B pieces of the gout tile per thread
+  constexpr int NX = 16 / RX;
+  __shared__ __attribute__((aligned(16))) uint16_t Gt[R + 1][GP];              // row R stays zero: the row of absent pairs
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[kWaves][16][XP];
+  __shared__ int2 Ls[kWaves][R];                                               // (row in the super-group, input row) of the present pairs of the wave's current tap
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tid = threadIdx.x;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int bo = blockIdx.z / nbi_blocks, bi = blockIdx.z % nbi_blocks;
+  const int co0 = bo * (NBO * 32), ci0 = bi * (NBI * 32);
+  const int64_t c_begin = (int64_t)blockIdx.x * chunk_rows, c_end = min(n_out, c_begin + (int64_t)chunk_rows);
+  const int k_first = blockIdx.y * (kWaves * T) + wv;                          // this wave's taps: k_first + kWaves * t
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 2), 0x00020000);
+  const int x_piece = lane % LX, x_row = lane / LX;
+  const unsigned x_coff = (x_piece < NBI * 4 && ci0 + x_piece * 8 < Cin) ? (unsigned)((ci0 + x_piece * 8) * 2) : 0xFFFFFFFFu;
+
+  f32x16 acc[T][NBO][NBI];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int a = 0; a < NBO; ++a)
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][a][b][i] = 0.f;
+
+  // the gout tile of the super-group starting at row r0 -> registers (rows past the chunk / channels past the block read as zeros)
+  auto tile_load = [&](int64_t r0, u32x4 (&gq)[NPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * (kWaves * 64), row = q / LG, piece = q % LG;
+      const bool ok = r0 + row < c_end && piece < NBO * 4 && co0 + piece * 8 < Cout;
+      const unsigned base = ok ? (unsigned)((r0 + row) * g_ld * 2) + (unsigned)((co0 + piece * 8) * 2) : 0xFFFFFFFFu;
+      gq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)base, 0, 0));
+    }
+  };
+  auto tile_store = [&](const u32x4 (&gq)[NPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * (kWaves * 64);
+      *reinterpret_cast<u32x4*>(&Gt[q / LG][(q % LG) * 8]) = gq[i];
+    }
+  };
+  auto fetch = [&](int p0, int cnt, u32x4 (&xq)[NX]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int p = p0 + x_row + i * RX;
+      const int2 e = Ls[wv][p < cnt ? p : 0];
+      const unsigned base = (p < cnt && e.y >= 0 && x_coff != 0xFFFFFFFFu) ? (unsigned)((int64_t)e.y * x_ld * 2) + x_coff : 0xFFFFFFFFu;
+      xq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)base, 0, 0));
+    }
+  };
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) s16x4* lds4;
+  const int ti = lane & 15, tg = (lane >> 4) & 1;
+  const int prow = 8 * fh + (ti >> 2), pcol = 16 * tg + 4 * (ti & 3);
+  auto contract = [&](int p0, int cnt, const u32x4 (&xq)[NX], f32x16 (&ac)[NBO][NBI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<u32x4*>(&Xs[wv][x_row + i * RX][x_piece * 8]) = xq[i];
+    int grow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const int pp = p0 + prow + 4 * q; grow[q] = DENSE ? pp : (pp < cnt ? Ls[wv][pp].x : R); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 A[NBO], B[NBI];
+#pragma unroll
+    for (int a = 0; a < NBO; ++a)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Gt[grow[q]][a * 32 + pcol])));
+        A[a][2 * q] = v[0]; A[a][2 * q + 1] = v[1];
+      }
+#pragma unroll
+    for (int b = 0; b < NBI; ++b)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&Xs[wv][prow + 4 * q][b * 32 + pcol])));
+        B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
+      }
+#pragma unroll
+    for (int a = 0; a < NBO; ++a)
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+        ac[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), ac[a][b], 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  for (int c = tid; c < GP; c += kWaves * 64) Gt[R][c] = 0;
+  {
+    u32x4 g0[NPT];
+    tile_load(c_begin, g0);
+    tile_store(g0);
+  }
+  __syncthreads();
+  constexpr int D = 2;                                     // batches of x rows in flight per wave
+  // rulebook entries of the first super-group, for every tap of the wave
+  int idx_n[T][R / 64];
+  auto table_load = [&](int64_t r0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int k = k_first + kWaves * t;
+#pragma unroll
+      for (int q = 0; q < R / 64; ++q) {
+        const int64_t row = r0 + q * 64 + lane;
+        idx_n[t][q] = (k < K && row < c_end) ? (table ? table[(int64_t)k * n_out + row] : (int)row) : -1;
+      }
+    }
+  };
+  if (MODE == 2) table_load(c_begin);
+  for (int64_t r0 = c_begin; r0 < c_end; r0 += R) {
+    u32x4 gn[NPT];
+    const bool more = r0 + R < c_end;
+    if (MODE != 2) table_load(r0);
+    int idx_c[T][R / 64];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int q = 0; q < R / 64; ++q) idx_c[t][q] = idx_n[t][q];
+    bool ahead = MODE != 2;                                // next super-group's gout tile and rulebook entries requested?
+    if (MODE != 2 && more) tile_load(r0 + R, gn);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int k = k_first + kWaves * t;
+      int cnt = 0;
+      if (k < K) {
+#pragma unroll
+        for (int q = 0; q < R / 64; ++q) {
+          const int idx = idx_c[t][q];
+          if constexpr (DENSE) {
+            Ls[wv][q * 64 + lane] = make_int2(q * 64 + lane, idx);
+            cnt += 64;
+          } else {
+            const unsigned long long m = __ballot(idx >= 0);
+            if (idx >= 0) Ls[wv][cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_int2(q * 64 + lane, idx);
+            cnt += __builtin_popcountll(m);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // branch-free pipeline: every step issues its prefetch (past the end of the list every lane's offset is out of range: no memory
+      // access, zeros back), so the loop body is straight-line code and the waits for a batch stay counted (vmcnt(N)) instead of
+      // draining the younger prefetches at a control-flow join
+      u32x4 xb[D][NX];
+#pragma unroll
+      for (int d = 0; d < D; ++d) if (MODE != 0 || 16 * d < cnt) fetch(16 * d, cnt, xb[d]);
+      if (!ahead) {                                        // behind this tap's first x rows in the (in-order) load queue
+        ahead = true;
+        if (more) { tile_load(r0 + R, gn); table_load(r0 + R); }
+      }
+      for (int p0 = 0; p0 < cnt; p0 += 16 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          u32x4 xc[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xc[i] = xb[d][i];
+          if (MODE != 0 || p0 + 16 * (d + D) < cnt) fetch(p0 + 16 * (d + D), cnt, xb[d]);
+          if (MODE != 0 || p0 + 16 * d < cnt) contract(p0 + 16 * d, cnt, xc, acc[t]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                    // the list is rebuilt by the next tap
+    }
+    __syncthreads();                                       // every wave is done with this tile
+    if (more) tile_store(gn);
+    __syncthreads();
+  }
+  // every wave owns whole taps: its tiles are the workgroup's partials -- workspace [row chunk][K][Cout][Cin]
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int k = k_first + kWaves * t;
+    if (k >= K) continue;
+    float* wp = ws + (((int64_t)blockIdx.x * K + k) * (int64_t)Cout) * Cin;
+#pragma unroll
+    for (int a = 0; a < NBO; ++a)
+#pragma unroll
+      for (int b = 0; b < NBI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ci = ci0 + b * 32 + fi;
+          if (co < Cout && ci < Cin) wp[(int64_t)co * Cin + ci] = acc[t][a][b][r];
+        }
+  }
+}
+
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t nparts, int64_t per, float* __restrict__ gw) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -291,12 +497,18 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, int64_t nparts, int
 
 }  // namespace
 
+static int g_wgrad_var = 0, g_wgrad_chunk = 0;   // developer A/B: kernel variant / fixed chunk rows
+static int g_wgrad_shared = 1;             // developer A/B (tl_dev_wgrad_mode bit 1): 0 = per-tap workgroups that gather gout per pair
 static int g_wgrad_bf16_mfma = 1;          // developer A/B (tl_dev_wgrad_mode): 0 = bf16 inputs through the fp32-MFMA kernel
 
 extern "C" {
 
 #ifdef TL_DEV
-int tl_dev_wgrad_mode(int bf16_mfma) { g_wgrad_bf16_mfma = bf16_mfma; return TL_OK; }
+int tl_dev_wgrad_mode(int mode) {
+  g_wgrad_bf16_mfma = mode & 1; g_wgrad_shared = !(mode & 2); g_wgrad_var = (mode >> 8) & 15;
+  g_wgrad_chunk = ((mode >> 12) & 3) ? 2048 << ((mode >> 12) & 3) : 0;
+  return TL_OK;
+}
 #endif
 
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
@@ -313,6 +525,7 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   if (n_in * x_ld * eb > 0x7FFFFFFFll || n_out * g_ld * eb > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   hipStream_t s = tl_s(stream);
   const int64_t nchunks = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves);
+  int64_t nchunks_used = nchunks;
   const bool bf16_mfma = dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 &&
                          ((uintptr_t)gout) % 16 == 0 && g_wgrad_bf16_mfma;
   if (bf16_mfma) {
@@ -323,13 +536,39 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
     const bool wide = Cout % 96 == 0 && Cin % 96 == 0 && n_out >= 100000;
     const int to = wide ? 3 : (Cout > 32 ? 2 : 1), ti = wide ? 3 : (Cin > 32 ? 2 : 1);
     const int nbo = (int)tl_cdiv(Cout, 32 * to), nbi = (int)tl_cdiv(Cin, 32 * ti);
-    const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
     const uint16_t* xb = (const uint16_t*)x; const uint16_t* gb = (const uint16_t*)gout;
+    if (K == 27 && to >= 2 && ti >= 2 && g_wgrad_shared) {
+      // shared-gout form (27-tap convs with both sides >= 64 channels; 32-channel sides and the 8-tap down / up convs measured
+      // slower in it): workgroup = (row chunk, 4 taps, block); chunks of 4 096 .. 16 384 rows (the workspace holds one partial per
+      // 4 096 rows), the smallest that still gives every CU a few workgroups
+      int64_t chunk = 16384;
+      if (g_wgrad_chunk) chunk = g_wgrad_chunk;
+      else while (chunk > 4096 && tl_cdiv(n_out, chunk) * tl_cdiv(K, kWaves) * nbo * nbi < 2048) chunk >>= 1;
+      nchunks_used = tl_cdiv(n_out, chunk);
+#define TL_WS(O_, I_, T_, R_, ...)                                                                                          \
+  k_wgrad_bf16s<O_, I_, T_, R_, ##__VA_ARGS__><<<dim3((unsigned)nchunks_used, (unsigned)tl_cdiv(K, kWaves * T_), (unsigned)(nbo * nbi)), kWaves * 64, 0, s>>>( \
+      xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, (int)chunk, ws)
+#ifdef TL_DEV
+      const int v = g_wgrad_var;                               // tools/dev_wgrad_var.py
+      if (v && to == 2) {
+        if (v == 1) TL_WS(2, 2, 1, 128, false, 0); else if (v == 2) TL_WS(2, 2, 1, 128, false, 2); else if (v == 3) TL_WS(2, 2, 1, 128, true, 0);
+        else if (v == 4) TL_WS(2, 2, 1, 128, true, 1); else if (v == 5) TL_WS(2, 2, 1, 128, true, 2); else if (v == 6) TL_WS(2, 2, 2, 128, true, 1);
+        else TL_WS(2, 2, 1, 256, true, 1);
+      } else if (v && to == 3) {
+        if (v == 1) TL_WS(3, 3, 1, 128, false, 1); else if (v == 3) TL_WS(3, 3, 1, 128, true, 0); else TL_WS(3, 3, 1, 128, false, 0);
+      } else
+#endif
+      if (to == 3) TL_WS(3, 3, 1, 128, true, 1);              // level 3 (24 of 27 taps present): no pair compaction
+      else TL_WS(2, 2, 1, 128, false, 1);
+#undef TL_WS
+    } else {
+    const dim3 grid((unsigned)nchunks, (unsigned)K, (unsigned)(nbo * nbi));
     if (to == 3 && ti == 3) k_wgrad_bf16<3, 3><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else if (to == 2 && ti == 2) k_wgrad_bf16<2, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else if (to == 2) k_wgrad_bf16<2, 1><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else if (ti == 2) k_wgrad_bf16<1, 2><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
     else k_wgrad_bf16<1, 1><<<grid, kWaves * 64, 0, s>>>(xb, x_ld, gb, g_ld, table, n_out, n_in, K, Cin, Cout, nbi, ws);
+    }
   } else {
   // [Cout x Cin] is cut into blocks of 32 NBO x 32 NBI; 96 channels take one 3-tile block instead of two 2-tile blocks
   // (a 2 x 2 tiling of 96 x 96 would spend 16 MFMAs where 9 are needed)
@@ -350,7 +589,7 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
 #undef TL_W
   }
   const int64_t per = (int64_t)K * Cout * Cin;
-  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, bf16_mfma ? nchunks : nchunks * kWaves, per, gw);
+  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, bf16_mfma ? nchunks_used : nchunks * kWaves, per, gw);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
