@@ -580,7 +580,7 @@ def test_training_step_mixed_precision(golden_dir):
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 17001), (64, 32, 27, 16500), (32, 64, 8, 16400), (64, 32, 8, 20000), (64, 96, 8, 16390),
                                                (96, 64, 8, 16385), (64, 32, 1, 20000), (64, 64, 27, 16500), (32, 32, 27, 300), (4, 32, 27, 5000), (128, 64, 27, 16400), (96, 96, 27, 16390),
                                                (128, 128, 27, 16401), (192, 96, 27, 16402), (96, 128, 8, 16403), (256, 128, 27, 16404),
-                                               (160, 160, 27, 6500), (320, 160, 27, 6000), (192, 192, 27, 1200)])
+                                               (160, 160, 27, 6500), (320, 160, 27, 6000), (192, 192, 27, 1200), (64, 128, 27, 16420)])
 def test_conv_bf16_no_prologue_multi_output(cin, cout, K, n_out):
     """Pre-activated form: no gather-side prologue, residual, three output views (raw, bn+relu, bn+relu) --
     exercises the weights-in-LDS direct kernel (level-1 shapes), the stream kernel (fragment-shaped gathers),

@@ -313,6 +313,7 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
     if (nb == 2 && pn == 1) return launch<27, 2, 1, 2>(p, s);
     if (nb == 2 && pn == 2) return launch<27, 2, 2, 2>(p, s);
     if (nb == 4 && pn == 2) return launch<27, 4, 2, 2>(p, s);
+    if (nb == 4 && pn == 1) return launch<27, 4, 1, 2>(p, s);          // 64 -> 128: the dgrad of the level-2 128 -> 64 conv
     if (nb == 3 && pn == 3) return launch<27, 3, 3, 2>(p, s);
     if (nb == 4 && pn == 4) return launch<27, 4, 2, 2, 8, 1, 0, 2>(p, s);
   } else if (p.K == 8) {
