@@ -691,6 +691,16 @@ def test_next_rows_voxel_downsample_vs_oracle():
         np.testing.assert_array_equal(propagate_to_original(preds, trace).cpu().numpy(), preds[p2v])
 
 
+def test_next_rows_voxel_downsample_vs_hand_worked_example():
+    from kat_cases import voxel_downsample_by_hand
+    from treelearn_amd.util.prepare import voxelize
+    data, voxel, expect, first, p2v = voxel_downsample_by_hand()
+    out, trace = voxelize(data, voxel)
+    np.testing.assert_allclose(out.cpu().numpy(), expect, atol=1e-6)
+    np.testing.assert_array_equal(trace["first_idx"].cpu().numpy(), first)
+    np.testing.assert_array_equal(trace["point2vox"].cpu().numpy(), p2v)
+
+
 def test_next_rows_verticality_vs_oracle():
     """Verticality = 1 - |n_z| of the radius-neighbourhood covariance vs scipy cKDTree + numpy eigh (fp64), 1e-5 absolute
     wherever the normal is well conditioned; same NaN set (fewer than 3 neighbours) and the same NaN replacement."""
@@ -709,6 +719,16 @@ def test_next_rows_verticality_vs_oracle():
     assert np.abs(ours[good] - ref[good]).max() < 1e-5
     filled = op.replace_nan(ref)
     assert np.abs(ours[nan] - filled[nan]).max() < 1e-4 and ours.dtype == np.float32
+
+
+def test_next_rows_verticality_vs_hand_derived_planes():
+    """The HIP verticality feature against answers that need no implementation (tests/kat_cases.verticality_planes): 1 - cos(theta)
+    on a plane whose normal is theta off the vertical."""
+    from kat_cases import verticality_planes
+    from treelearn_amd.util.prepare import compute_features
+    for pts, expect in verticality_planes():
+        v = compute_features(pts, search_radius=0.6).cpu().numpy()[:, 0]
+        assert np.abs(v - expect).max() < 1e-5, (expect, float(np.abs(v - expect).max()))
 
 
 def test_end_to_end_plot_pipeline_runs_and_is_deterministic():

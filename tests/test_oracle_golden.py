@@ -192,3 +192,23 @@ def test_g12_gradients_float64_second_opinion(golden_dir):
                      ("grad_l6_deconv", grads["unet.u.u.u.u.u.deconv.2.weight"][:, 1, 0, 1, :]), ("grad_sem3", grads["semantic_linear.3.weight"])):
         a = val.numpy(); b = g[key].astype(np.float64)
         assert np.abs(a - b).max() / np.abs(a).max() < 2.5e-2, key
+
+
+def test_oracle_verticality_vs_hand_derived_planes():
+    """oracle/prepare.verticality against answers written down from the definition (tests/kat_cases.verticality_planes): a plane whose
+    normal is theta off the vertical has verticality 1 - cos(theta) at every point."""
+    from oracle import prepare as op
+    from kat_cases import verticality_planes
+    for pts, expect in verticality_planes():
+        v, _ = op.verticality(pts, 0.6)
+        assert not np.isnan(v).any()
+        assert np.abs(v - expect).max() < 1e-6, expect
+
+
+def test_oracle_voxel_downsample_vs_hand_worked_example():
+    from oracle import prepare as op
+    from kat_cases import voxel_downsample_by_hand
+    data, voxel, expect, first, p2v = voxel_downsample_by_hand()
+    out, f, m = op.voxelize(data, voxel)
+    np.testing.assert_allclose(out, expect, atol=1e-6)
+    np.testing.assert_array_equal(f, first); np.testing.assert_array_equal(m, p2v)
