@@ -86,6 +86,18 @@ def cpu_baseline(timeout_s=240):
         return dict(value=None, unit="Mpoints/s", cores=host_cores(), kind="port", sample=f"failed: {type(e).__name__}")
 
 
+def emit(res):
+    """The ONE JSON line, and the last thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be flushed
+    after Python's line when the process exits."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                        # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(res), flush=True)
+
+
 def power_probe(step_fn, seconds=2.5):
     """Board power and shader clock while the forward loops (rocm-smi sampled from a thread; not part of the timed region).
     The mid-level conv kernels run at the 1400 W cap, so the clock is part of the story."""
@@ -295,7 +307,7 @@ def main():
         if dist:
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(res)
         return
     if args.workload == "config4":
         if dist is None:
@@ -308,7 +320,7 @@ def main():
         model = model.cuda().eval()
         sec, total_pts, rows = sharded_plot(model, dist, rank, world, args.plot_tiles, args.steps, args.warmup)
         if rank == 0:
-            res = dict(metric="Mpoints/sec through sparse U-Net fwd (0.1 m voxel, 40x40 m tile)", value=total_pts / sec / 1e6, unit="Mpoints/s",
+            res = dict(metric=f"Mpoints/sec through sparse U-Net fwd ({cfg['voxel']:g} m voxel, 40x40 m tile)", value=total_pts / sec / 1e6, unit="Mpoints/s",
                        n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, higher_is_better=True, scaling="strong",
                        vs_baseline=None, dtype=args.dtype, data="synthetic",
                        config=dict(workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares) sharded "
@@ -317,7 +329,7 @@ def main():
                        roofline=None, cpu_baseline=None)
         dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(res)
         return
 
     cfg = CONFIGS[args.workload]
@@ -412,7 +424,7 @@ def main():
                     algorithmic_gflop_per_step=flops / 1e9, algorithmic_gb_per_step=byts / 1e9)
 
     if rank == 0:
-        res = dict(metric="Mpoints/sec through sparse U-Net fwd (0.1 m voxel, 40x40 m tile)",
+        res = dict(metric=f"Mpoints/sec through sparse U-Net fwd ({cfg['voxel']:g} m voxel, 40x40 m tile)",
                    value=total_pts * args.steps / dt / 1e6, unit="Mpoints/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=args.dtype, data="synthetic",
@@ -462,7 +474,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:                                    # noqa: BLE001
             pass
-        print(json.dumps(res), flush=True)
+        emit(res)
 
 
 if __name__ == "__main__":

@@ -12,4 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o p -- python
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 $Q > /dev/null 2> $O/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 $Q > /dev/null 2> $O/write.err
 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o p -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 $Q > /dev/null 2> $O/sq.err
+python tools/power_kernels.py > $O/power_per_layer.txt 2> $O/power.err
+python tools/dev_train_layers.py > $O/train_per_layer.txt 2> $O/train_layers.err
+python bench.py --workload config3 --steps 4 --warmup 2 > $O/bench_config3.json 2> $O/bench_config3.err
+python bench.py --workload config5 $Q > $O/bench_config5.json 2> $O/bench_config5.err
+python bench.py --workload config4 $Q > $O/bench_config4.json 2> $O/bench_config4.err
+mkdir -p $O/c3; rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o p -- python3 bench.py --workload config3 --steps 4 --warmup 2 > $O/bench_config3_profiled.json 2> $O/c3.err
 tail -c 400 $O/bench_unprofiled.json; ls $O/*

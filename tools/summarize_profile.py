@@ -73,7 +73,8 @@ def sq():
 sq()
 fetch = pmc("fetch", "FETCH_SIZE", "pmc_fetch_size.csv")
 write = pmc("write", "WRITE_SIZE", "pmc_write_size.csv")
-for name in ("bench_line.json", "bench_line_1_in_flight.json", "bench_unprofiled.json", "bench_unprofiled_1_in_flight.json"):
+for name in ("bench_line.json", "bench_line_1_in_flight.json", "bench_unprofiled.json", "bench_unprofiled_1_in_flight.json", "power_per_layer.txt",
+             "train_per_layer.txt", "bench_config3.json", "bench_config5.json", "bench_config4.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 ks1 = glob.glob(os.path.join(src, "stats1", "**", "*kernel_stats.csv"), recursive=True)
