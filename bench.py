@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
     ap.add_argument("--tiles-in-flight", type=int, default=3, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
+    ap.add_argument("--layer-table", default=None, help="write the per-launch table of the conv event pass (time, work, both roofs) to this file")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"])
     ap.add_argument("--plot-tiles", type=int, default=64, help="config4: tiles of the plot")
     ap.add_argument("--no-sharded-plot", action="store_true", help="N > 1: skip the config-4 sharded tile loop + gather measurement")
@@ -405,6 +406,23 @@ def main():
         for _, _, m in recs[:per]:
             f, b, _ = conv_work(m); flops += f; byts += b
         avg_ms = tot_ms / per
+        if args.layer_table:
+            # per launch: measured time against its own two roofs -- matrix work if every tap of every 32-row block is contracted
+            # (what an output-stationary MFMA kernel must do: "dense-equivalent") and compulsory bytes
+            with open(args.layer_table, "w") as f:
+                f.write(f"# {args.workload} {args.dtype}, one tile at a time inside the event pass; ms = mean of {reps} runs (HIP events on the launch stream)\n")
+                f.write("#  i   K  Cin->Cout     rows  pairs/row      ms  TFLOP/s(present)  dense-equiv %of 2.5PF  compulsory GB  GB/s  t_mfma@2.5PF  t_hbm@8TB/s (ms)\n")
+                lo = 0.0
+                for i in range(per):
+                    m = recs[i][2]
+                    ms = sum(recs[i + r * per][0].elapsed_time(recs[i + r * per][1]) for r in range(reps)) / reps
+                    fl, by, pairs = conv_work(m)
+                    dense = 2.0 * ((m["n_out"] + 31) // 32 * 32) * m["K"] * m["Cin"] * m["Cout"]
+                    t_m, t_h = dense / (PEAK_MFMA_BF16_TFLOPS * 1e12) * 1e3, by / (PEAK_HBM_GBS * 1e9) * 1e3
+                    lo += max(t_m, t_h)
+                    f.write(f"{i:4d} {m['K']:3d} {m['Cin']:4d}->{m['Cout']:<4d} {m['n_out']:8d} {pairs / max(m['n_out'], 1):10.2f} {ms:7.3f} {fl / ms / 1e9:17.0f} "
+                            f"{100 * dense / (ms * 1e-3) / (PEAK_MFMA_BF16_TFLOPS * 1e12):22.1f} {by / 1e9:14.3f} {by / ms / 1e6:5.0f} {t_m:13.3f} {t_h:12.3f}\n")
+                f.write(f"# sum of measured times {tot_ms:.3f} ms; sum over launches of max(t_mfma at 2.5 PFLOP/s on dense-equivalent work, t_hbm at 8 TB/s on compulsory bytes) = {lo:.3f} ms\n")
         if args.dtype == "fp32":
             ach = flops / (tot_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", achieved=ach, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_MFMA_F32_TFLOPS, traffic=None)
