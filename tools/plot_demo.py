@@ -39,6 +39,9 @@ ens = ensemble(res[4], res[0], res[1], res[2], res[3], res[5], res[6], res[7], r
 coords, sem, off, infeat = (ens[i].cpu().numpy() for i in (0, 1, 3, 7)); t0 = lap("D2H of what grouping reads", t0)
 cfg = dict(tree_conf_thresh=0.5, tau_vert=0.0, tau_off=1e9, tau_group=0.3, tau_min=20, use_hdbscan=False)
 inst = get_instances(coords, off, sem, cfg, infeat[:, -1], 0, 0, -1, 1); t0 = lap("grouping (DBSCAN)", t0)
+cfg_h = dict(cfg, use_hdbscan=True, tau_min=50)
+inst_h = get_instances(coords, off, sem, cfg_h, infeat[:, -1], 0, 0, -1, 1); t0 = lap("grouping (HDBSCAN, extra)", t0)
+print(f"HDBSCAN grouping over {int((inst_h != 0).sum())} points: {int(inst_h.max())} instances, {int((inst_h == -1).sum())} unassigned")
 tree = inst != 0
 if tree.any() and (inst[tree] != -1).any():
     inst[tree] = assign_remaining_points_nearest_neighbor(coords[tree] + off[tree], inst[tree], -1)

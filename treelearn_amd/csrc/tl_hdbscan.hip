@@ -228,14 +228,14 @@ int tl_hdbscan_labels_host(const int32_t* e_src, const int32_t* e_dst, const dou
   }
   // --- _condense_tree
   const int64_t root = 2 * (n - 1);
+  // breadth-first list of the nodes below `start` (level by level, left before right -- the order sklearn's bfs_from_hierarchy
+  // gives); the output vector doubles as the queue, so the ~n calls on small sub-trees allocate nothing
   auto bfs = [&](int64_t start, std::vector<int64_t>& out) {
     out.clear();
-    std::vector<int64_t> queue{start}, nxt;
-    while (!queue.empty()) {
-      out.insert(out.end(), queue.begin(), queue.end());
-      nxt.clear();
-      for (int64_t x : queue) if (x >= n) { nxt.push_back(left[x - n]); nxt.push_back(right[x - n]); }
-      queue.swap(nxt);
+    out.push_back(start);
+    for (size_t head = 0; head < out.size(); ++head) {
+      const int64_t x = out[head];
+      if (x >= n) { out.push_back(left[x - n]); out.push_back(right[x - n]); }
     }
   };
   struct Row { int64_t parent, child; double lambda; int64_t size; };
