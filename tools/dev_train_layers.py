@@ -27,8 +27,8 @@ for li, lv in enumerate(geom.levels):
     for ci, co, kind, mult in shapes:
         if mult == 0: continue
         if kind == "subm": table, n_out, n_in, K, ttab = lv.nbr, lv.n, lv.n, 27, lv.nbr
-        elif kind == "down": nx = geom.levels[li + 1]; table, n_out, n_in, K, ttab = nx.child, nx.n, lv.n, 8, lv.inv
-        else: nx = geom.levels[li + 1]; table, n_out, n_in, K, ttab = lv.inv, lv.n, nx.n, 8, nx.child
+        elif kind == "down": nx = geom.levels[li + 1]; table, n_out, n_in, K, ttab = lv.child, nx.n, lv.n, 8, lv.inv
+        else: nx = geom.levels[li + 1]; table, n_out, n_in, K, ttab = lv.inv, lv.n, nx.n, 8, lv.child
         if table is None or ttab is None: continue
         x = torch.randn(n_in, ci, device="cuda").bfloat16(); g = torch.randn(n_out, co, device="cuda").bfloat16()
         w = (torch.randn(K, co, ci, device="cuda") * 0.05).bfloat16(); wt = w.permute(0, 2, 1).contiguous()

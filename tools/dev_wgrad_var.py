@@ -22,7 +22,7 @@ for li in range(0, 5):
     shapes = [(C, C, "subm"), (2 * C, C, "subm"), (C, C + 32, "down"), (C + 32, C, "up")]
     for ci, co, kind in shapes:
         if kind == "subm": table, n_out, n_in, K = lv.nbr, lv.n, lv.n, 27
-        elif kind == "down": nx = geom.levels[li + 1]; table, n_out, n_in, K = nx.child, nx.n, lv.n, 8
+        elif kind == "down": nx = geom.levels[li + 1]; table, n_out, n_in, K = lv.child, nx.n, lv.n, 8
         else: nx = geom.levels[li + 1]; table, n_out, n_in, K = lv.inv, lv.n, nx.n, 8
         x = torch.randn(n_in, ci, device="cuda").bfloat16(); g = torch.randn(n_out, co, device="cuda").bfloat16()
         ref = None; row = []

@@ -32,7 +32,7 @@ class _SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, ref, residual):
         x = feats.contiguous()
-        out = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual)
+        out = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
         ctx.save_for_backward(x, weight)
         ctx.ref = ref
         return out
@@ -51,7 +51,7 @@ def sparse_conv(feats, weight, ref, residual=None):
     if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)):
         return _SparseConvFn.apply(feats, weight, ref, residual)
     x = feats.contiguous()
-    return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual)
+    return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
 
 
 class _BNReLUTrainFn(torch.autograd.Function):

@@ -17,10 +17,13 @@ from . import ops
 
 class TableRef:
     """A rulebook plus what dgrad needs: the table of the transposed conv and whether taps flip."""
-    __slots__ = ("table", "n_out", "t_table", "n_in", "flip")
+    __slots__ = ("table", "n_out", "t_table", "n_in", "flip", "one_hot", "t_one_hot")
 
-    def __init__(self, table, n_out, t_table, n_in, flip):
+    def __init__(self, table, n_out, t_table, n_in, flip, one_hot=False, t_one_hot=False):
         self.table, self.n_out, self.t_table, self.n_in, self.flip = table, n_out, t_table, n_in, flip
+        # exactly one valid entry per row (the parent table of an inverse conv = the transposed table of a strided conv): the kernels
+        # gather that row once instead of issuing K gathers of which K - 1 are absent
+        self.one_hot, self.t_one_hot = one_hot, t_one_hot
 
 
 def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
@@ -33,14 +36,14 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
             w = w.flip(0)
         wt = w.contiguous().to(grad_out.dtype)                             # kernel layout [K]["Cout"=Cin]["Cin"=Cout]
         if ci <= 224:
-            gx = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in)
+            gx = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in, one_hot=ref.t_one_hot)
         else:
             # the 2C -> C convs of the decoder have up to 448 "output" channels when transposed; the MFMA kernels cover
             # <= 224, so run column slices of the transposed weights into column views of the result
             gx = torch.empty((ref.n_in, ci), dtype=grad_out.dtype, device=grad_out.device)
             step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
             for s in range(0, ci, step):
-                ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=gx[:, s:s + step])
+                ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=gx[:, s:s + step], one_hot=ref.t_one_hot)
     if need_gw:
         gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K)               # [K, Cout, Cin] fp32, present pairs only
         gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)

@@ -158,7 +158,7 @@ class SparseConv3d(SparseConvolution):
         assert int(self.kernel_size) == 2 and int(self.stride) == 2
         if lv.child is None:
             raise ValueError("geometry was built with too few levels for this SparseConv3d")
-        return TableRef(lv.child, x.geometry.levels[x.level + 1].n, lv.inv, lv.n, False), x.level + 1
+        return TableRef(lv.child, x.geometry.levels[x.level + 1].n, lv.inv, lv.n, False, t_one_hot=True), x.level + 1
 
 
 class SparseInverseConv3d(SparseConvolution):
@@ -168,4 +168,4 @@ class SparseInverseConv3d(SparseConvolution):
     def _table(self, x):
         assert int(self.kernel_size) == 2 and x.level > 0
         lv = x.geometry.levels[x.level - 1]
-        return TableRef(lv.inv, lv.n, lv.child, x.geometry.levels[x.level].n, False), x.level - 1
+        return TableRef(lv.inv, lv.n, lv.child, x.geometry.levels[x.level].n, False, one_hot=True), x.level - 1
