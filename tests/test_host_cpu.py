@@ -255,3 +255,18 @@ def test_hdbscan_host_stage_prim_order_of_a_shuffled_tree():
     assert set(la.tolist()) >= {0, 1}
     s[0] = s[1]; d[0] = d[1]                                  # a repeated edge: no longer a spanning tree
     assert L.tl_hdbscan_prim_order_host(s.ctypes.data, d.ctypes.data, w.ctypes.data, n, os_.ctypes.data, od.ctypes.data, ow.ctypes.data) != 0
+
+
+def test_conv_wrapper_rejects_a_rulebook_of_the_wrong_shape():
+    """The C ABI takes the rulebook as a bare pointer; ops.conv_fwd / conv_wgrad check its shape first, so handing over the table of
+    another level raises instead of reading out of bounds on the device.  (Argument checks only: nothing is launched.)"""
+    from treelearn_amd import ops
+    x = torch.zeros(10, 32, dtype=torch.bfloat16); w = torch.zeros(27, 32, 32, dtype=torch.bfloat16)
+    for bad in (torch.zeros(27, 9, dtype=torch.int32), torch.zeros(8, 10, dtype=torch.int32), torch.zeros(27, 10, dtype=torch.int64),
+                torch.zeros(10, 27, dtype=torch.int32).t()):
+        with pytest.raises(ValueError, match="rulebook"):
+            ops.conv_fwd(x, w, bad, 10)
+        with pytest.raises(ValueError, match="rulebook"):
+            ops._check_table(bad, 27, 10, x.device)          # what conv_wgrad calls before its launch
+    with pytest.raises(ValueError, match="needs a rulebook"):
+        ops.conv_fwd(x, w, None, 10)

@@ -32,6 +32,17 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+def _check_table(table, K, n_out, device):
+    """The C ABI takes the rulebook as a bare pointer: a table of the wrong level (too few columns) would be read out of bounds on the
+    device, so its shape is checked here."""
+    if table is None:
+        if K != 1:
+            raise ValueError(f"a {K}-tap conv needs a rulebook")
+        return
+    if table.dtype != torch.int32 or table.dim() != 2 or tuple(table.shape) != (K, n_out) or not table.is_contiguous() or table.device != device:
+        raise ValueError(f"rulebook must be a contiguous int32 [{K}, {n_out}] tensor on {device}, got {table.dtype} {tuple(table.shape)} on {table.device}")
+
+
 def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
              in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False,
              out2=None, out3=None, one_hot=False):
@@ -47,6 +58,7 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
         raise ValueError("bad output view")
     if w_packed.dtype != x.dtype or out.dtype != x.dtype:
         raise ValueError("dtype mismatch")
+    _check_table(table, K, n_out, x.device)
     a = _hip.ConvArgs()
     a.in_ = x.data_ptr(); a.in_ld = x.stride(0)
     a.weight = w_packed.data_ptr()
@@ -104,6 +116,9 @@ def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: in
     if not (x.is_cuda and g.is_cuda):
         raise RuntimeError("conv_wgrad: tensors must live on the GPU; the HIP path has no CPU fallback")
     ci, co = x.shape[1], g.shape[1]
+    if g.shape[0] != n_out:
+        raise ValueError(f"grad_out has {g.shape[0]} rows, the rulebook {n_out}")
+    _check_table(table, K, n_out, x.device)
     gw = torch.empty((K, co, ci), dtype=torch.float32, device=x.device)
     ws = torch.empty(int(L.tl_conv_wgrad_ws_floats(n_out, K, ci, co)), dtype=torch.float32, device=x.device)
     _hip.check(L.tl_conv_wgrad(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(table) if table is not None else None, n_out, x.shape[0],
