@@ -372,6 +372,8 @@ def main():
         return out
 
     step(); torch.cuda.synchronize()                                   # builds the inference plan (packed weights) before steps spread over streams
+    if streams:                                                        # setup, like the plan: one forward per stream, so that every stream's pool of the
+        run_steps(nfl); torch.cuda.synchronize()                       # caching allocator exists however small --warmup is (a cold pool = hipMalloc in the timed region)
     run_steps(max(args.warmup, 1))
     torch.cuda.synchronize()
     if dist: dist.barrier()
