@@ -135,8 +135,8 @@ def pmc_traffic(dtype, workload):
             d = json.load(open(f))
         except Exception:                                    # noqa: BLE001
             continue
-        if d.get("dtype") == dtype and d.get("workload") == workload:
-            best = (d, f)
+        if d.get("dtype") == dtype and d.get("workload") == workload and (best is None or d.get("sequence", 0) >= best[0].get("sequence", 0)):
+            best = (d, f)                                    # the most recently collected set (`sequence` = collection time), else the last path
     return best
 
 

@@ -85,6 +85,7 @@ if fetch is not None and write is not None:
          "fetch_size_kb_per_step": fetch / forwards["fetch"], "write_size_kb_per_step": write / forwards["write"],
          "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled (MI355X_MICROARCH.md HBM section); units KB",
          "hbm_gb_per_step": (2 * fetch / forwards["fetch"] + write / forwards["write"]) * 1024 / 1e9,
-         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 --no-cpu-baseline --no-fp32-mode --no-power-probe"}
+         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --tiles-in-flight 1 --no-cpu-baseline --no-fp32-mode --no-power-probe",
+         "sequence": int(__import__("time").time())}     # bench.py reads the set with the largest sequence
     json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(t, indent=1))
