@@ -86,9 +86,10 @@ def cpu_baseline(timeout_s=240):
         return dict(value=None, unit="Mpoints/s", cores=host_cores(), kind="port", sample=f"failed: {type(e).__name__}")
 
 
-def emit(res):
-    """The ONE JSON line, and the last thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be flushed
-    after Python's line when the process exits."""
+def emit(res, used_rccl=False):
+    """The ONE JSON line, and the last thing on stdout.  RCCL writes a version banner that reaches stdout only when the process
+    exits (after anything Python prints; flushing C stdio does not bring it forward), so a rank that created a process group ends
+    with os._exit right after its line: the group is already destroyed, nothing else is pending, and the banner never follows the result."""
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
@@ -96,6 +97,9 @@ def emit(res):
         pass
     sys.stdout.flush()
     print(json.dumps(res), flush=True)
+    if used_rccl:
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def power_probe(step_fn, seconds=2.5):
@@ -308,7 +312,7 @@ def main():
         if dist:
             dist.destroy_process_group()
         if rank == 0:
-            emit(res)
+            emit(res, used_rccl=bool(dist))
         return
     if args.workload == "config4":
         if dist is None:
@@ -321,7 +325,7 @@ def main():
         model = model.cuda().eval()
         sec, total_pts, rows = sharded_plot(model, dist, rank, world, args.plot_tiles, args.steps, args.warmup)
         if rank == 0:
-            res = dict(metric=f"Mpoints/sec through sparse U-Net fwd ({cfg['voxel']:g} m voxel, 40x40 m tile)", value=total_pts / sec / 1e6, unit="Mpoints/s",
+            res = dict(metric="Mpoints/sec through sparse U-Net fwd (0.1 m voxel, 40x40 m tile)", value=total_pts / sec / 1e6, unit="Mpoints/s",
                        n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, higher_is_better=True, scaling="strong",
                        vs_baseline=None, dtype=args.dtype, data="synthetic",
                        config=dict(workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares) sharded "
@@ -330,7 +334,7 @@ def main():
                        roofline=None, cpu_baseline=None)
         dist.destroy_process_group()
         if rank == 0:
-            emit(res)
+            emit(res, used_rccl=True)
         return
 
     cfg = CONFIGS[args.workload]
@@ -487,14 +491,7 @@ def main():
     if dist:
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes a version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise come
-        # out at exit, after the result: flush it first so that the JSON line is the last line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:                                    # noqa: BLE001
-            pass
-        emit(res)
+        emit(res, used_rccl=bool(dist))
 
 
 if __name__ == "__main__":

@@ -543,3 +543,25 @@ def test_feature_buffers_beyond_2g_and_4g_bytes(dt, n_in, cin, cout):
     subc = torch.full_like(sub, -1); subc[sub >= 0] = inv.to(torch.int32)
     ref = osp.conv_table(x[used.long()].float().cpu(), w.to(dt).float().cpu(), subc.cpu().numpy()).numpy()
     assert rel_err(out[rows].float().cpu().numpy(), ref) < (1.2e-2 if dt == torch.bfloat16 else 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py itself
+@pytest.mark.parametrize("flags", [
+    ["--workload", "config2", "--steps", "3", "--warmup", "1"],
+    ["--workload", "config3", "--steps", "1", "--warmup", "1"],
+    ["--workload", "config4", "--plot-tiles", "3", "--steps", "2", "--warmup", "1"],
+])
+def test_bench_prints_one_json_line_last(flags):
+    """Every workload of bench.py end to end in a child process: exit code 0 and the LAST line of stdout is the JSON line with the
+    contract's keys (config4 creates an RCCL group, whose version banner must not follow the result)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags, "--no-cpu-baseline", "--no-fp32-mode", "--no-power-probe"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "workload" in d["config"]
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
