@@ -481,7 +481,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["config"]["cpu_baseline_sample"] = "26x26 m tile of the same generator / voxel size / model (about 40 % of the points of the timed tile), 1 forward"
-    if dist and world > 1 and args.workload == "config2" and not args.no_sharded_plot:
+    if dist and (world > 1 or os.environ.get("TL_BENCH_FORCE_DIST") == "1") and args.workload == "config2" and not args.no_sharded_plot:
         # BASELINE config 4 alongside: 8 tiles per rank through the sharded tile loop WITH the record gather timed (weak form of the
         # 64-tiles-on-8-GPUs plot; `--workload config4` times the fixed 64-tile plot instead)
         sec, tp, rows = sharded_plot(model, dist, rank, world, 8 * world, 2, 1)

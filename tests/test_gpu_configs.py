@@ -550,14 +550,19 @@ def test_feature_buffers_beyond_2g_and_4g_bytes(dt, n_in, cin, cout):
     ["--workload", "config2", "--steps", "3", "--warmup", "1"],
     ["--workload", "config3", "--steps", "1", "--warmup", "1"],
     ["--workload", "config4", "--plot-tiles", "3", "--steps", "2", "--warmup", "1"],
+    ["--workload", "config2", "--steps", "2", "--warmup", "1", "FORCE_DIST"],          # the N > 1 code path (RCCL group + the sharded-plot extra) on one GPU
 ])
 def test_bench_prints_one_json_line_last(flags):
     """Every workload of bench.py end to end in a child process: exit code 0 and the LAST line of stdout is the JSON line with the
     contract's keys (config4 creates an RCCL group, whose version banner must not follow the result)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if "FORCE_DIST" in flags:
+        flags = [f for f in flags if f != "FORCE_DIST"]
+        env.update(TL_BENCH_FORCE_DIST="1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags, "--no-cpu-baseline", "--no-fp32-mode", "--no-power-probe"],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     d = json.loads(last)
@@ -565,3 +570,5 @@ def test_bench_prints_one_json_line_last(flags):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and "workload" in d["config"]
     assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
+    if env.get("TL_BENCH_FORCE_DIST") == "1":
+        assert d["sharded_plot"]["value"] > 0 and d["sharded_plot"]["collectives_per_plot"] == 2
