@@ -1,7 +1,7 @@
 """Golden g12 (7-level training step): per-slice gradient errors vs the reference, and the level-4 256->128 wgrad against a float64
 gather + matmul of the SAME saved activations / output gradients (separates kernel error from upstream numerics)."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import random_state_dict

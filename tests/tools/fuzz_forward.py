@@ -1,8 +1,8 @@
 """Soak: random small tiles (odd point counts, thin slabs, unequal batches, voxel 0.1-0.3, with / without input features and a
 preset spatial_shape) through the HIP forward in fp32 against the oracle, the bf16 mode against fp32, and one training step for
-finiteness.      python tools/fuzz_forward.py [first_seed] [count]"""
+finiteness.      python tests/tools/fuzz_forward.py [first_seed] [count]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import model as om
 from treelearn_amd.model import TreeLearn

@@ -1,7 +1,7 @@
 """Measure plot preparation on a synthetic raw cloud: device voxel down-sample + verticality, beside the
 numpy/scipy restatement (oracle/prepare.py, one core) on a bounded sample."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from treelearn_amd.synth import CONFIGS, make_tile
 from treelearn_amd.util.prepare import compute_features, voxelize

@@ -2,7 +2,7 @@
 host offset-label derivation, beside the CPU restatement of the reference chain (oracle/tiles.py; no npz I/O, which the
 reference additionally pays)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from treelearn_amd.synth import make_tile
 from treelearn_amd.util.tiles import PlotTiler
