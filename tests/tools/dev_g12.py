@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from treelearn_amd.model import TreeLearn
 from treelearn_amd.synth import random_state_dict
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "g12_train7.npz"))
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "golden", "g12_train7.npz"))
 cfg = json.loads(str(g["cfg"]))
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=cfg["spatial_shape"], voxel_size=cfg["voxel_size"], **cfg["cfg"])
 model.load_state_dict(random_state_dict(cfg["seed"], **cfg["cfg"]), strict=True); model = model.cuda().train()
