@@ -223,7 +223,9 @@ int tl_affine_relu(const void* in, int64_t in_ld, void* out, int64_t out_ld, int
  *   UNBIASED variance like torch, num_batches_tracked (nullable, i64[1]) += 1.  y = relu(x * scale + shift) is then one
  *   tl_affine_relu call.  ws f64[tl_bn_ws_doubles(n, C)].  C % 4 == 0, C <= 1024.
  * tl_bn_train_bwd: dy [n, C] (f32 or bf16) = gradient w.r.t. y -> dx [n, C] in x's dtype, dgamma, dbeta f32[C]; `relu` != 0
- *   masks dy where y <= 0 (y is recomputed from x).  Under mixed precision (the reference trains under autocast,
+ *   masks dy where y <= 0 (y is recomputed from x); dx_add (nullable, x's dtype, [n, C]) is added to dx in the same pass -- the
+ *   gradient reaching x along its OTHER use (the residual / skip connection: x feeds both this BatchNorm and an identity path), so
+ *   autograd's separate accumulation kernel disappears.  Under mixed precision (the reference trains under autocast,
  *   tools/training/train.py:32) activations and their gradients stay bf16 between layers; all statistics are fp64 / fp32. */
 int64_t tl_bn_ws_doubles(int64_t n, int C);
 int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, const float* gamma, const float* beta, float eps,
@@ -231,7 +233,7 @@ int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, co
                       float* running_var, int64_t* num_batches_tracked, tl_stream_t stream);
 int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int64_t dld, int dy_dtype, int64_t n, int C,
                     const float* mean, const float* rstd, const float* scale, const float* shift, int relu, double* ws,
-                    float* dgamma, float* dbeta, void* dx, int64_t xld, tl_stream_t stream);
+                    float* dgamma, float* dbeta, void* dx, int64_t xld, const void* dx_add, int64_t dx_add_ld, tl_stream_t stream);
 
 /* Keep rows where mask != 0 (masks_inner filtering before D2H, util/pipeline.py:100-103).
  * in f32[n,C] -> out f32[count,C]; count i32[1] device.  Stable (input order kept).

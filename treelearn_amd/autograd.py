@@ -56,10 +56,14 @@ def sparse_conv(feats, weight, ref, residual=None):
 
 class _BNReLUTrainFn(torch.autograd.Function):
     """y = relu?(BatchNorm1d_train(x)) on the HIP kernels (tl_bn_train_stats + tl_affine_relu forward, tl_bn_train_bwd backward):
-    the `norm_fn(C), nn.ReLU()` pairs of reference blocks.py:55-70,102-123 / tree_learn.py:42-46 in training mode."""
+    the `norm_fn(C), nn.ReLU()` pairs of reference blocks.py:55-70,102-123 / tree_learn.py:42-46 in training mode.
+    With `skip`, x itself comes back as a second output: the block's identity / skip path takes THAT tensor instead of x, so x has one
+    consumer in the graph and the gradient of its other use arrives here as `dskip` and is added inside the backward kernel
+    (tl_bn_train_bwd's dx_add) -- otherwise autograd accumulates the two gradients of every residual / skip fan-out with a kernel of
+    its own (26 per step of the default architecture)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, relu):
+    def forward(ctx, x, gamma, beta, bn, relu, skip):
         x = x.contiguous()
         track = bn.track_running_stats and bn.running_mean is not None
         st = ops.bn_train_stats(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), bn.eps,
@@ -68,21 +72,25 @@ class _BNReLUTrainFn(torch.autograd.Function):
         y = ops.affine_relu(x, st[2], st[3], relu)
         ctx.save_for_backward(x, st)
         ctx.relu = relu
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, st = ctx.saved_tensors
         dy = dy.contiguous()
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
-        dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu)               # dx in x's dtype (bf16 stays bf16 under mixed precision)
-        return dx, dgamma, dbeta, None, None
+        if dskip is not None:
+            dskip = dskip.to(x.dtype).contiguous()
+        dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu, dx_add=dskip)    # dx in x's dtype (bf16 stays bf16 under mixed precision)
+        return dx, dgamma, dbeta, None, None, None
 
 
-def bn_relu_train(x, bn, relu=True):
-    """Training-mode BatchNorm1d `bn` (+ ReLU) of the feature matrix x on the HIP library."""
-    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu)
+def bn_relu_train(x, bn, relu=True, skip=False):
+    """Training-mode BatchNorm1d `bn` (+ ReLU) of the feature matrix x on the HIP library; skip=True returns (y, x passed through)."""
+    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu, skip)
 
 
 def fusable_bn(module, x):

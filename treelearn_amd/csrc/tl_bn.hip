@@ -160,7 +160,8 @@ template <typename TX, typename TG>
 __global__ void __launch_bounds__(kThreads) k_bn_bwd_apply(const TX* __restrict__ x, int64_t ld, const TG* __restrict__ dy, int64_t dld, int64_t n, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu, const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, TX* __restrict__ dx, int64_t xld) {
+                                                           const float* __restrict__ dbeta, TX* __restrict__ dx, int64_t xld,
+                                                           const TX* __restrict__ add, int64_t ald) {
   const int cg = C / 4;
   const int64_t total = n * cg;
   const float inv_n = 1.0f / (float)n;
@@ -175,6 +176,12 @@ __global__ void __launch_bounds__(kThreads) k_bn_bwd_apply(const TX* __restrict_
       const float gg = (relu && !(fmaf(v[c], sc[c], sh[c]) > 0.f)) ? 0.f : g[c];
       const float xh = (v[c] - mu[c]) * rs[c];
       o[c] = sc[c] * (gg - db[c] * inv_n - xh * dg[c] * inv_n);
+    }
+    if (add) {                                             // the gradient that reaches x along its other use (residual / skip), accumulated here
+      float a[4];
+      load4<TX>(add + r * ald + c0, a);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] += a[c];
     }
     store4(dx + r * xld + c0, o);
   }
@@ -212,9 +219,9 @@ int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, co
 
 int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int64_t dld, int dy_dtype, int64_t n, int C, const float* mean,
                     const float* rstd, const float* scale, const float* shift, int relu, double* ws, float* dgamma, float* dbeta, void* dx,
-                    int64_t xld, tl_stream_t stream) {
+                    int64_t xld, const void* dx_add, int64_t ald, tl_stream_t stream) {
   if (!x || !dy || !mean || !rstd || !scale || !shift || !ws || !dgamma || !dbeta || !dx || n <= 0 || C <= 0 || C % 4 || C > 4 * kThreads || ld % 4 ||
-      dld % 4 || xld % 4)
+      dld % 4 || xld % 4 || (dx_add && ald % 4))
     return TL_ERR_ARG;
   int blocks;
   const Part pt = partition(n, C, blocks);
@@ -227,7 +234,7 @@ int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int6
     TL_CHECK_LAUNCH();                                                                                                                 \
     k_bn_bwd_finish<<<C, 64, 0, s>>>(ws, blocks, C, dgamma, dbeta);                                                        \
     TL_CHECK_LAUNCH();                                                                                                                 \
-    k_bn_bwd_apply<TX, TG><<<g, kThreads, 0, s>>>((const TX*)x, ld, (const TG*)dy, dld, n, C, mean, rstd, scale, shift, relu, dgamma, dbeta, (TX*)dx, xld); \
+    k_bn_bwd_apply<TX, TG><<<g, kThreads, 0, s>>>((const TX*)x, ld, (const TG*)dy, dld, n, C, mean, rstd, scale, shift, relu, dgamma, dbeta, (TX*)dx, xld, (const TX*)dx_add, ald); \
     TL_CHECK_LAUNCH();                                                                                                                 \
   } while (0)
   if (x_dtype == TL_F32 && dy_dtype == TL_F32) TL_BN_BWD(float, float);

@@ -88,10 +88,13 @@ class ResidualBlock(SparseModule):
             spconv.SubMConv3d(out_channels, out_channels, kernel_size=int(kernel_size), padding=pad, bias=False, indice_key=indice_key))
 
     def forward(self, input):
-        identity = input.replace_feature(input.features)
-        res = self.i_branch(identity).features
         last = len(self.conv_branch) - 1
-        return self.conv_branch[last](self.conv_branch(input, stop=last), residual=res)      # the add rides in the last conv's epilogue
+        # the input feeds the conv branch AND the identity branch: in training the first BatchNorm hands it back (`skip`) and the
+        # identity branch takes that, so the two gradients of the fan-out are added inside the BatchNorm backward kernel
+        branch, skip = self.conv_branch(input, stop=last, want_skip=True)
+        identity = input.replace_feature(skip if skip is not None else input.features)
+        res = self.i_branch(identity).features
+        return self.conv_branch[last](branch, residual=res)      # the add rides in the last conv's epilogue
 
 
 class UBlock(nn.Module):
@@ -116,9 +119,10 @@ class UBlock(nn.Module):
 
     def forward(self, input):
         output = self.blocks(input)
-        identity = output.replace_feature(output.features)
         if len(self.nPlanes) > 1:
-            dec = self.deconv(self.u(self.conv(output)))
-            output = output.replace_feature(torch.cat((identity.features, dec.features), dim=1))
+            down, skip = self.conv(output, want_skip=True)     # same fan-out as in ResidualBlock: skip = the features the concat takes
+            identity = skip if skip is not None else output.features
+            dec = self.deconv(self.u(down))
+            output = output.replace_feature(torch.cat((identity, dec.features), dim=1))
             output = self.blocks_tail(output)
         return output

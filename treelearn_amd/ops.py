@@ -177,15 +177,20 @@ def bn_train_stats(x, gamma, beta, eps, momentum, running_mean=None, running_var
     return st
 
 
-def bn_train_bwd(x, dy, st, relu):
-    """(dx, dgamma, dbeta) of y = relu?(batchnorm_train(x)) given dy (tl_bn_train_bwd); st = bn_train_stats' result."""
+def bn_train_bwd(x, dy, st, relu, dx_add=None):
+    """(dx, dgamma, dbeta) of y = relu?(batchnorm_train(x)) given dy (tl_bn_train_bwd); st = bn_train_stats' result; dx_add (x's dtype
+    and shape) is added to dx in the same pass."""
     L = _hip.lib()
     n, C = x.shape
     dev = x.device
     ws = torch.empty(int(L.tl_bn_ws_doubles(n, C)), dtype=torch.float64, device=dev)
     dx = torch.empty((n, C), dtype=x.dtype, device=dev)
     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+    if dx_add is not None:
+        if dx_add.shape != x.shape or dx_add.dtype != x.dtype or dx_add.stride(1) != 1 or dx_add.device != dev:
+            raise ValueError("dx_add must match x in shape, dtype and device")
     _hip.check(L.tl_bn_train_bwd(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(dy), dy.stride(0), _hip.dtype_code(dy.dtype), n, C,
                                  _hip.ptr(st[0]), _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), int(bool(relu)), _hip.ptr(ws),
-                                 _hip.ptr(dgb[0]), _hip.ptr(dgb[1]), _hip.ptr(dx), dx.stride(0), _hip.stream()), "tl_bn_train_bwd")
+                                 _hip.ptr(dgb[0]), _hip.ptr(dgb[1]), _hip.ptr(dx), dx.stride(0), _hip.ptr(dx_add),
+                                 dx_add.stride(0) if dx_add is not None else 0, _hip.stream()), "tl_bn_train_bwd")
     return dx, dgb[0], dgb[1]

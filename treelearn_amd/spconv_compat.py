@@ -58,11 +58,15 @@ class SparseSequential(SparseModule):
     def __len__(self):
         return len(self._modules)
 
-    def forward(self, x, stop=None):
-        """`stop`: run only the first `stop` modules (the caller runs the rest itself, e.g. the last conv with its residual fused)."""
+    def forward(self, x, stop=None, want_skip=False):
+        """`stop`: run only the first `stop` modules (the caller runs the rest itself, e.g. the last conv with its residual fused).
+        `want_skip`: returns (result, skip) where skip is the input's feature matrix handed back by the FIRST module when that is a
+        BatchNorm served by the HIP training kernels (autograd.bn_relu_train(skip=True): the caller's identity / skip path must use
+        it instead of the input so that the two gradients of the fan-out are added inside the BatchNorm backward kernel), else None."""
         from .autograd import bn_relu_train, fusable_bn      # late import (autograd depends on ops)
         mods = list(self._modules.values())[:stop]
         i = 0
+        skip = None
         while i < len(mods):
             module = mods[i]
             if isinstance(module, SparseModule):
@@ -72,14 +76,18 @@ class SparseSequential(SparseModule):
                     if fusable_bn(module, x.features):
                         # training-mode BatchNorm1d (+ the ReLU behind it) on the HIP kernels instead of ATen's
                         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                        x = x.replace_feature(bn_relu_train(x.features, module, relu))
+                        if want_skip and i == 0 and x.features.requires_grad:
+                            y, skip = bn_relu_train(x.features, module, relu, skip=True)
+                            x = x.replace_feature(y)
+                        else:
+                            x = x.replace_feature(bn_relu_train(x.features, module, relu))
                         i += int(relu)
                     else:
                         x = x.replace_feature(module(x.features))
             else:
                 x = module(x)
             i += 1
-        return x
+        return (x, skip) if want_skip else x
 
 
 class SparseConvolution(SparseModule):
