@@ -93,6 +93,29 @@ def bn_relu_train(x, bn, relu=True, skip=False):
     return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu, skip)
 
 
+class _BiasAddFn(torch.autograd.Function):
+    """x + bias over millions of rows (the heads' Linear biases): the bias gradient is a column sum over all rows, done on the
+    statistics kernel (ops.column_sum) instead of ATen's dim-0 reduction."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x + bias.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        n, C = g.shape
+        if g.is_cuda and C % 4 == 0 and C <= 1024 and n > 1 and g.dtype in (torch.float32, torch.bfloat16):
+            db = ops.column_sum(g)
+        else:
+            db = g.float().sum(0)
+        return g, db
+
+
+def bias_add(x, bias):
+    return _BiasAddFn.apply(x, bias)
+
+
 def fusable_bn(module, x):
     """True when `module` is a BatchNorm1d that the HIP training kernels serve for x (batch statistics, affine, CUDA, C % 4 == 0)."""
     return (isinstance(module, torch.nn.BatchNorm1d) and module.training and module.affine and x.is_cuda and x.dim() == 2

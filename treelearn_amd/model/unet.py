@@ -28,7 +28,7 @@ class MLP(nn.Sequential):
         super().__init__(*modules)
 
     def forward(self, x):
-        from ..autograd import bn_relu_train, fusable_bn, sparse_conv
+        from ..autograd import bias_add, bn_relu_train, fusable_bn, sparse_conv
         from ..backward import TableRef
         mods = list(self._modules.values())
         i = 0
@@ -46,7 +46,7 @@ class MLP(nn.Sequential):
                 n = x.shape[0]
                 x = sparse_conv(x, m.weight.view(m.out_features, 1, 1, 1, m.in_features), TableRef(None, n, None, n, False))
                 if m.bias is not None:
-                    x = x + m.bias
+                    x = bias_add(x, m.bias)
             else:
                 x = m(x)
             i += 1

@@ -177,6 +177,15 @@ def bn_train_stats(x, gamma, beta, eps, momentum, running_mean=None, running_var
     return st
 
 
+def column_sum(x):
+    """sum over the rows of x [n, C] -> f32[C] on the BatchNorm statistics kernel (fp64 partial sums in a fixed order: deterministic;
+    one read of x at memory speed -- ATen's reduction over dim 0 of a [3.7 M, 32] matrix runs five times slower)."""
+    n, C = x.shape
+    ones = torch.ones(C, dtype=torch.float32, device=x.device)
+    st = bn_train_stats(x, ones, torch.zeros_like(ones), 1e-5, 0.0)
+    return st[0] * float(n)                                  # mean * n
+
+
 def bn_train_bwd(x, dy, st, relu, dx_add=None):
     """(dx, dgamma, dbeta) of y = relu?(batchnorm_train(x)) given dy (tl_bn_train_bwd); st = bn_train_stats' result; dx_add (x's dtype
     and shape) is added to dx in the same pass."""
