@@ -10,6 +10,8 @@ all through `tl_conv_fwd`.  wgrad (gW[k] = sum_o gout[o] (x) x[table[k][o]]) is 
 32x32x2 MFMAs over the present (output row, input row) pairs only, two pairs per instruction, no materialised gather; with bf16
 inputs (mixed-precision training) the bf16 32x32x16 MFMA takes 16 pairs per instruction from LDS-staged rows.
 """
+import os
+
 import torch
 
 from . import ops
@@ -26,10 +28,33 @@ class TableRef:
         self.one_hot, self.t_one_hot = one_hot, t_one_hot
 
 
+_side = {}
+
+
+def _side_stream(device):
+    st = _side.get(device)
+    if st is None:
+        st = _side[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
     co, ci = weight.shape[0], weight.shape[-1]
     K = weight.numel() // (co * ci)
     gx = gw = None
+    # dgrad and wgrad of a layer depend only on grad_out: with both wanted, the weight gradient goes to a side stream and the two run
+    # side by side (the wgrad kernels are latency-chain-bound and leave the matrix pipes mostly idle, the dgrad kernels are
+    # MFMA / power-bound -- the same complementarity the tile loop uses across tiles).  The main stream waits for the side stream
+    # before this function returns, so everything downstream stays stream-ordered.
+    overlap = need_gx and need_gw and grad_out.is_cuda and os.environ.get("TL_WGRAD_STREAM", "1") != "0"
+    if overlap:
+        cur = torch.cuda.current_stream(grad_out.device)
+        side = _side_stream(grad_out.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K)
+            gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+        gw.record_stream(cur)
     if need_gx:
         w = weight.detach().reshape(co, K, ci).permute(1, 2, 0)            # [K][Cin][Cout] = W[k]^T
         if ref.flip:
@@ -44,7 +69,9 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
             step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
             for s in range(0, ci, step):
                 ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=gx[:, s:s + step], one_hot=ref.t_one_hot)
-    if need_gw:
+    if need_gw and not overlap:
         gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K)               # [K, Cout, Cin] fp32, present pairs only
         gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+    if overlap:
+        cur.wait_stream(side)
     return gx, gw
