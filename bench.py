@@ -241,6 +241,13 @@ def training_step_bench(args, rank, world, dist):
                 cpu_baseline=None)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (fresh processes;
     this parent never initialises the GPU and never re-execs), relay their output, print rank 0's JSON line last."""
@@ -317,7 +324,7 @@ def main():
     if args.workload == "config4":
         if dist is None:
             import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1,
                           compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)

@@ -15,6 +15,13 @@ import numpy as np
 import pytest
 import torch
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 pytestmark = pytest.mark.gpu
 
 from oracle import model as om
@@ -422,7 +429,7 @@ def test_config4_64_tiles_loop_equals_single_forwards(plot64):
     assert torch.equal(res[0], torch.cat(sem)) and torch.equal(res[2], torch.cat(off)) and torch.equal(res[6], torch.cat(bb))
     assert torch.equal(res[4], torch.cat(coords))
     assert torch.equal(res[5], torch.cat([b["instance_labels"][b["masks_inner"]] for b in plot64]))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29671")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", _free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         made = []
@@ -458,7 +465,7 @@ def test_config4_whole_plot_order_of_operations_under_rccl():
     tree = inst != 0
     if tree.any() and (inst[tree] != -1).any() and (inst[tree] == -1).any():
         inst[tree] = assign_remaining_points_nearest_neighbor(coords[tree] + off[tree], inst[tree], -1)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29673")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = _free_port()
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         c2, ids = segment_plot_sharded(model, tiles, dict(voxel_size=0.1), cfg)
@@ -560,7 +567,7 @@ def test_bench_prints_one_json_line_last(flags):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     if "FORCE_DIST" in flags:
         flags = [f for f in flags if f != "FORCE_DIST"]
-        env.update(TL_BENCH_FORCE_DIST="1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        env.update(TL_BENCH_FORCE_DIST="1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags, "--no-cpu-baseline", "--no-fp32-mode", "--no-power-probe"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
