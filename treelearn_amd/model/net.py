@@ -8,6 +8,8 @@ and heads (treelearn_amd.model.engine) -- no spconv, no CPU fallback.
 """
 import functools
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -171,7 +173,12 @@ class TreeLearn(nn.Module):
             output['semantic_prediction_logits'] = logits
             output['offset_predictions'] = offsets
             return output
-        backbone_feats = backbone_output.features[v2p_map].float()      # bf16 under mixed precision; the heads run in fp32
+        backbone_feats = backbone_output.features[v2p_map]
+        if not (self.training and backbone_feats.dtype == torch.bfloat16 and os.environ.get("TL_HEAD_FP32") != "1"):
+            backbone_feats = backbone_feats.float()
+        # mixed-precision TRAINING keeps the heads in bf16 like the backbone (the reference's autocast runs their nn.Linear layers in
+        # half precision too; get_loss casts logits / offsets to fp32): half the traffic of the gather, the two MLPs and their backward
+        # over millions of points.  Inference / fp32 training: fp32 heads.
         output['backbone_feats'] = backbone_feats
         output['semantic_prediction_logits'] = self.semantic_linear(backbone_feats)
         output['offset_predictions'] = self.offset_linear(backbone_feats)
