@@ -26,3 +26,10 @@ for e in ev:
 print(f"device time of the step {tot / 1e3:.1f} ms, {len(ev)} device events; ATen / copies: {sum(t.values()) / 1e3:.2f} ms")
 for k, v in sorted(t.items(), key=lambda kv: -kv[1])[:25]:
     print(f"{c[k]:4d} {v / 1e3:7.2f} ms  {k}")
+# which Python lines the big ATen ops come from
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof2:
+    step(); torch.cuda.synchronize()
+rows = [r for r in prof2.key_averages(group_by_stack_n=8) if r.device_time_total > 300 and r.key.startswith("aten::")]
+for r in sorted(rows, key=lambda r: -r.device_time_total)[:14]:
+    st = [s_ for s_ in r.stack if ("treelearn_amd" in s_ or "bench" in s_ or "dev_train" in s_)][:3]
+    print(f"{r.count:4d} {r.key:26s} {r.device_time_total / 1e3:7.2f} ms  {' <- '.join(x.split('/')[-1][:60] for x in st)}")

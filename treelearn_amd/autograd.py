@@ -5,6 +5,7 @@ backward : dgrad = tl_conv_fwd over the transposed rulebook with W^T; wgrad = tl
            (reference: spconv's autograd functions behind SubMConv3d/SparseConv3d.forward,
            exercised by tools/training/train.py:40 `scaler.scale(loss).backward()`).
 """
+import math
 import weakref
 
 import torch
@@ -107,6 +108,15 @@ class _BiasAddFn(torch.autograd.Function):
         n, C = g.shape
         if g.is_cuda and C % 4 == 0 and C <= 1024 and n > 1 and g.dtype in (torch.float32, torch.bfloat16):
             db = ops.column_sum(g)
+        elif g.is_cuda and C < 4 and n >= 64 and g.dtype in (torch.float32, torch.bfloat16):
+            # 2 or 3 columns (the heads' output layers): fold rows so that the matrix is a multiple of four wide -- [n, C] read as
+            # [n / r, r * C] with r * C = lcm(C, 4) -- sum its columns on the same kernel, then add the r partial rows (and the < r
+            # left-over rows); ATen's dim-0 reduction of a [3.7 M, 3] matrix takes 0.6 ms
+            r = 4 // math.gcd(C, 4)
+            m = n - n % r
+            db = ops.column_sum(g[:m].view(m // r, r * C)).view(r, C).sum(0)
+            if m < n:
+                db = db + g[m:].float().sum(0)
         else:
             db = g.float().sum(0)
         return g, db
