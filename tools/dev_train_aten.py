@@ -33,3 +33,9 @@ rows = [r for r in prof2.key_averages(group_by_stack_n=8) if r.device_time_total
 for r in sorted(rows, key=lambda r: -r.device_time_total)[:14]:
     st = [s_ for s_ in r.stack if ("treelearn_amd" in s_ or "bench" in s_ or "dev_train" in s_)][:3]
     print(f"{r.count:4d} {r.key:26s} {r.device_time_total / 1e3:7.2f} ms  {' <- '.join(x.split('/')[-1][:60] for x in st)}")
+# the big casts / copies by input shape
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof3:
+    step(); torch.cuda.synchronize()
+rows = [r for r in prof3.key_averages(group_by_input_shape=True) if r.device_time_total > 150 and r.key in ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::sum", "aten::index", "aten::_index_put_impl_", "aten::add", "aten::add_", "aten::mul")]
+for r in sorted(rows, key=lambda r: -r.device_time_total)[:18]:
+    print(f"{r.count:4d} {r.key:24s} {r.device_time_total / 1e3:7.2f} ms  {str(r.input_shapes)[:110]}")
