@@ -804,7 +804,9 @@ def test_inverse_conv_one_hot_form(cin, cout, n_out):
 
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 9000), (64, 32, 27, 5000), (4, 32, 27, 7000), (96, 64, 8, 4100), (160, 192, 8, 700),
                                                (64, 32, 1, 6000), (224, 224, 27, 223), (96, 96, 27, 3000), (192, 96, 27, 1500),
-                                               (96, 96, 27, 120000), (192, 96, 27, 100100)])      # big + multiples of 96: the 96 x 96-block form
+                                               (96, 96, 27, 120000), (192, 96, 27, 100100),       # big levels: the dense-over-taps form (tl_wgrad_dense.hip)
+                                               (32, 32, 27, 70001), (64, 32, 27, 65000), (64, 64, 27, 99999), (128, 64, 27, 61000),
+                                               (96, 96, 27, 50000), (192, 96, 27, 40000)])        # multiples of 96 below the dense form's row threshold: 96 x 96 pair-list blocks
 def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     """tl_conv_wgrad (present pairs only, fp32 MFMA, deterministic) vs gather + matmul in float64."""
     from treelearn_amd import ops

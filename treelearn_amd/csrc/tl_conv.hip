@@ -245,6 +245,8 @@ static int g_dbg = 0;
 static int g_bf16_depth = 0, g_bf16_units = 0;   // 0 = kernel default
 extern int g_small_mode;                          // tl_conv_small.hip
 extern int g_head_mode;                           // tl_head.hip
+extern int g_wgrad_dense;                         // tl_wgrad_dense.hip
+extern int64_t g_wgrad_dense_min_rows;
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
@@ -270,6 +272,8 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "small_mode")) { g_small_mode = (int)value; return TL_OK; }
   if (!strcmp(key, "head_mode")) { g_head_mode = (int)value; return TL_OK; }
   if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
+  if (!strcmp(key, "wgrad_dense")) { g_wgrad_dense = (int)value; return TL_OK; }
+  if (!strcmp(key, "wgrad_dense_min_rows")) { g_wgrad_dense_min_rows = value; return TL_OK; }
   return TL_ERR_ARG;
 }
 

@@ -501,6 +501,11 @@ static int g_wgrad_var = 0, g_wgrad_chunk = 0;   // developer A/B: kernel varian
 static int g_wgrad_shared = 1;             // developer A/B (tl_dev_wgrad_mode bit 1): 0 = per-tap workgroups that gather gout per pair
 static int g_wgrad_bf16_mfma = 1;          // developer A/B (tl_dev_wgrad_mode): 0 = bf16 inputs through the fp32-MFMA kernel
 
+// tl_wgrad_dense.hip: the dense-over-taps form of the 27-tap convs of the big levels
+int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout);
+int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
+                          int Cout, float* gw, float* ws, hipStream_t s);
+
 extern "C" {
 
 #ifdef TL_DEV
@@ -512,7 +517,9 @@ int tl_dev_wgrad_mode(int mode) {
 #endif
 
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
-  const int64_t nparts = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves) * kWaves;
+  int64_t nparts = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves) * kWaves;
+  const int64_t dense = tl_wgrad_dense_slots(n_out, K, Cin, Cout);
+  if (dense > nparts) nparts = dense;
   return nparts * K * Cout * Cin;
 }
 
@@ -528,6 +535,10 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   int64_t nchunks_used = nchunks;
   const bool bf16_mfma = dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 &&
                          ((uintptr_t)gout) % 16 == 0 && g_wgrad_bf16_mfma;
+  if (bf16_mfma && table) {
+    const int rc = tl_launch_wgrad_dense((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, table, n_out, n_in, K, Cin, Cout, gw, ws, s);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
   if (bf16_mfma) {
     // bf16 matrix cores: blocks of at most 64 x 64 channels (partially filled blocks are masked); on big levels whose widths are
     // multiples of 96 (level 3: 96 -> 96, 192 -> 96) 96 x 96 blocks -- ONE 3 x 3 block per 96 x 96 (9 MFMAs per 16 pairs, rows

@@ -1,0 +1,281 @@
+// Weight gradient of the 27-tap convs of the big levels, "dense over taps" form (bf16 operands, fp32 accumulation):
+//     gW[k][co][ci] = sum_o gout[o][co] * x[nbr[k][o]][ci]            (reference: spconv's autograd behind SubMConv3d.forward,
+//                                                                      reached from tools/training/train.py:40 `.backward()`)
+// The contraction index of this GEMM is the ROW, so both MFMA operands are needed "8 rows of one channel per lane": a transposed
+// view of the row-major feature matrices.  tl_wgrad.hip compacts the present (output row, input row) pairs of a tap into a list and
+// gathers BOTH operands per pair; the list look-ups, two gathers and two LDS transpositions per 16 pairs form one dependent chain
+// per wave and the matrix pipes sit idle 90 % of the time.  Here nothing is compacted:
+//   * a workgroup walks blocks of MBR consecutive output rows; their gout tile goes to LDS ONCE (coalesced, double-buffered, one
+//     barrier per block) and is the A operand of every tap: its fragments are read with ds_read_b64_tr_b16, two reads per 32 channels;
+//   * every WAVE owns one (tap, 64- or 32-channel slice of Cin) job and keeps that job's [Cout x slice] fp32 tile in registers for the
+//     whole kernel; per step of 16 (32) rows it gathers the tap's input rows with full-row 16-B buffer loads straight through the
+//     rulebook column -- an absent neighbour is index -1 = an out-of-range offset = zeros from the hardware, it simply contributes
+//     nothing -- parks them in a wave-private LDS tile and reads the B fragments back transposed.  No pair lists, no per-pair gout
+//     gather, no branches: the loop body is straight-line code with PD steps of gathers in flight (counted vmcnt);
+//   * the matrix work is that of the dense form (27 / 16.4 of the present pairs at level 2, 27 / 5.5 at level 1) -- at most a quarter
+//     of the kernel's time on this part, which is what buys the simple dataflow;
+//   * LDS tiles are unpadded and XOR-swizzled by 16-B piece so that the 4 rows x 64 B a half-wave touches per transposing read fall
+//     into the four different 64-B quarters of the 256-B bank row (swz<>), and the 16-B row writes stay whole 128-B lines;
+//   * persistent workgroups (one per CU): workgroup bx owns the macro blocks {xcd * M/8 + slot + j * slots} -- every XCD a contiguous
+//     eighth of the rows (neighbouring rows gather overlapping input rows: one L2), interleaved inside the XCD -- and writes ONE
+//     partial tile set; k_wgrad_reduce_par adds the <= 128 partials in a fixed order.  Deterministic.
+#include "tl_conv_internal.h"
+#include <atomic>
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) s16x4* lds4;
+
+// 16-B piece p of row r of a tile with row pitch P bytes lives at piece slot p ^ swz<P>(r)
+template <int P>
+static __device__ __forceinline__ int swz(int r) {
+  if constexpr ((P / 64) % 2 == 1) return 0;                       // odd multiple of 64 B: consecutive rows already rotate through the quarters
+  else if constexpr ((P / 64) % 4 == 2) return ((r >> 1) & 1) << 2;
+  else return (r & 3) << 2;
+}
+
+// NBO = Cout / 32; NBIW = 32-channel blocks of the wave's Cin slice (1 or 2); KS = 16-row MFMA steps per gather step;
+// PD = gather steps in flight per wave (2 or 4); NW = waves per workgroup
+template <int NBO, int NBIW, int KS, int PD, int NW>
+__global__ void __launch_bounds__(NW * 64) k_wgrad_dense(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
+                                                         const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int NS,
+                                                         int nmb, float* __restrict__ ws) {
+  constexpr int NT = NW * 64;
+  constexpr int COUT = NBO * 32, CS = NBIW * 32, PG = COUT * 2, PX = CS * 2, ROWS = 16 * KS, SPM = 4, MBR = ROWS * SPM;
+  constexpr int PRG = COUT / 8, PRX = CS / 8;
+  constexpr int NPT = (MBR * PRG + NT - 1) / NT;                   // 16-B pieces of the gout tile per thread
+  constexpr int NL = ROWS * PRX / 64;                              // gather instructions per lane and step
+  static_assert(ROWS * PRX % 64 == 0 && SPM % PD == 0, "configuration");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* Gs = smem;                                                 // [2][MBR][PG]
+  char* Xs = smem + 2 * MBR * PG + wv * (2 * ROWS * PX);           // wave-private [2][ROWS][PX]
+
+  const int job = (int)blockIdx.y * NW + wv;
+  const int tap = job / NS, slice = job % NS;
+  const bool active = tap < K;
+  const int bx = (int)blockIdx.x, nslot = (int)gridDim.x >> 3, xcd = bx & 7, slot = bx >> 3;
+  const int m8 = (nmb + 7) >> 3;
+  const int m_lo = xcd * m8 + slot, m_hi = min(nmb, (xcd + 1) * m8);
+  const int niter = m_lo < m_hi ? (m_hi - 1 - m_lo) / nslot + 1 : 0;
+  auto mb_of = [&](int it) { return it < niter ? m_lo + it * nslot : -1; };
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 2), 0x00020000);
+  const unsigned x_ld_b = (unsigned)(x_ld * 2);
+
+  // gather pattern: piece q = lane + 64 i of the step's [ROWS][PRX] pieces
+  int xrow[NL]; unsigned xcol[NL]; int xlds[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int q = lane + 64 * i, r = q / PRX, pc = q % PRX;
+    xrow[i] = r;
+    xcol[i] = (unsigned)((slice * CS + pc * 8) * 2);
+    xlds[i] = r * PX + ((pc ^ swz<PX>(r)) << 4);
+  }
+  // transposing reads: lane (fh, tg, ti) supplies the 8-byte chunk (row 8 fh + 4 q + (ti >> 2), channels 16 tg + 4 (ti & 3) ..) of a 32-channel block
+  const int fi = lane & 31, fh = lane >> 5, ti = lane & 15, tg = (lane >> 4) & 1;
+  const int prow = 8 * fh + (ti >> 2);
+  int ga[NBO], xa[NBIW];
+#pragma unroll
+  for (int a = 0; a < NBO; ++a) ga[a] = prow * PG + (((4 * a + 2 * tg + ((ti & 3) >> 1)) ^ swz<PG>(prow)) << 4) + 8 * (ti & 1);
+#pragma unroll
+  for (int b = 0; b < NBIW; ++b) xa[b] = prow * PX + (((4 * b + 2 * tg + ((ti & 3) >> 1)) ^ swz<PX>(prow)) << 4) + 8 * (ti & 1);
+
+  f32x16 acc[NBO][NBIW];
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBIW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // rulebook entries of a macro block: lane l holds rows l, l + 64, ... of the block
+  auto idx_load = [&](int it, int (&dst)[KS]) __attribute__((always_inline)) {
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int64_t row = (int64_t)mb * MBR + kk * 64 + lane;
+      dst[kk] = (mb >= 0 && active && row < n_out) ? table[(int64_t)tap * n_out + row] : -1;
+    }
+  };
+  auto g_load = [&](int it, u32x4 (&dst)[NPT]) __attribute__((always_inline)) {
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * NT, r = q / PRG, pc = q % PRG;
+      const int64_t row = (int64_t)mb * MBR + r;
+      const bool ok = mb >= 0 && row < n_out && (NPT * NT == MBR * PRG || q < MBR * PRG);
+      const unsigned off = ok ? (unsigned)(row * g_ld * 2) + (unsigned)(pc * 16) : 0xFFFFFFFFu;
+      dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 0));
+    }
+  };
+  auto g_store = [&](int buf, const u32x4 (&src)[NPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * NT, r = q / PRG, pc = q % PRG;
+      if (NPT * NT == MBR * PRG || q < MBR * PRG) *reinterpret_cast<u32x4*>(Gs + buf * (MBR * PG) + r * PG + ((pc ^ swz<PG>(r)) << 4)) = src[i];
+    }
+  };
+  // gathers of step s (0 .. SPM-1) of a macro block whose rulebook entries are `idx`
+  auto x_issue = [&](int s, const int (&idx)[KS], u32x4 (&dst)[NL]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int rmb = s * ROWS + xrow[i];                          // row inside the macro block; its entry sits in lane rmb & 63 of idx[rmb >> 6]
+      int e;
+      if constexpr (KS == 1) e = __builtin_amdgcn_ds_bpermute((rmb & 63) << 2, idx[0]);
+      else {
+        // ROWS = 32, MBR = 128: steps 0, 1 read idx[0], steps 2, 3 idx[1] (s is a compile-time constant after unrolling)
+        e = __builtin_amdgcn_ds_bpermute((rmb & 63) << 2, idx[(s * ROWS) >> 6]);
+      }
+      const unsigned off = (unsigned)e * x_ld_b + xcol[i];          // e = -1 wraps past the end of the buffer: zeros
+      dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0));
+    }
+  };
+
+  if (niter > 0) {                                                  // uniform over the workgroup (an idle workgroup still writes its zero partials)
+  int idx0[KS], idx1[KS], idx2[KS];
+  idx_load(0, idx0); idx_load(1, idx1); idx_load(2, idx2);
+  {
+    u32x4 g0[NPT];
+    g_load(0, g0);
+    g_store(0, g0);
+  }
+  u32x4 xb[PD][NL];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) x_issue(d, idx0, xb[d]);
+  __syncthreads();
+
+  for (int it = 0; it < niter; ++it) {
+    u32x4 gn[NPT];
+    g_load(it + 1, gn);
+    const char* Gc = Gs + (it & 1) * (MBR * PG);
+#pragma unroll
+    for (int s = 0; s < SPM; ++s) {
+      char* Xc = Xs + (s & 1) * (ROWS * PX);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) *reinterpret_cast<u32x4*>(Xc + xlds[i]) = xb[s % PD][i];
+      // the slot is free again: gathers of the step PD ahead (the next macro block's entries from step SPM - PD on)
+      if (s + PD < SPM) x_issue(s + PD, idx0, xb[s % PD]);
+      else x_issue(s + PD - SPM, idx1, xb[s % PD]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 A[NBO], B[NBIW];
+#pragma unroll
+        for (int a = 0; a < NBO; ++a)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Gc + (s * ROWS + 16 * ks + 4 * q) * PG + ga[a])));
+            A[a][2 * q] = v[0]; A[a][2 * q + 1] = v[1];
+          }
+#pragma unroll
+        for (int b = 0; b < NBIW; ++b)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Xc + (16 * ks + 4 * q) * PX + xa[b])));
+            B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
+          }
+#pragma unroll
+        for (int a = 0; a < NBO; ++a)
+#pragma unroll
+          for (int b = 0; b < NBIW; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    g_store((it + 1) & 1, gn);                                      // every wave passed the previous barrier after its last read of that buffer
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) { idx0[kk] = idx1[kk]; idx1[kk] = idx2[kk]; }
+    idx_load(it + 3, idx2);
+    __syncthreads();
+  }
+  }
+
+  if (!active) return;
+  float* wp = ws + (((int64_t)bx * K + tap) * COUT) * (int64_t)Cin + slice * CS;
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBIW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ci = b * 32 + fi;
+        wp[(int64_t)co * Cin + ci] = acc[a][b][r];
+      }
+}
+
+// gw[e] = sum over the partial tile sets, four interleaved partial sums per element combined in a fixed order (deterministic)
+__global__ void __launch_bounds__(256) k_wgrad_reduce_par(const float* __restrict__ ws, int nparts, int64_t per, float* __restrict__ gw) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v * 4 >= per) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(ws) + v;
+  const int64_t stride = per / 4;
+  f32x4 s[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  int p = 0;
+  for (; p + 4 <= nparts; p += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += src[(int64_t)(p + u) * stride];
+  }
+  for (int u = 0; p < nparts; ++p, ++u) s[u] += src[(int64_t)p * stride];
+  reinterpret_cast<f32x4*>(gw)[v] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+template <int NBO, int NBIW, int KS, int PD, int NW>
+int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin, int NS,
+           int gx, float* ws, hipStream_t s) {
+  constexpr int MBR = 64 * KS;
+  const size_t lds = 2 * (size_t)MBR * NBO * 64 + (size_t)NW * 2 * (16 * KS) * (NBIW * 64);
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_dense<NBO, NBIW, KS, PD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return TL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nmb = (int)tl_cdiv(n_out, MBR);
+  const int gy = (int)tl_cdiv((int64_t)K * NS, NW);
+  k_wgrad_dense<NBO, NBIW, KS, PD, NW><<<dim3((unsigned)gx, (unsigned)gy), NW * 64, lds, s>>>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, NS, nmb, ws);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+}  // namespace
+
+int g_wgrad_dense = 1;            // tl_set_tuning("wgrad_dense", 0) restores the pair-list kernels of tl_wgrad.hip everywhere
+int64_t g_wgrad_dense_min_rows = 60000;
+
+// row slots (= partial tile sets) of the dense form for a shape, 0 if the shape is not served
+int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout) {
+  if (!g_wgrad_dense || K != 27 || n_out < g_wgrad_dense_min_rows) return 0;
+  const int key = Cin * 1000 + Cout;
+  switch (key) {
+    case 32032: case 64032: return 128;                  // 27 jobs: 2 workgroups of 14 waves per slot
+    case 64064: return 80;                               // 27 jobs: 3 workgroups of 9 waves (170 registers each) per slot
+    case 128064: return 40;                              // 54 jobs: 6 workgroups of 9 waves per slot
+    case 96096: return 40;                               // 81 jobs (27 taps x 3 slices of 32 channels): 6 workgroups per slot
+    case 192096: return 16;                              // 162 jobs: 12 workgroups per slot
+  }
+  return 0;
+}
+
+int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
+                          int Cout, float* gw, float* ws, hipStream_t s) {
+  const int gx = tl_wgrad_dense_slots(n_out, K, Cin, Cout);
+  if (!gx || !table) return TL_ERR_UNSUPPORTED;
+  int rc = TL_ERR_UNSUPPORTED;
+  switch (Cin * 1000 + Cout) {
+    case 32032: rc = launch<1, 1, 2, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 1, gx, ws, s); break;
+    case 64032: rc = launch<1, 2, 1, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 1, gx, ws, s); break;
+    case 64064: rc = launch<2, 2, 1, 4, 9>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 1, gx, ws, s); break;
+    case 128064: rc = launch<2, 2, 1, 4, 9>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 2, gx, ws, s); break;
+    case 96096: rc = launch<3, 1, 2, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 3, gx, ws, s); break;
+    case 192096: rc = launch<3, 1, 2, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 6, gx, ws, s); break;
+  }
+  if (rc != TL_OK) return rc;
+  const int64_t per = (int64_t)K * Cout * Cin;
+  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 256), 256, 0, s>>>(ws, gx, per, gw);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
