@@ -175,7 +175,29 @@ typedef struct tl_conv_args {
   int32_t table_one_hot;
   /* optional column form of `table` (tl_rulebook_compact; K must be 27), NULL if absent */
   const int32_t* table_compact;
+  /* Training-mode epilogue reductions (the BatchNorm1d that surrounds every conv of the reference, blocks.py:55-70,102-123, in
+   * train() mode; tools/training/train.py:30-44).  With y = acc + residual:
+   *   TL_EPI_STATS : red_part f64[parts][2][Cout] receives per-workgroup sums of y and y^2 (y as stored) -- the batch statistics of
+   *                  the BatchNorm that consumes this conv's output (finish: tl_bn_train_finish), without a pass over y;
+   *   TL_EPI_BN_BWD: this launch is the input-gradient conv of a layer whose input was relu?(bn(x)): y is dy of that activation;
+   *                  every view receives g = dy * [x * bn_scale + bn_shift > 0] (bn_relu) and red_part the sums of g and of
+   *                  g * (x - bn_mean) * bn_rstd = dbeta / dgamma (finish + dx: tl_bn_train_bwd_from_parts).  bn_x [n_out, Cout]
+   *                  in `dtype`, row stride bn_x_ld.
+   * red_part must hold tl_conv_red_parts(n_out) rows; *red_nparts (HOST, optional) receives the rows actually written.
+   * Only the direct / stream kernel families carry these epilogues: other shapes return TL_ERR_UNSUPPORTED (nothing launched)
+   * and the caller runs the separate passes (tl_bn_train_stats / tl_bn_train_bwd).  Deterministic. */
+  int32_t epi_mode;
+  double* red_part;
+  int32_t* red_nparts;
+  const void* bn_x;      int64_t bn_x_ld;
+  const float* bn_mean;  const float* bn_rstd;  const float* bn_scale;  const float* bn_shift;  int32_t bn_relu;
 } tl_conv_args;
+
+#define TL_EPI_NONE 0
+#define TL_EPI_STATS 1
+#define TL_EPI_BN_BWD 2
+/* upper bound of the partial rows a tl_conv_fwd launch with epi_mode != 0 writes for n_out output rows */
+int64_t tl_conv_red_parts(int64_t n_out);
 
 int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
 
@@ -234,6 +256,17 @@ int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, co
 int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int64_t dld, int dy_dtype, int64_t n, int C,
                     const float* mean, const float* rstd, const float* scale, const float* shift, int relu, double* ws,
                     float* dgamma, float* dbeta, void* dx, int64_t xld, const void* dx_add, int64_t dx_add_ld, tl_stream_t stream);
+
+/* The same BatchNorm with its reductions taken from a conv epilogue (tl_conv_args.epi_mode): part f64[nparts][2][C] as written by
+ * tl_conv_fwd.  tl_bn_train_finish = the second half of tl_bn_train_stats (partial sums of x and x^2 -> mean .. shift, running
+ * statistics); tl_bn_train_bwd_from_parts = the second half of tl_bn_train_bwd for an ALREADY masked g (TL_EPI_BN_BWD: sums of g and
+ * g * xhat -> dgamma, dbeta, then dx = scale * (g - dbeta / n - xhat * dgamma / n) + dx_add in one pass over x and g; C % 8 == 0 and
+ * 16-B aligned rows, else TL_ERR_UNSUPPORTED). */
+int tl_bn_train_finish(const double* part, int64_t nparts, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum, float* mean,
+                       float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int64_t* num_batches_tracked, tl_stream_t stream);
+int tl_bn_train_bwd_from_parts(const void* x, int64_t ld, int x_dtype, const void* g, int64_t gld, int g_dtype, int64_t n, int C, const float* mean,
+                               const float* rstd, const float* scale, const float* shift, const double* part, int64_t nparts, float* dgamma, float* dbeta,
+                               void* dx, int64_t xld, const void* dx_add, int64_t dx_add_ld, tl_stream_t stream);
 
 /* Keep rows where mask != 0 (masks_inner filtering before D2H, util/pipeline.py:100-103).
  * in f32[n,C] -> out f32[count,C]; count i32[1] device.  Stable (input order kept).

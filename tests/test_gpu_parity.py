@@ -101,7 +101,9 @@ def test_reach_zero_raises():
     # > 16384 rows: the 128-row output-stationary MFMA kernels (smaller sizes take the split-tap small-level kernel)
     (32, 32, 27, 17001), (64, 64, 27, 16500), (128, 64, 27, 16400), (96, 96, 8, 16390), (64, 32, 1, 20000), (224, 224, 8, 16385),
     # mid-size levels: the 4-wave small-level kernel with fragment-order weights (more than 512 output blocks)
-    (160, 160, 27, 6500), (320, 160, 27, 6000)])
+    (160, 160, 27, 6500), (320, 160, 27, 6000),
+    # the heads' output Linears in training: one thread per row (tl_linear_small.hip)
+    (32, 2, 1, 30001), (32, 3, 1, 600), (64, 8, 1, 5000)])
 def test_conv_fwd_vs_oracle(cin, cout, K, n_out):
     from treelearn_amd import ops
     rng = np.random.default_rng(cin * 1000 + cout + K)
@@ -260,6 +262,26 @@ def test_conv_fwd_bf16_vs_oracle(cin, cout, K, n_out):
     out = ops.conv_fwd(T(x, torch.bfloat16), wp, tab, n_out, in_scale=T(sc), in_shift=T(sh), in_relu=True, residual=T(res, torch.bfloat16))
     assert out.dtype == torch.bfloat16
     assert rel_err(out.float().cpu().numpy(), ref) < 8e-3          # one bf16 rounding of the output (2^-8)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(32, 2, 100003), (32, 3, 4097), (64, 4, 9000)])
+def test_head_output_linear_kernels_bf16(cin, cout, n):
+    """The heads' output Linears in mixed-precision training (tl_linear_small.hip: one thread per row, forward and weight gradient)
+    against float64 on the same bf16-rounded operands; deterministic."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    d = _dev()
+    x = _bf16_round(rng.normal(size=(n, cin)).astype(np.float32)); w = _bf16_round((rng.normal(size=(cout, 1, 1, 1, cin)) / 6).astype(np.float32))
+    g = _bf16_round(rng.normal(size=(n, cout)).astype(np.float32))
+    T = lambda a, dt=torch.bfloat16: torch.from_numpy(a).to(d).to(dt)
+    out = ops.conv_fwd(T(x), ops.pack_weight(T(w, torch.float32), torch.bfloat16), None, n)
+    ref = x.astype(np.float64) @ w.reshape(cout, cin).astype(np.float64).T
+    assert out.dtype == torch.bfloat16 and rel_err(out.float().cpu().numpy(), ref) < 8e-3
+    gw = ops.conv_wgrad(T(x), T(g), None, n, 1)
+    gw2 = ops.conv_wgrad(T(x), T(g), None, n, 1)
+    assert torch.equal(gw, gw2)
+    refw = (g.astype(np.float64).T @ x.astype(np.float64))[None]
+    assert rel_err(gw.cpu().numpy(), refw) < 2e-5
 
 
 @pytest.mark.parametrize("device_tiles", [False, True])
@@ -805,6 +827,7 @@ def test_inverse_conv_one_hot_form(cin, cout, n_out):
 @pytest.mark.parametrize("cin,cout,K,n_out", [(32, 32, 27, 9000), (64, 32, 27, 5000), (4, 32, 27, 7000), (96, 64, 8, 4100), (160, 192, 8, 700),
                                                (64, 32, 1, 6000), (224, 224, 27, 223), (96, 96, 27, 3000), (192, 96, 27, 1500),
                                                (96, 96, 27, 120000), (192, 96, 27, 100100),       # big levels: the dense-over-taps form (tl_wgrad_dense.hip)
+                                               (32, 2, 1, 50000), (32, 3, 1, 70001), (64, 4, 1, 3000),     # the heads' output Linears (tl_linear_small.hip)
                                                (32, 32, 27, 70001), (64, 32, 27, 65000), (64, 64, 27, 99999), (128, 64, 27, 61000),
                                                (96, 96, 27, 50000), (192, 96, 27, 40000)])        # multiples of 96 below the dense form's row threshold: 96 x 96 pair-list blocks
 def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):

@@ -1,0 +1,120 @@
+"""Training-mode conv epilogues (tl_conv_args.epi_mode) and the fused BatchNorm -> ReLU -> conv autograd node against the separate
+passes / float64 (reference: the `norm_fn(C), nn.ReLU(), conv` triples of tree_learn/model/blocks.py:55-70,102-123 in train() mode,
+stepped by tools/training/train.py:30-44)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda")
+
+
+def _table(rng, n_out, n_in, K, density=0.4):
+    t = rng.integers(0, n_in, size=(K, n_out)).astype(np.int32)
+    t[rng.uniform(size=t.shape) > density] = -1
+    return t
+
+
+# (Cin, Cout, K, rows): the direct kernel (whole weight tensor in LDS), the 4-channel input conv, stream-q, stream, the one-hot stream form
+SHAPES = [(32, 32, 27, 40001), (64, 32, 27, 30000), (4, 32, 27, 50017), (64, 64, 27, 33000), (128, 64, 27, 20000), (96, 96, 27, 17000),
+          (192, 96, 27, 17000), (32, 64, 8, 30000), (64, 32, 1, 25000), (64, 96, 8, 18000), (128, 128, 27, 17001)]
+
+
+@pytest.mark.parametrize("cin,cout,K,n", SHAPES)
+def test_conv_epilogue_statistics(cin, cout, K, n):
+    """epi="stats": same output bits as the plain launch; the partial sums add up to the column sums of the STORED result."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin + cout + K)
+    d = _dev()
+    n_in = n + 33 if K > 1 else n
+    x = torch.from_numpy(rng.normal(size=(n_in, cin)).astype(np.float32)).to(d).bfloat16()
+    w = ops.pack_weight(torch.from_numpy((rng.normal(size=(cout, K, cin)) / np.sqrt(cin * K * 0.4)).astype(np.float32).reshape(cout, K, 1, 1, cin)).to(d), torch.bfloat16)
+    tab = None if K == 1 else torch.from_numpy(_table(rng, n, n_in, K)).to(d)
+    res = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).to(d).bfloat16()
+    for residual in (None, res):
+        plain = ops.conv_fwd(x, w, tab, n, residual=residual)
+        r = ops.conv_fwd(x, w, tab, n, residual=residual, epi="stats")
+        assert r is not None, "this shape is expected on a kernel family with the training epilogue"
+        out, parts, nparts = r
+        assert torch.equal(out, plain)
+        assert 0 < nparts <= parts.shape[0]
+        s = parts[:nparts].sum(0).cpu().numpy()
+        y = out.double().cpu().numpy()
+        np.testing.assert_allclose(s[0], y.sum(0), rtol=1e-6, atol=1e-6 * np.abs(y).sum(0).max())
+        np.testing.assert_allclose(s[1], (y * y).sum(0), rtol=1e-6)
+        r2 = ops.conv_fwd(x, w, tab, n, residual=residual, epi="stats")
+        assert torch.equal(r2[1][:nparts], parts[:nparts])                       # deterministic
+
+
+@pytest.mark.parametrize("cin,cout,K,n", SHAPES[:2] + SHAPES[3:7] + SHAPES[7:9])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv_epilogue_bn_backward(cin, cout, K, n, relu):
+    """epi=("bn_bwd", x, st, relu): the views receive dy masked by the ReLU of the BatchNorm in front of the layer, the partial sums are
+    dbeta / dgamma; tl_bn_train_bwd_from_parts then equals tl_bn_train_bwd on the unmasked dy."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin * 3 + cout + K)
+    d = _dev()
+    n_in = n + 33 if K > 1 else n
+    gy = torch.from_numpy(rng.normal(size=(n_in, cin)).astype(np.float32)).to(d).bfloat16()         # "grad_out" rows gathered by the transposed conv
+    w = ops.pack_weight(torch.from_numpy((rng.normal(size=(cout, K, cin)) / np.sqrt(cin * K * 0.4)).astype(np.float32).reshape(cout, K, 1, 1, cin)).to(d), torch.bfloat16)
+    tab = None if K == 1 else torch.from_numpy(_table(rng, n, n_in, K)).to(d)
+    xb = torch.from_numpy((rng.normal(size=(n, cout)) * 2 + 0.5).astype(np.float32)).to(d).bfloat16()   # the BatchNorm input of the layer
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(d); beta = torch.from_numpy(rng.normal(0, 0.3, cout).astype(np.float32)).to(d)
+    st = ops.bn_train_stats(xb, gamma, beta, 1e-4, 0.1)
+    dy = ops.conv_fwd(gy, w, tab, n)
+    r = ops.conv_fwd(gy, w, tab, n, epi=("bn_bwd", xb, st, relu))
+    assert r is not None
+    g, parts, nparts = r
+    keep = ((xb.double() * st[2].double() + st[3].double()) > 0) if relu else torch.ones_like(xb, dtype=torch.bool)
+    assert torch.equal(g, torch.where(keep, dy, torch.zeros_like(dy)))
+    add = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).to(d).bfloat16()
+    ref = ops.bn_train_bwd(xb, dy, st, relu, dx_add=add)
+    got = ops.bn_train_bwd_from_parts(xb, g, st, parts, nparts, dx_add=add)
+    assert got is not None
+    for a, b, tol in ((got[1], ref[1], 2e-5), (got[2], ref[2], 2e-5)):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6
+    err = float((got[0].float() - ref[0].float()).abs().max()) / float(ref[0].float().abs().max())
+    assert err < 1e-2                                                                       # one bf16 rounding of dx
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fused_training_nodes_equal_separate_passes(dtype):
+    """One training step of a 4-level model on a 14 m tile (120 k voxels at level 1: the big levels take the epilogue-fused kernels,
+    the small ones the separate passes) with TL_TRAIN_FUSE on and off: same loss, running statistics and gradients."""
+    from treelearn_amd import autograd as ag
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    cfg = dict(channels=32, num_blocks=4)
+    batch = make_batch([make_tile(extent=14.0, voxel=0.1, n_trees=8, fill=0.10, seed=s) for s in (3, 4)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    res = {}
+    for fuse in (True, False):
+        ag.FUSE_BN = fuse
+        try:
+            model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, compute_dtype=dtype, **cfg)
+            model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+            model = model.cuda().train()
+            loss, _ = model(gb, return_loss=True)
+            loss.backward()
+            res[fuse] = (float(loss), {n: p.grad.detach().float().cpu().numpy() for n, p in model.named_parameters()},
+                         {n: b.detach().float().cpu().numpy() for n, b in model.named_buffers() if "running" in n})
+        finally:
+            ag.FUSE_BN = True
+    (la, ga, ba), (lb, gb_, bb) = res[True], res[False]
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert la == pytest.approx(lb, rel=tol)
+    for n in bb:                                                                  # bf16: activations that differ by a rounding shift a channel mean by ~1e-4
+        np.testing.assert_allclose(ba[n], bb[n], rtol=1e-3, atol=(3e-3 if dtype == torch.bfloat16 else 1e-5) * max(1e-3, float(np.abs(bb[n]).max())))
+    worst = 0.0
+    for n in ga:
+        a, b = ga[n].ravel(), gb_[n].ravel()
+        assert np.isfinite(a).all()
+        if np.linalg.norm(b) > 0:
+            cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+            worst = max(worst, 1 - cos)
+            assert cos > (0.995 if dtype == torch.bfloat16 else 0.99999), (n, cos)
+            assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < (5e-2 if dtype == torch.bfloat16 else 1e-3), n

@@ -73,6 +73,14 @@ def main():
         print("  kernel families (ms, dispatches):")
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:45]:
             print(f"    {k:44s} {v[0] / 1e6:8.3f} {v[1]:5d}")
+        at = collections.defaultdict(lambda: [0, 0])
+        for s_, e_, n_ in seg:
+            if "at::" in n_ or "rocclr" in n_:
+                a_ = at[re.sub(r"\s+", " ", n_)[:230]]
+                a_[0] += e_ - s_; a_[1] += 1
+        print("  ATen / runtime kernels by full name (ms, dispatches):")
+        for k, v in sorted(at.items(), key=lambda kv: -kv[1][0])[:24]:
+            print(f"    {v[0] / 1e6:8.3f} {v[1]:5d}  {k}")
         print("  idle attributed to the kernel before the gap (ms, gaps):")
         for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
             print(f"    {k:44s} {v[0] / 1e6:8.3f} {v[1]:5d}")

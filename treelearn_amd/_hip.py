@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtreelearn_hip.so")
 
 TL_F32, TL_BF16 = 0, 1
+TL_ERR_UNSUPPORTED = -3
+TL_EPI_NONE, TL_EPI_STATS, TL_EPI_BN_BWD = 0, 1, 2
 # opt-in: the window form of the 27-tap bf16 convs (csrc/tl_conv_win.hip) for levels of >= 65536 voxels; measured at parity with
 # the register-gather kernels on the config-2 tile, so the default dispatch does not use it
 WIN_KERNEL = os.environ.get("TL_CONV_WIN") == "1"
@@ -29,6 +31,9 @@ class ConvArgs(_c.Structure):
         ("out2", _vp), ("out2_ld", _i64), ("out2_scale", _vp), ("out2_shift", _vp), ("out2_relu", _i32),
         ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
         ("weight_frag", _vp), ("table_one_hot", _i32), ("table_compact", _vp),
+        # training-mode epilogue reductions (include/treelearn_hip.h: TL_EPI_STATS / TL_EPI_BN_BWD)
+        ("epi_mode", _i32), ("red_part", _vp), ("red_nparts", _c.POINTER(_i32)),
+        ("bn_x", _vp), ("bn_x_ld", _i64), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_scale", _vp), ("bn_shift", _vp), ("bn_relu", _i32),
     ]
 
 
@@ -68,6 +73,9 @@ PROTOTYPES = {
     "tl_pyramid_build": (_i32, [_vp, _i64, _I4, _I3, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tl_rulebooks_build": (_i32, [_c.POINTER(Level), _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
+    "tl_conv_red_parts": (_i64, [_i64]),
+    "tl_bn_train_finish": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tl_bn_train_bwd_from_parts": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_conv_wgrad_ws_floats": (_i64, [_i64, _i32, _i32, _i32]),

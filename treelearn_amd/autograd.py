@@ -6,6 +6,7 @@ backward : dgrad = tl_conv_fwd over the transposed rulebook with W^T; wgrad = tl
            exercised by tools/training/train.py:40 `scaler.scale(loss).backward()`).
 """
 import math
+import os
 import weakref
 
 import torch
@@ -29,11 +30,26 @@ def _packed(weight, dtype):
     return w
 
 
+FUSE_BN = os.environ.get("TL_TRAIN_FUSE", "1") != "0"      # conv-epilogue BatchNorm reductions in training (0: the separate passes, for A/B)
+
+
+def _conv_with_stats(x, w_packed, ref, residual, holder):
+    """Forward conv whose epilogue also sums y and y^2 per channel when the kernel family can (ops.conv_fwd(epi="stats")); the partial
+    sums go to holder["stats"] = [(parts, nparts, Cout)] for the BatchNorm that consumes the result (attached to the output tensor as
+    `_tl_stats` by the caller)."""
+    if holder is not None and FUSE_BN and ref.n_out > 1:
+        r = ops.conv_fwd(x, w_packed, ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot, epi="stats")
+        if r is not None:
+            holder["stats"] = [(r[1], r[2], int(w_packed.shape[1]))]
+            return r[0]
+    return ops.conv_fwd(x, w_packed, ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
+
+
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, ref, residual):
+    def forward(ctx, feats, weight, ref, residual, holder=None):
         x = feats.contiguous()
-        out = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
+        out = _conv_with_stats(x, _packed(weight, x.dtype), ref, residual, holder)
         ctx.save_for_backward(x, weight)
         ctx.ref = ref
         return out
@@ -44,15 +60,79 @@ class _SparseConvFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         gx, gw = bw.conv_backward(x, weight, ctx.ref, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gw, None, (grad_out if ctx.needs_input_grad[3] else None)      # d(out)/d(residual) = identity: no kernel
+        return gx, gw, None, (grad_out if ctx.needs_input_grad[3] else None), None      # d(out)/d(residual) = identity: no kernel
 
 
-def sparse_conv(feats, weight, ref, residual=None):
-    """`ref`: treelearn_amd.backward.TableRef (rulebook + its transpose); `residual` is added in the kernel's epilogue."""
+def sparse_conv(feats, weight, ref, residual=None, want_stats=False):
+    """`ref`: treelearn_amd.backward.TableRef (rulebook + its transpose); `residual` is added in the kernel's epilogue.
+    want_stats (training): the result carries `_tl_stats`, its per-channel partial sums from the conv epilogue, when available."""
     if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)):
-        return _SparseConvFn.apply(feats, weight, ref, residual)
+        holder = {} if want_stats else None
+        out = _SparseConvFn.apply(feats, weight, ref, residual, holder)
+        if holder:
+            out._tl_stats = holder["stats"]
+        return out
     x = feats.contiguous()
     return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
+
+
+def _bn_forward_stats(x, bn, gamma, beta, stats_in):
+    """st [4, C] (mean, rstd, scale, shift) of the training-mode BatchNorm `bn` over x; running statistics updated.  `stats_in`: the
+    producer's conv-epilogue partial sums (no pass over x), else the statistics kernel reads x."""
+    track = bn.track_running_stats and bn.running_mean is not None
+    g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if track else (None, None, None)
+    if stats_in is not None and sum(sg[2] for sg in stats_in) == x.shape[1]:
+        return ops.bn_train_finish(stats_in, x.shape[0], g32, b32, bn.eps, bn.momentum, rm, rv, nbt)
+    return ops.bn_train_stats(x, g32, b32, bn.eps, bn.momentum, rm, rv, nbt)
+
+
+class _BNReLUConvFn(torch.autograd.Function):
+    """y = conv(relu?(BatchNorm1d_train(x))) [+ residual] as ONE autograd node -- the `norm_fn(C), nn.ReLU(), conv` triple of reference
+    blocks.py:55-70,102-123 in training mode -- so that the BatchNorm's reductions ride on the neighbouring conv kernels:
+      forward : statistics of x from the producer's epilogue (`stats_in`), one apply pass, the conv -- whose epilogue in turn sums its
+                result for the next BatchNorm (holder["stats"]);
+      backward: the weight gradient on the side stream; the input-gradient conv masks its result with the ReLU and sums g and g * xhat
+                in its epilogue (ops.conv_fwd(epi=("bn_bwd", ...))); ONE pass forms dx (+ the gradient of the identity / skip use).
+    Where a kernel family has no such epilogue the separate passes run instead (same results up to summation order)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, residual, bn, relu, ref, want_skip, stats_in, holder):
+        x = x.contiguous()
+        st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
+        a = ops.affine_relu(x, st[2], st[3], relu)
+        y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder)
+        ctx.save_for_backward(x, a, st, weight)
+        ctx.ref, ctx.relu = ref, relu
+        if want_skip:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, gskip=None):
+        from . import backward as bw
+        x, a, st, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gskip is not None:
+            gskip = gskip.to(x.dtype).contiguous()
+        need_gw = ctx.needs_input_grad[3]
+        dx, dgamma, dbeta, gw = bw.bn_conv_backward(x, a, st, ctx.relu, weight, ctx.ref, gy, need_gw, gskip)
+        return dx, dgamma, dbeta, gw, (gy if ctx.needs_input_grad[4] else None), None, None, None, None, None, None
+
+
+def bn_relu_conv(x, bn, relu, weight, ref, residual=None, want_skip=False):
+    """Fused training-mode BatchNorm1d(+ReLU) -> sparse conv of the feature matrix x; returns y, or (y, skip) with want_skip (skip = x
+    passed through: the caller's identity path must use it, see _BNReLUTrainFn).  y carries `_tl_stats` when the conv kernel summed it."""
+    holder = {}
+    out = _BNReLUConvFn.apply(x, bn.weight, bn.bias, weight, residual, bn, relu, ref, want_skip, getattr(x, "_tl_stats", None) if FUSE_BN else None, holder)
+    y = out[0] if want_skip else out
+    if "stats" in holder:
+        y._tl_stats = holder["stats"]
+    if want_skip:
+        if getattr(x, "_tl_stats", None) is not None:
+            out[1]._tl_stats = x._tl_stats
+        return y, out[1]
+    return y
 
 
 class _BNReLUTrainFn(torch.autograd.Function):
@@ -64,12 +144,9 @@ class _BNReLUTrainFn(torch.autograd.Function):
     its own (26 per step of the default architecture)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, relu, skip):
+    def forward(ctx, x, gamma, beta, bn, relu, skip, stats_in=None):
         x = x.contiguous()
-        track = bn.track_running_stats and bn.running_mean is not None
-        st = ops.bn_train_stats(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), bn.eps,
-                                0.1 if bn.momentum is None else bn.momentum,
-                                bn.running_mean if track else None, bn.running_var if track else None, bn.num_batches_tracked if track else None)
+        st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
         y = ops.affine_relu(x, st[2], st[3], relu)
         ctx.save_for_backward(x, st)
         ctx.relu = relu
@@ -86,12 +163,16 @@ class _BNReLUTrainFn(torch.autograd.Function):
         if dskip is not None:
             dskip = dskip.to(x.dtype).contiguous()
         dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu, dx_add=dskip)    # dx in x's dtype (bf16 stays bf16 under mixed precision)
-        return dx, dgamma, dbeta, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None
 
 
 def bn_relu_train(x, bn, relu=True, skip=False):
     """Training-mode BatchNorm1d `bn` (+ ReLU) of the feature matrix x on the HIP library; skip=True returns (y, x passed through)."""
-    return _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu, skip)
+    stats_in = getattr(x, "_tl_stats", None) if FUSE_BN else None
+    out = _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu, skip, stats_in)
+    if skip and stats_in is not None:
+        out[1]._tl_stats = stats_in
+    return out
 
 
 class _BiasAddFn(torch.autograd.Function):
@@ -128,5 +209,5 @@ def bias_add(x, bias):
 
 def fusable_bn(module, x):
     """True when `module` is a BatchNorm1d that the HIP training kernels serve for x (batch statistics, affine, CUDA, C % 4 == 0)."""
-    return (isinstance(module, torch.nn.BatchNorm1d) and module.training and module.affine and x.is_cuda and x.dim() == 2
-            and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16))
+    return (isinstance(module, torch.nn.BatchNorm1d) and module.training and module.affine and module.momentum is not None and x.is_cuda
+            and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16))

@@ -38,6 +38,59 @@ def _side_stream(device):
     return st
 
 
+def _dgrad_weight(weight, ref, dtype):
+    """[K]["Cout" = Cin]["Cin" = Cout] weights of the input-gradient conv: W[k]^T, taps flipped for SubM."""
+    co, ci = weight.shape[0], weight.shape[-1]
+    K = weight.numel() // (co * ci)
+    w = weight.detach().reshape(co, K, ci).permute(1, 2, 0)
+    if ref.flip:
+        w = w.flip(0)
+    return w.contiguous().to(dtype)
+
+
+def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, gskip):
+    """Backward of y = conv(a), a = relu?(bn_train(x)) (autograd._BNReLUConvFn): returns (dx, dgamma, dbeta, gw).  The weight gradient
+    runs on the side stream next to the input-gradient conv, whose epilogue applies the ReLU mask and sums g and g * xhat
+    (ops.conv_fwd(epi=("bn_bwd", ...))) so that ONE more pass over (x, g) yields dx; shapes without that epilogue (small levels, > 224
+    transposed output channels, the heads' 2 / 3-wide Linears) take the plain conv + tl_bn_train_bwd."""
+    from .autograd import FUSE_BN
+    co, ci = weight.shape[0], weight.shape[-1]
+    K = weight.numel() // (co * ci)
+    gw = None
+    overlap = need_gw and grad_out.is_cuda and os.environ.get("TL_WGRAD_STREAM", "1") != "0"
+    if overlap:
+        cur = torch.cuda.current_stream(grad_out.device)
+        side = _side_stream(grad_out.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gw = ops.conv_wgrad(a, grad_out, ref.table, ref.n_out, K)
+            gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+        gw.record_stream(cur)
+    wt = _dgrad_weight(weight, ref, grad_out.dtype)
+    res = None
+    if FUSE_BN and ci <= 224 and x.dtype == grad_out.dtype:
+        r = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in, one_hot=ref.t_one_hot, epi=("bn_bwd", x, st, relu))
+        if r is not None:
+            res = ops.bn_train_bwd_from_parts(x, r[0], st, r[1], r[2], dx_add=gskip)
+            if res is None:                                                    # views the vector kernel cannot take: g is masked already
+                res = ops.bn_train_bwd(x, r[0], st, False, dx_add=gskip)
+    if res is None:
+        if ci <= 224:
+            ga = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in, one_hot=ref.t_one_hot)
+        else:
+            ga = torch.empty((ref.n_in, ci), dtype=grad_out.dtype, device=grad_out.device)
+            step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
+            for s in range(0, ci, step):
+                ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=ga[:, s:s + step], one_hot=ref.t_one_hot)
+        res = ops.bn_train_bwd(x, ga, st, relu, dx_add=gskip)
+    if need_gw and not overlap:
+        gw = ops.conv_wgrad(a, grad_out, ref.table, ref.n_out, K)
+        gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+    if overlap:
+        cur.wait_stream(side)
+    return res[0], res[1], res[2], gw
+
+
 def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
     co, ci = weight.shape[0], weight.shape[-1]
     K = weight.numel() // (co * ci)

@@ -187,9 +187,114 @@ __global__ void __launch_bounds__(kThreads) k_bn_bwd_apply(const TX* __restrict_
   }
 }
 
+// dx over 8-channel vectors with the thread's channel group fixed (the grid stride is a multiple of the vectors per row): the six
+// per-channel constants live in registers as two fused coefficients, one 16-B load per operand and step.
+//   dx = a * g + b - c * x        a = scale,  c = scale * rstd * dgamma / n,  b = -scale * dbeta / n + c * mean
+// MASK: g = dy * [x * scale + shift > 0] is formed here (dy raw); otherwise dy is already masked (conv epilogue TL_EPI_BN_BWD)
+template <bool XB, bool GB, bool MASK>
+__global__ void __launch_bounds__(kThreads) k_bn_bwd_apply_v8(const void* __restrict__ x, int64_t ld, const void* __restrict__ dy, int64_t dld, int64_t n, int C,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                              void* __restrict__ dx, int64_t xld, const void* __restrict__ add, int64_t ald) {
+  const int vpr = C >> 3;
+  const int64_t total = n * vpr, stride = (int64_t)gridDim.x * kThreads;
+  int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (v >= total) return;
+  const int c0 = (int)(v % vpr) * 8;
+  const float inv_n = 1.0f / (float)n;
+  float ca[8], cb[8], cc[8], sc[8], sh[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    sc[q] = scale[c0 + q]; sh[q] = shift[c0 + q];
+    ca[q] = sc[q];
+    cc[q] = sc[q] * rstd[c0 + q] * dgamma[c0 + q] * inv_n;
+    cb[q] = cc[q] * mean[c0 + q] - sc[q] * dbeta[c0 + q] * inv_n;
+  }
+  auto ld8 = [](const void* base, int64_t elem, bool bf, float (&o)[8]) __attribute__((always_inline)) {
+    if (bf) {
+      const u32x4 q4 = *reinterpret_cast<const u32x4*>((const uint16_t*)base + elem);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[2 * q] = bf16_lo(q4[q]); o[2 * q + 1] = bf16_hi(q4[q]); }
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)base + elem), b = *reinterpret_cast<const f32x4*>((const float*)base + elem + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[q] = a[q]; o[q + 4] = b[q]; }
+    }
+  };
+  for (; v < total; v += stride) {
+    const int64_t r = v / vpr;
+    float xv[8], g[8], o[8];
+    ld8(x, r * ld + c0, XB, xv); ld8(dy, r * dld + c0, GB, g);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float gg = g[q];
+      if constexpr (MASK) { if (!(fmaf(xv[q], sc[q], sh[q]) > 0.f)) gg = 0.f; }
+      o[q] = fmaf(ca[q], gg, fmaf(-cc[q], xv[q], cb[q]));
+    }
+    if (add) {
+      float a[8];
+      ld8(add, r * ald + c0, XB, a);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] += a[q];
+    }
+    if constexpr (XB) {
+      u32x4 w;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = pack_bf16x2(o[2 * q], o[2 * q + 1]);
+      *reinterpret_cast<u32x4*>((uint16_t*)dx + r * xld + c0) = w;
+    } else {
+      f32x4* d = reinterpret_cast<f32x4*>((float*)dx + r * xld + c0);
+      d[0] = f32x4{o[0], o[1], o[2], o[3]}; d[1] = f32x4{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
+// launch the vector form if the views allow it; false = caller uses the 4-channel kernel
+static bool launch_apply_v8(const void* x, int64_t ld, int x_dtype, const void* dy, int64_t dld, int dy_dtype, int64_t n, int C, const float* mean, const float* rstd,
+                            const float* scale, const float* shift, bool mask, const float* dgamma, const float* dbeta, void* dx, int64_t xld, const void* add,
+                            int64_t ald, hipStream_t s) {
+  if (C % 8 || ld % 8 || dld % 8 || xld % 8 || (add && ald % 8) || ((uintptr_t)x) % 16 || ((uintptr_t)dy) % 16 || ((uintptr_t)dx) % 16 || (add && ((uintptr_t)add) % 16))
+    return false;
+  const int vpr = C / 8;
+  int64_t gv = tl_cdiv(n * vpr, kThreads * 4);
+  if (gv > 256 * 16) gv = 256 * 16;
+  gv = tl_cdiv(gv, (int64_t)vpr) * vpr;                        // grid * 256 is a multiple of the vectors per row
+  const bool xb = x_dtype == TL_BF16, gb = dy_dtype == TL_BF16;
+#define TL_AP(XB_, GB_, M_) k_bn_bwd_apply_v8<XB_, GB_, M_><<<(unsigned)gv, kThreads, 0, s>>>(x, ld, dy, dld, n, C, mean, rstd, scale, shift, dgamma, dbeta, dx, xld, add, ald)
+  if (xb && gb) { if (mask) TL_AP(true, true, true); else TL_AP(true, true, false); }
+  else if (xb && !gb) { if (mask) TL_AP(true, false, true); else TL_AP(true, false, false); }
+  else if (!xb && gb) { if (mask) TL_AP(false, true, true); else TL_AP(false, true, false); }
+  else { if (mask) TL_AP(false, false, true); else TL_AP(false, false, false); }
+#undef TL_AP
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+int tl_bn_train_finish(const double* part, int64_t nparts, int64_t n, int C, const float* gamma, const float* beta, float eps, float momentum, float* mean,
+                       float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int64_t* num_batches_tracked, tl_stream_t stream) {
+  if (!part || nparts <= 0 || nparts > 0x7FFFFFFF || !gamma || !beta || !mean || !rstd || !scale || !shift || n <= 0 || C <= 0) return TL_ERR_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TL_ERR_ARG;
+  k_bn_stats_finish<<<C, 64, 0, tl_s(stream)>>>(part, (int)nparts, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
+                                              num_batches_tracked);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_bn_train_bwd_from_parts(const void* x, int64_t ld, int x_dtype, const void* g, int64_t gld, int g_dtype, int64_t n, int C, const float* mean,
+                               const float* rstd, const float* scale, const float* shift, const double* part, int64_t nparts, float* dgamma, float* dbeta,
+                               void* dx, int64_t xld, const void* dx_add, int64_t ald, tl_stream_t stream) {
+  if (!x || !g || !mean || !rstd || !scale || !shift || !part || nparts <= 0 || nparts > 0x7FFFFFFF || !dgamma || !dbeta || !dx || n <= 0 || C <= 0) return TL_ERR_ARG;
+  if ((x_dtype != TL_F32 && x_dtype != TL_BF16) || (g_dtype != TL_F32 && g_dtype != TL_BF16)) return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  k_bn_bwd_finish<<<C, 64, 0, s>>>(part, (int)nparts, C, dgamma, dbeta);
+  TL_CHECK_LAUNCH();
+  if (!launch_apply_v8(x, ld, x_dtype, g, gld, g_dtype, n, C, mean, rstd, scale, shift, false, dgamma, dbeta, dx, xld, dx_add, ald, s)) return TL_ERR_UNSUPPORTED;
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
 
 int64_t tl_bn_ws_doubles(int64_t n, int C) {
   if (n <= 0 || C <= 0 || C % 4 || C > 4 * kThreads) return 0;
@@ -234,6 +339,8 @@ int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int6
     TL_CHECK_LAUNCH();                                                                                                                 \
     k_bn_bwd_finish<<<C, 64, 0, s>>>(ws, blocks, C, dgamma, dbeta);                                                        \
     TL_CHECK_LAUNCH();                                                                                                                 \
+    if (relu && launch_apply_v8(x, ld, x_dtype, dy, dld, dy_dtype, n, C, mean, rstd, scale, shift, true, dgamma, dbeta, dx, xld, dx_add, ald, s)) { TL_CHECK_LAUNCH(); break; } \
+    if (!relu && launch_apply_v8(x, ld, x_dtype, dy, dld, dy_dtype, n, C, mean, rstd, scale, shift, false, dgamma, dbeta, dx, xld, dx_add, ald, s)) { TL_CHECK_LAUNCH(); break; } \
     k_bn_bwd_apply<TX, TG><<<g, kThreads, 0, s>>>((const TX*)x, ld, (const TG*)dy, dld, n, C, mean, rstd, scale, shift, relu, dgamma, dbeta, (TX*)dx, xld, (const TX*)dx_add, ald); \
     TL_CHECK_LAUNCH();                                                                                                                 \
   } while (0)

@@ -23,7 +23,8 @@ namespace {
 // CT: the rulebook comes in column form (p.ctab, 40 B per voxel; decode_ctab) instead of the 27-entry table (108 B)
 __device__ unsigned long long g_tmd[8];   // developer timing mode (ABL bit 16): cycles summed over waves per tile segment
 
-template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false>
+// TR: the training-mode epilogue (tl_conv_args.epi_mode) is compiled in; the inference instantiations (TR = false) carry none of it
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles, int walk) {
   constexpr bool TM = (ABL & 16) != 0;
   [[maybe_unused]] unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -46,6 +47,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ws = smem;                                                          // [K][UN][COUT][UB], 16-B slots swizzled
   float* Es = reinterpret_cast<float*>(smem + (size_t)K * UN * COUT * UB);  // [WAVES][32][EP]
+  double* Ds = reinterpret_cast<double*>(smem + (size_t)K * UN * COUT * UB + (size_t)WAVES * 32 * EP * 4);   // training mode only: [WAVES][2][COUT] column sums
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fi = lane & 31, fh = lane >> 5;
@@ -68,6 +70,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
   const int swz = swz_of(fi);
   const char* wl = Ws + fi * UB;
   float* ew = Es + wv * 32 * EP;
+  [[maybe_unused]] double* dw = Ds + wv * 2 * COUT;
+  if constexpr (TR) {
+    for (int e = lane; e < 2 * COUT; e += 64) dw[e] = 0.0;
+  }
 
   // walk 1 (developer A/B): every XCD (block b runs on XCD b % 8) walks its own contiguous eighth of the tiles
   const int nblk = walk ? ((int)gridDim.x >> 3) : (int)gridDim.x, bidx = walk ? ((int)blockIdx.x >> 3) : (int)blockIdx.x;
@@ -185,6 +191,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
       for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + nb * 32 + fi] = acc[nb][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (!TR) {
     for (int e = lane; e < 32 * VROW; e += 64) {
       const int rr = e / VROW, cvv = e % VROW;
       const int64_t orow = (int64_t)tile * 32 + rr;
@@ -193,6 +200,58 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if constexpr (ABL & 4) { if (v[0] == 1.2345e30f) epi_views8<BF16>(p, orow, cvv * 8, v); }
       else epi_views8<BF16>(p, orow, cvv * 8, v);
+    }
+    } else {
+      // training mode: the row stage writes the summands back into the tile, every lane then adds its NB columns (tl_conv_internal.h)
+      constexpr int IT = VROW / 2;                            // 32 * VROW / 64 row vectors per lane
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int e = lane + 64 * it, rr = e / VROW, cvv = e % VROW;
+        const int64_t orow = (int64_t)tile * 32 + rr;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}, q1[8];
+        if (orow < p.n_out) epi_views8_red<BF16>(p, orow, cvv * 8, v, q1);
+        else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float s0[NB], s1[NB];
+      if (p.epi_mode == TL_EPI_STATS) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tile_colsum<true>(ew, EP, nb * 32 + fi, fh, s0[nb], s1[nb]);
+      } else {
+        float dummy;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tile_colsum<false>(ew, EP, nb * 32 + fi, fh, s0[nb], dummy);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {                     // g -> g * xhat in place (x re-read: a cache hit)
+          const int e = lane + 64 * it, rr = e / VROW, cvv = e % VROW;
+          const int64_t orow = (int64_t)tile * 32 + rr;
+          if (orow < p.n_out) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+            const float g[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            float q1[8];
+            epi_bnb_q1<BF16>(p, orow, cvv * 8, g, q1);
+            *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8) = f32x4{q1[0], q1[1], q1[2], q1[3]};
+            *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8 + 4) = f32x4{q1[4], q1[5], q1[6], q1[7]};
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tile_colsum<false>(ew, EP, nb * 32 + fi, fh, s1[nb], dummy);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { dw[nb * 32 + fi] += (double)s0[nb]; dw[COUT + nb * 32 + fi] += (double)s1[nb]; }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -205,6 +264,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
       for (int i = 0; i < 6; ++i) atomicAdd(&g_tmd[i], tm[i]);
     }
   }
+  if constexpr (TR) {                                            // the waves' column sums, added in wave order -> the workgroup's partial row
+    __syncthreads();
+    for (int e = tid; e < 2 * COUT; e += WAVES * 64) {
+      double t = 0.0;
+      for (int w = 0; w < WAVES; ++w) t += Ds[w * 2 * COUT + e];
+      p.red_part[(int64_t)blockIdx.x * 2 * COUT + e] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ the 4-channel input conv on the matrix cores
@@ -213,11 +280,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
 // row i: two 8-byte bounds-checked gathers; the weight fragments (7 x 16 B per lane) live in registers for the whole
 // kernel.  HBM-bound on the 108 B/voxel rulebook read and the output writes.
 // CT: rulebook in column form (p.ctab), the ten words of the next tile requested while this tile's gathers are in flight.
-template <int WAVES, bool CT = false>
+template <int WAVES, bool CT = false, bool TR = false>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   constexpr int EP = 36;
   __shared__ float Es[WAVES][32][EP];
+  __shared__ double Ds[TR ? WAVES : 1][2][32];             // training mode (TR): the waves' column sums
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if constexpr (TR) { if (lane < 32) { Ds[wv][0][lane] = 0.0; Ds[wv][1][lane] = 0.0; } }
   const int fi = lane & 31, fh = lane >> 5;
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   // B fragments: W packed [K][32][4] bf16 = 8 B per (tap, column)
@@ -283,39 +352,52 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
     for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const char* res = (const char*)p.res;
+    if constexpr (TR) {
+      float r0 = 0.f, r1 = 0.f;
+      epi_block32<true, EP>(p, ew, lane, (int64_t)tile * 32, 0, r0, r1);
+      if (lane < 32) { Ds[wv][0][lane] += (double)r0; Ds[wv][1][lane] += (double)r1; }
+    } else {
 #pragma unroll
-    for (int e0 = 0; e0 < 2; ++e0) {
-      const int e = lane + e0 * 64, rr = e >> 2, cvv = e & 3;
-      const int64_t orow = (int64_t)tile * 32 + rr;
-      if (orow < p.n_out) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (res) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (orow * p.res_ld + cvv * 8) * 2);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { v[2 * q] += bf16_lo(rv[q]); v[2 * q + 1] += bf16_hi(rv[q]); }
+      for (int e0 = 0; e0 < 2; ++e0) {
+        const int e = lane + e0 * 64, rr = e >> 2, cvv = e & 3;
+        const int64_t orow = (int64_t)tile * 32 + rr;
+        if (orow < p.n_out) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          epi_views8<true>(p, orow, cvv * 8, v);
         }
-        epi_store8<true>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, orow, cvv * 8, v);
-        if (p.out2) epi_store8<true>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, orow, cvv * 8, v);
-        if (p.out3) epi_store8<true>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, orow, cvv * 8, v);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (TR) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64; e += WAVES * 64) {
+      double t = 0.0;
+      for (int w = 0; w < WAVES; ++w) t += Ds[w][e >> 5][e & 31];
+      p.red_part[(int64_t)blockIdx.x * 64 + e] = t;
+    }
+  }
 }
 
 int g_direct_walk = 0;
 
-template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false>
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false>
 int launch(const ConvP& p, hipStream_t s) {
+  if constexpr (!TR && BF16 && ABL == 0) {
+    if (p.epi_mode != TL_EPI_NONE) return launch<BF16, K, NB, UN, G, WAVES, ABL, CT, true>(p, s);      // training-mode epilogue: its own instantiation
+  } else if constexpr (!TR) {
+    if (p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
+  }
+  if constexpr (TR && NB >= 3) return TL_ERR_UNSUPPORTED;       // 96 output channels: six row vectors per lane spill; the stream kernels take these
+  else {
   constexpr int UB = BF16 ? 64 : 128;
-  const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4;
+  const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4 + (TR ? (size_t)WAVES * 2 * NB * 32 * 8 : 0);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
@@ -324,8 +406,10 @@ int launch(const ConvP& p, hipStream_t s) {
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
+  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
+  if (p.red_nparts) *p.red_nparts = grid;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+  }
 }
 
 int g_direct_abl = 0;
@@ -393,8 +477,12 @@ int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s) {
     const int ntiles = (int)tl_cdiv(p.n_out, 32);
     int grid = (int)tl_cdiv(ntiles, 8);
     if (grid > 2048) grid = 2048;
-    if (p.ctab && p.K == 27 && g_direct_abl != 15) k_conv_in4<8, true><<<grid, 512, 0, s>>>(p, ntiles);
+    if (p.epi_mode != TL_EPI_NONE) {
+      if (p.ctab && p.K == 27) k_conv_in4<8, true, true><<<grid, 512, 0, s>>>(p, ntiles);
+      else k_conv_in4<8, false, true><<<grid, 512, 0, s>>>(p, ntiles);
+    } else if (p.ctab && p.K == 27 && g_direct_abl != 15) k_conv_in4<8, true><<<grid, 512, 0, s>>>(p, ntiles);
     else k_conv_in4<8><<<grid, 512, 0, s>>>(p, ntiles);
+    if (p.red_nparts) *p.red_nparts = grid;
     return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
   }
   if (p.Cin % 32 || p.Cout % 32) return TL_ERR_UNSUPPORTED;

@@ -24,6 +24,14 @@ struct ConvP {
   void* out2; int64_t out2_ld; const float* out2_scale; const float* out2_shift; int out2_relu;
   void* out3; int64_t out3_ld; const float* out3_scale; const float* out3_shift; int out3_relu;
   int nblk;
+  // training-mode epilogue reductions (tl_conv_args.epi_mode): per-workgroup fp64 partial sums [workgroup][2][Cout] of
+  //   TL_EPI_STATS : y and y^2 (y = acc + residual as stored) -- the batch statistics of the BatchNorm that consumes this conv's output
+  //   TL_EPI_BN_BWD: the result is dy of relu(bn(x)); views get g = dy * [bn(x) > 0], sums are g and g * xhat (dbeta, dgamma)
+  int epi_mode;
+  double* red_part;
+  int32_t* red_nparts;   // HOST out (may be NULL): partial rows the launched kernel writes (= its grid size)
+  const void* bn_x; int64_t bn_x_ld;
+  const float* bn_mean; const float* bn_rstd; const float* bn_scale; const float* bn_shift; int bn_relu;
   int one_hot; // every output row has at most one valid table entry (inverse conv)
   int dbg;     // developer ablation bits (tl_set_tuning "dbg"): 1 no A loads, 2 no B loads, 4 no MFMA, 8 no stores
 };
@@ -122,6 +130,145 @@ static __device__ __forceinline__ void epi_views8(const ConvP& p, int64_t row, i
   if (p.out3) epi_store8<BF16>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, row, c0, v);
 }
 
+// ---- training-mode epilogue (epi_mode != 0).  The kernels that support it keep the fp32 accumulators of a 32-row block in a wave-private
+// LDS tile for the row-vector stage anyway; the reductions reuse that tile: the row stage writes the quantity to be summed back to
+// its own place, then every lane adds ONE column over 16 rows (lane (fi, fh): column fi, rows 16 fh ..) and the two halves are combined.
+static __device__ __forceinline__ float round_to(float v, bool bf16) { return bf16 ? __uint_as_float(pack_bf16x2(v, 0.f) << 16) : v; }
+
+// row stage: v = acc of channels c0..c0+7 of `row` -> views written; on return v = the first summand (y, resp. g), q1 = the second
+// (y^2 is formed in the column pass, so q1 is only set for TL_EPI_BN_BWD: g * xhat)
+template <bool BF16>
+static __device__ __forceinline__ void epi_views8_red(const ConvP& p, int64_t row, int c0, float (&v)[8], float (&q1)[8]) {
+  if (p.res) res_add8<BF16>(p.res, row * p.res_ld + c0, v);
+  if (p.epi_mode == TL_EPI_BN_BWD) {
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    res_add8<BF16>(p.bn_x, row * p.bn_x_ld + c0, x);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(p.bn_mean + c0), m1 = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.bn_rstd + c0), r1 = *reinterpret_cast<const f32x4*>(p.bn_rstd + c0 + 4);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.bn_scale + c0), a1 = *reinterpret_cast<const f32x4*>(p.bn_scale + c0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bn_shift + c0), b1 = *reinterpret_cast<const f32x4*>(p.bn_shift + c0 + 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float mu = q < 4 ? m0[q & 3] : m1[q & 3], rs = q < 4 ? r0[q & 3] : r1[q & 3], sc = q < 4 ? a0[q & 3] : a1[q & 3], sh = q < 4 ? b0[q & 3] : b1[q & 3];
+      const bool keep = !p.bn_relu || fmaf(x[q], sc, sh) > 0.f;
+      v[q] = keep ? round_to(v[q], BF16) : 0.f;
+      q1[q] = v[q] * ((x[q] - mu) * rs);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = round_to(v[q], BF16);
+  }
+  epi_store8<BF16>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, row, c0, v);
+  if (p.out2) epi_store8<BF16>(p.out2, p.out2_ld, p.out2_scale, p.out2_shift, p.out2_relu, row, c0, v);
+  if (p.out3) epi_store8<BF16>(p.out3, p.out3_ld, p.out3_scale, p.out3_shift, p.out3_relu, row, c0, v);
+}
+
+// second summand of TL_EPI_BN_BWD recomputed from the stored g (the persistent kernels do this instead of keeping q1 of every row
+// vector in registers across the first column pass): q1 = g * xhat, x re-read (a cache hit)
+template <bool BF16>
+static __device__ __forceinline__ void epi_bnb_q1(const ConvP& p, int64_t row, int c0, const float (&g)[8], float (&q1)[8]) {
+  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  res_add8<BF16>(p.bn_x, row * p.bn_x_ld + c0, x);
+  const f32x4 m0 = *reinterpret_cast<const f32x4*>(p.bn_mean + c0), m1 = *reinterpret_cast<const f32x4*>(p.bn_mean + c0 + 4);
+  const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.bn_rstd + c0), r1 = *reinterpret_cast<const f32x4*>(p.bn_rstd + c0 + 4);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) q1[q] = g[q] * ((x[q] - (q < 4 ? m0[q & 3] : m1[q & 3])) * (q < 4 ? r0[q & 3] : r1[q & 3]));
+}
+
+// column pass over a [32][EP] fp32 tile: sum (and sum of squares) of column `col`; every lane returns the total of its column
+template <bool SQ>
+static __device__ __forceinline__ void tile_colsum(const float* ew, int EP, int col, int fh, float& s, float& ss) {
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float t = ew[(16 * fh + j) * EP + col];
+    a += t;
+    if constexpr (SQ) b = fmaf(t, t, b);
+  }
+  s = a + __shfl_xor(a, 32, 64);
+  if constexpr (SQ) ss = b + __shfl_xor(b, 32, 64);
+}
+
+// the stream kernels' row stage of one 32 x 32 block (tile ew [32][EP], rows row0.., columns col0..) with the optional reductions:
+// red0 / red1 += this block's column sums (lane's column = col0 + (lane & 31))
+template <bool BF16, int EP>
+static __device__ __forceinline__ void epi_block32(const ConvP& p, float* ew, int lane, int64_t row0, int col0, float& red0, float& red1) {
+  const int fi = lane & 31, fh = lane >> 5;
+  if (p.epi_mode == TL_EPI_NONE) {
+#pragma unroll
+    for (int e0 = 0; e0 < 2; ++e0) {
+      const int e = lane + e0 * 64;                        // 32 rows x 4 vectors of 8 channels
+      const int rr = e >> 2, cvv = e & 3;
+      const int64_t orow = row0 + rr;
+      if (orow < p.n_out) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        epi_views8<BF16>(p, orow, col0 + cvv * 8, v);
+      }
+    }
+    return;
+  }
+  float q1s[2][8];
+#pragma unroll
+  for (int e0 = 0; e0 < 2; ++e0) {
+    const int e = lane + e0 * 64;
+    const int rr = e >> 2, cvv = e & 3;
+    const int64_t orow = row0 + rr;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) q1s[e0][q] = 0.f;
+    if (orow < p.n_out) epi_views8_red<BF16>(p, orow, col0 + cvv * 8, v, q1s[e0]);
+    else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    }
+    *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float s = 0.f, ss = 0.f;
+  if (p.epi_mode == TL_EPI_STATS) tile_colsum<true>(ew, EP, fi, fh, s, ss);
+  else {
+    float dummy;
+    tile_colsum<false>(ew, EP, fi, fh, s, dummy);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e0 = 0; e0 < 2; ++e0) {
+      const int e = lane + e0 * 64;
+      const int rr = e >> 2, cvv = e & 3;
+      *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8) = f32x4{q1s[e0][0], q1s[e0][1], q1s[e0][2], q1s[e0][3]};
+      *reinterpret_cast<f32x4*>(ew + rr * EP + cvv * 8 + 4) = f32x4{q1s[e0][4], q1s[e0][5], q1s[e0][6], q1s[e0][7]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    tile_colsum<false>(ew, EP, fi, fh, ss, dummy);
+  }
+  red0 += s; red1 += ss;
+}
+
+// end of a (non-persistent) stream kernel in training mode: every wave parks its column sums in its own tile, the first 2 * COUT
+// threads add the W waves' values in wave order in fp64 and write the workgroup's partial row
+template <int W, int EP, int NB>
+static __device__ __forceinline__ void epi_finish_wg(const ConvP& p, float* Es, int tid, const float (&red0)[NB], const float (&red1)[NB]) {
+  constexpr int COUT = NB * 32;
+  static_assert(2 * COUT <= 32 * EP, "the wave's tile holds its column sums");
+  const int lane = tid & 63, wv = tid >> 6, fi = lane & 31;
+  float* ew = Es + wv * 32 * EP;
+  if (lane < 32) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ew[nb * 32 + fi] = red0[nb]; ew[COUT + nb * 32 + fi] = red1[nb]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * COUT; e += W * 64) {
+    double s = 0.0;
+    for (int w = 0; w < W; ++w) s += (double)Es[w * 32 * EP + e];
+    p.red_part[(int64_t)blockIdx.x * 2 * COUT + e] = s;
+  }
+}
+
 // One lane's 27 rulebook entries from the column form (9 bases + presence mask, tl_rulebook_compact)
 static __device__ __forceinline__ void decode_ctab(const int32_t* __restrict__ ctab, int64_t n, int64_t row, bool rvalid, int (&idx)[27]) {
   int base[9];
@@ -157,3 +304,6 @@ int tl_launch_conv_win(const ConvP& p, hipStream_t s);                  // bf16,
 // tl_conv_small.hip
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves
 int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s);   // Cin <= 8 (the 4-channel input conv)
+
+// tl_linear_small.hip
+int tl_launch_conv_tinycout(const ConvP& p, int dtype, hipStream_t s);  // K = 1, Cout <= 8 (the heads' output Linears)

@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   // epilogue, one 32x32 block at a time through a wave-private LDS transposition buffer (aliases the weight tiles)
   __syncthreads();
   float* ew = Es + wv * 32 * EP;
+  float red0[NB], red1[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { red0[nb] = 0.f; red1[nb] = 0.f; }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -186,20 +189,11 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
       for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[rb][nb][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int e0 = 0; e0 < 2; ++e0) {
-        const int e = lane + e0 * 64;                        // 32 rows x 4 vectors of 8 channels
-        const int rr = e >> 2, cvv = e & 3;
-        const int64_t orow = r0 + rb * 32 + rr;
-        if (orow < p.n_out) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
-          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          epi_views8<BF16>(p, orow, nb * 32 + cvv * 8, v);
-        }
-      }
+      epi_block32<BF16, EP>(p, ew, lane, r0 + rb * 32, nb * 32, red0[nb], red1[nb]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  if (p.epi_mode != TL_EPI_NONE) epi_finish_wg<WAVES, EP, NB>(p, Es, tid, red0, red1);
 }
 
 template <bool BF16, int K, int NB, int UN, int DA, int RB, bool TM = false, bool OH = false>
@@ -219,6 +213,7 @@ int launch(ConvP p, hipStream_t s) {
   }
   p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32 * RB);
   k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH><<<p.nblk, NT, lds, s>>>(p);
+  if (p.red_nparts) *p.red_nparts = p.nblk;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 

@@ -224,6 +224,9 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   // epilogue: MFMA row m = (r & 3) + 8 (r >> 2) + 4 fh is tile row rho(m) = ((m >> 2) & 7) + 8 (m & 3) = 2 (r >> 2) + fh + 8 (r & 3)
   __syncthreads();
   float* ew = Es + wv * 32 * EP;
+  float red0[NB], red1[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { red0[nb] = 0.f; red1[nb] = 0.f; }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -232,20 +235,11 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
       for (int r = 0; r < 16; ++r) ew[(2 * (r >> 2) + fh + 8 * (r & 3)) * EP + fi] = acc[rb][nb][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int e0 = 0; e0 < 2; ++e0) {
-        const int e = lane + e0 * 64;
-        const int rr = e >> 2, cvv = e & 3;
-        const int64_t orow = r0 + rb * 32 + rr;
-        if (orow < p.n_out) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
-          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          epi_views8<true>(p, orow, nb * 32 + cvv * 8, v);
-        }
-      }
+      epi_block32<true, EP>(p, ew, lane, r0 + rb * 32, nb * 32, red0[nb], red1[nb]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  if (p.epi_mode != TL_EPI_NONE) epi_finish_wg<W, EP, NB>(p, Es, tid, red0, red1);
 }
 
 template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0, int SP = 1>
@@ -262,6 +256,7 @@ int launch(ConvP p, hipStream_t s) {
   }
   p.nblk = (int)tl_cdiv(p.n_out, W * 32 * RB);
   k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP><<<p.nblk, W * 64, lds, s>>>(p);
+  if (p.red_nparts) *p.red_nparts = p.nblk;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 

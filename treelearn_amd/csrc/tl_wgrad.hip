@@ -505,6 +505,10 @@ static int g_wgrad_bf16_mfma = 1;          // developer A/B (tl_dev_wgrad_mode):
 int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout);
 int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
                           int Cout, float* gw, float* ws, hipStream_t s);
+int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s);
+// tl_linear_small.hip: K = 1 with <= 4 output channels (the heads' output Linears)
+int64_t tl_wgrad_tinycout_parts(int64_t n);
+int tl_launch_wgrad_tinycout(const void* x, int64_t x_ld, const void* g, int64_t g_ld, int dtype, int64_t n, int Cin, int Cout, float* gw, float* ws, hipStream_t s);
 
 extern "C" {
 
@@ -520,6 +524,7 @@ int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
   int64_t nparts = tl_cdiv(n_out, (int64_t)kRowsPerWave * kWaves) * kWaves;
   const int64_t dense = tl_wgrad_dense_slots(n_out, K, Cin, Cout);
   if (dense > nparts) nparts = dense;
+  if (K == 1 && Cout <= 4 && tl_wgrad_tinycout_parts(n_out) > nparts) nparts = tl_wgrad_tinycout_parts(n_out);
   return nparts * K * Cout * Cin;
 }
 
@@ -535,6 +540,10 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   int64_t nchunks_used = nchunks;
   const bool bf16_mfma = dtype == TL_BF16 && Cout % 8 == 0 && Cin % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && ((uintptr_t)x) % 16 == 0 &&
                          ((uintptr_t)gout) % 16 == 0 && g_wgrad_bf16_mfma;
+  if (K == 1 && !table && Cout <= 4 && n_in == n_out) {
+    const int rc = tl_launch_wgrad_tinycout(x, x_ld, gout, g_ld, dtype, n_out, Cin, Cout, gw, ws, s);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
   if (bf16_mfma && table) {
     const int rc = tl_launch_wgrad_dense((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, table, n_out, n_in, K, Cin, Cout, gw, ws, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
@@ -600,7 +609,9 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
 #undef TL_W
   }
   const int64_t per = (int64_t)K * Cout * Cin;
-  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, bf16_mfma ? nchunks_used : nchunks * kWaves, per, gw);
+  const int64_t nparts = bf16_mfma ? nchunks_used : nchunks * kWaves;
+  if (per % 4 == 0 && ((uintptr_t)ws) % 16 == 0 && ((uintptr_t)gw) % 16 == 0) return tl_launch_wgrad_reduce(ws, nparts, per, gw, s);
+  k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nparts, per, gw);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

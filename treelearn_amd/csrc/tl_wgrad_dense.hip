@@ -209,20 +209,22 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense(const uint16_t* __restr
       }
 }
 
-// gw[e] = sum over the partial tile sets, four interleaved partial sums per element combined in a fixed order (deterministic)
+// gw[e] = sum over the partial tile sets.  A workgroup = 64 float4 elements x 4 part lanes: lane pl adds parts pl, pl + 4, ... in that
+// order (two interleaved sums, many loads in flight), the four lane sums are combined through LDS in a fixed order: deterministic.
 __global__ void __launch_bounds__(256) k_wgrad_reduce_par(const float* __restrict__ ws, int nparts, int64_t per, float* __restrict__ gw) {
-  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v * 4 >= per) return;
-  const f32x4* src = reinterpret_cast<const f32x4*>(ws) + v;
-  const int64_t stride = per / 4;
-  f32x4 s[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  int p = 0;
-  for (; p + 4 <= nparts; p += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] += src[(int64_t)(p + u) * stride];
+  __shared__ f32x4 red[4][64];
+  const int e = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int64_t v = (int64_t)blockIdx.x * 64 + e, stride = per / 4;
+  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+  if (v < stride) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(ws) + v;
+    int p = pl;
+    for (; p + 4 < nparts; p += 8) { s0 += src[(int64_t)p * stride]; s1 += src[(int64_t)(p + 4) * stride]; }
+    if (p < nparts) s0 += src[(int64_t)p * stride];
   }
-  for (int u = 0; p < nparts; ++p, ++u) s[u] += src[(int64_t)p * stride];
-  reinterpret_cast<f32x4*>(gw)[v] = (s[0] + s[1]) + (s[2] + s[3]);
+  red[pl][e] = s0 + s1;
+  __syncthreads();
+  if (pl == 0 && v < stride) reinterpret_cast<f32x4*>(gw)[v] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 template <int NBO, int NBIW, int KS, int PD, int NW>
@@ -243,6 +245,12 @@ int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, con
 }
 
 }  // namespace
+
+// shared with tl_wgrad.hip: gw = ordered sum of `nparts` partial tile sets of `per` floats (per % 4 == 0, 16-B aligned)
+int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s) {
+  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 64), 256, 0, s>>>(ws, (int)nparts, per, gw);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
 
 int g_wgrad_dense = 1;            // tl_set_tuning("wgrad_dense", 0) restores the pair-list kernels of tl_wgrad.hip everywhere
 int64_t g_wgrad_dense_min_rows = 60000;
@@ -276,6 +284,5 @@ int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, in
   }
   if (rc != TL_OK) return rc;
   const int64_t per = (int64_t)K * Cout * Cin;
-  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 256), 256, 0, s>>>(ws, gx, per, gw);
-  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+  return tl_launch_wgrad_reduce(ws, gx, per, gw, s);
 }

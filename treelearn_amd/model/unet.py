@@ -89,6 +89,16 @@ class ResidualBlock(SparseModule):
 
     def forward(self, input):
         last = len(self.conv_branch) - 1
+        cb = self.conv_branch
+        from ..autograd import fusable_bn
+        if (torch.is_grad_enabled() and input.features.shape[0] > 1 and input.features.requires_grad and fusable_bn(cb[0], input.features)
+                and cb[3].training and cb[2].bias is None and cb[5].bias is None):
+            # training: both BatchNorm -> ReLU -> conv triples as fused autograd nodes (autograd._BNReLUConvFn); the first hands the
+            # input back (`skip`) for the identity branch, the second adds the identity result in its epilogue
+            t, skip = cb[2].forward_fused(input, cb[0], True, want_skip=True)
+            res = self.i_branch(input.replace_feature(skip)).features
+            out, _ = cb[5].forward_fused(t, cb[3], True, residual=res)
+            return out
         # the input feeds the conv branch AND the identity branch: in training the first BatchNorm hands it back (`skip`) and the
         # identity branch takes that, so the two gradients of the fan-out are added inside the BatchNorm backward kernel
         branch, skip = self.conv_branch(input, stop=last, want_skip=True)
@@ -123,6 +133,10 @@ class UBlock(nn.Module):
             down, skip = self.conv(output, want_skip=True)     # same fan-out as in ResidualBlock: skip = the features the concat takes
             identity = skip if skip is not None else output.features
             dec = self.deconv(self.u(down))
-            output = output.replace_feature(torch.cat((identity, dec.features), dim=1))
+            cat = torch.cat((identity, dec.features), dim=1)
+            sa, sb = getattr(identity, "_tl_stats", None), getattr(dec.features, "_tl_stats", None)
+            if sa is not None and sb is not None:              # per-channel statistics of a concat = those of its halves
+                cat._tl_stats = list(sa) + list(sb)
+            output = output.replace_feature(cat)
             output = self.blocks_tail(output)
         return output

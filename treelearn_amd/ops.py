@@ -45,9 +45,14 @@ def _check_table(table, K, n_out, device):
 
 def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
              in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False,
-             out2=None, out3=None, one_hot=False):
+             out2=None, out3=None, one_hot=False, epi=None):
     """out[o] = epi(sum_k W[k] . pro(x[table[k][o]])); x / out / residual may be column views of wider
-    row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused."""
+    row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused.
+
+    `epi` (training): "stats" -> the kernel also sums y and y^2 per channel (the statistics of the BatchNorm that consumes the result);
+    ("bn_bwd", x_bn, st, relu) -> this is the input-gradient conv of a layer fed by relu?(bn(x_bn)): the result is masked by the ReLU
+    and the sums of g and g * xhat are formed (tl_conv_args.epi_mode).  Returns (out, parts f64[.,2,Cout], nparts), or None when the
+    kernel family that serves the shape has no such epilogue (nothing was launched: the caller runs the separate passes)."""
     L = _hip.lib()
     K, Cout, Cin = w_packed.shape
     if x.stride(1) != 1 or x.shape[1] != Cin:
@@ -92,6 +97,25 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
         setattr(a, name + "_scale", sc.data_ptr() if sc is not None else None)
         setattr(a, name + "_shift", sh.data_ptr() if sh is not None else None)
         setattr(a, name + "_relu", int(bool(relu)))
+    if epi is not None:
+        parts = torch.empty((int(L.tl_conv_red_parts(n_out)), 2, Cout), dtype=torch.float64, device=x.device)
+        nparts = ctypes.c_int32(0)
+        a.red_part = parts.data_ptr(); a.red_nparts = ctypes.pointer(nparts)
+        if epi == "stats":
+            a.epi_mode = _hip.TL_EPI_STATS
+        else:
+            _, xb, st, relu = epi
+            if xb.dtype != x.dtype or xb.stride(1) != 1 or xb.shape[0] != n_out or xb.shape[1] != Cout:
+                raise ValueError("bad BatchNorm input view for the bn_bwd epilogue")
+            a.epi_mode = _hip.TL_EPI_BN_BWD
+            a.bn_x = xb.data_ptr(); a.bn_x_ld = xb.stride(0)
+            a.bn_mean = st[0].data_ptr(); a.bn_rstd = st[1].data_ptr(); a.bn_scale = st[2].data_ptr(); a.bn_shift = st[3].data_ptr()
+            a.bn_relu = int(bool(relu))
+        rc = L.tl_conv_fwd(ctypes.byref(a), _hip.stream())
+        if rc == _hip.TL_ERR_UNSUPPORTED:
+            return None
+        _hip.check(rc, "tl_conv_fwd")
+        return out, parts, int(nparts.value)
     if PROFILE is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -175,6 +199,45 @@ def bn_train_stats(x, gamma, beta, eps, momentum, running_mean=None, running_var
                                    _hip.ptr(ws), _hip.ptr(st[0]), _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), _hip.ptr(running_mean),
                                    _hip.ptr(running_var), _hip.ptr(num_batches_tracked), _hip.stream()), "tl_bn_train_stats")
     return st
+
+
+def bn_train_finish(segments, n, gamma, beta, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """Batch statistics from conv-epilogue partial sums (tl_bn_train_finish): `segments` = [(parts f64[.,2,Ci], nparts, Ci), ...] covers
+    the channels in order (one segment per producer: the two halves of a skip concat come from different convs) -> st [4, C] as
+    bn_train_stats returns it; running statistics updated in place."""
+    L = _hip.lib()
+    C = sum(sg[2] for sg in segments)
+    st = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    c0 = 0
+    for i, (parts, nparts, Ci) in enumerate(segments):
+        sl = slice(c0, c0 + Ci)
+        _hip.check(L.tl_bn_train_finish(_hip.ptr(parts), nparts, n, Ci, _hip.ptr(gamma[sl]), _hip.ptr(beta[sl]), float(eps), float(momentum),
+                                        _hip.ptr(st[0, sl]), _hip.ptr(st[1, sl]), _hip.ptr(st[2, sl]), _hip.ptr(st[3, sl]),
+                                        _hip.ptr(running_mean[sl]) if running_mean is not None else None,
+                                        _hip.ptr(running_var[sl]) if running_var is not None else None,
+                                        _hip.ptr(num_batches_tracked) if (num_batches_tracked is not None and i == 0) else None, _hip.stream()),
+                   "tl_bn_train_finish")
+        c0 += Ci
+    return st
+
+
+def bn_train_bwd_from_parts(x, g, st, parts, nparts, dx_add=None):
+    """(dx, dgamma, dbeta) from an already masked g and the conv epilogue's partial sums of g and g * xhat (tl_bn_train_bwd_from_parts);
+    None if the views do not allow the vector kernel."""
+    L = _hip.lib()
+    n, C = x.shape
+    dx = torch.empty((n, C), dtype=x.dtype, device=x.device)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    if dx_add is not None and (dx_add.shape != x.shape or dx_add.dtype != x.dtype or dx_add.stride(1) != 1):
+        raise ValueError("dx_add must match x in shape and dtype")
+    rc = L.tl_bn_train_bwd_from_parts(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(g), g.stride(0), _hip.dtype_code(g.dtype), n, C,
+                                      _hip.ptr(st[0]), _hip.ptr(st[1]), _hip.ptr(st[2]), _hip.ptr(st[3]), _hip.ptr(parts), nparts,
+                                      _hip.ptr(dgb[0]), _hip.ptr(dgb[1]), _hip.ptr(dx), dx.stride(0), _hip.ptr(dx_add),
+                                      dx_add.stride(0) if dx_add is not None else 0, _hip.stream())
+    if rc == _hip.TL_ERR_UNSUPPORTED:
+        return None
+    _hip.check(rc, "tl_bn_train_bwd_from_parts")
+    return dx, dgb[0], dgb[1]
 
 
 def column_sum(x):

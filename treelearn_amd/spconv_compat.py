@@ -76,6 +76,16 @@ class SparseSequential(SparseModule):
                     if fusable_bn(module, x.features):
                         # training-mode BatchNorm1d (+ the ReLU behind it) on the HIP kernels instead of ATen's
                         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                        nxt = mods[i + 1 + int(relu)] if i + 1 + int(relu) < len(mods) else None
+                        if type(nxt) in (SubMConv3d, SparseConv3d, SparseInverseConv3d) and nxt.bias is None and torch.is_grad_enabled():
+                            # BatchNorm -> ReLU -> conv as one autograd node (autograd._BNReLUConvFn): statistics and backward
+                            # reductions ride on the conv kernels' epilogues
+                            ws = want_skip and i == 0 and x.features.requires_grad
+                            x, sk = nxt.forward_fused(x, module, relu, want_skip=ws)
+                            if ws:
+                                skip = sk
+                            i += 2 + int(relu)
+                            continue
                         if want_skip and i == 0 and x.features.requires_grad:
                             y, skip = bn_relu_train(x.features, module, relu, skip=True)
                             x = x.replace_feature(y)
@@ -121,6 +131,28 @@ class SparseConvolution(SparseModule):
     def _table(self, x):
         raise NotImplementedError
 
+    def forward_fused(self, x, bn, relu, residual=None, want_skip=False):
+        """conv(relu?(bn(x))) [+ residual] of a training-mode BatchNorm1d `bn` in front of this conv, as one autograd node
+        (autograd.bn_relu_conv).  Returns (SparseConvTensor, skip features or None)."""
+        from .autograd import bn_relu_conv, fusable_bn
+        ref, out_level = self._table(x)
+        amp = SparseConvolution.amp_dtype
+        fin = x.features if (amp is None or x.features.dtype == amp) else x.features.to(amp)
+        if not fusable_bn(bn, fin) or self.bias is not None:           # not a BatchNorm the HIP training kernels serve: module by module
+            f = bn(x.features)
+            out = self.forward(x.replace_feature(torch.relu(f) if relu else f), residual)
+            return out, (x.features if want_skip else None)
+        fuse = residual is not None and residual.dtype == fin.dtype and residual.is_cuda
+        out = bn_relu_conv(fin, bn, relu, self.weight, ref, residual if fuse else None, want_skip)
+        feats, skip = out if want_skip else (out, None)
+        if residual is not None and not fuse:
+            feats = feats + residual.to(feats.dtype)
+        lv = x.geometry.levels[out_level]
+        res = SparseConvTensor(feats, lv.coords, list(lv.shape), x.batch_size, x.geometry, out_level)
+        res.indice_dict = x.indice_dict
+        res.grid = x.grid
+        return res, skip
+
     def forward(self, x, residual=None):
         """`residual` [n_out, Cout]: added to the conv result -- inside the kernel's epilogue when the dtypes allow it (the
         `output.features + i_branch(identity).features` of reference blocks.py:76-78 without a separate add pass)."""
@@ -129,7 +161,7 @@ class SparseConvolution(SparseModule):
         amp = SparseConvolution.amp_dtype
         fin = x.features if (amp is None or x.features.dtype == amp) else x.features.to(amp)
         fuse = residual is not None and residual.dtype == fin.dtype and residual.is_cuda
-        feats = sparse_conv(fin, self.weight, ref, residual if fuse else None)
+        feats = sparse_conv(fin, self.weight, ref, residual if fuse else None, want_stats=self.bias is None and (residual is None or fuse))
         if residual is not None and not fuse:
             feats = feats + residual.to(feats.dtype)
         if self.bias is not None:
