@@ -204,6 +204,9 @@ int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
 /* Repack a reference-layout conv weight [Cout, k,k,k, Cin] (spconv `.weight`)
  * into the kernel layout [K=k^3][Cout][Cin] with dtype conversion. */
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream);
+/* Weights of the input-gradient ("dgrad") conv of the same layer, for tl_conv_fwd over the transposed rulebook: w_t[k][ci][co] =
+ * w_ref[co][flip ? K-1-k : k][ci] (taps flip for SubM convs: nbr[k][o] = i <=> nbr[K-1-k][i] = o), with dtype conversion. */
+int tl_pack_weight_dgrad(const float* w_ref, int Cout, int K, int Cin, int flip, void* w_t, int dtype, tl_stream_t stream);
 /* Same weights in fragment order (Cout % 32 == 0, Cin % 32 == 0): [K][Cout/32][Cin/32][J][64 lanes][16 B], where lane
  * (fi = lane & 31, fh = lane >> 5) of 16-B piece j holds W[k][32 cb + fi][32 ch + (32 j + 16 fh) / sizeof(elem) ...]:
  * the B operand of one 32x32 MFMA step is one contiguous 1 KB block (J = 2 for bf16, 4 for fp32). */
@@ -267,6 +270,15 @@ int tl_bn_train_finish(const double* part, int64_t nparts, int64_t n, int C, con
 int tl_bn_train_bwd_from_parts(const void* x, int64_t ld, int x_dtype, const void* g, int64_t gld, int g_dtype, int64_t n, int C, const float* mean,
                                const float* rstd, const float* scale, const float* shift, const double* part, int64_t nparts, float* dgamma, float* dbeta,
                                void* dx, int64_t xld, const void* dx_add, int64_t dx_add_ld, tl_stream_t stream);
+
+/* Voxel -> point feature gather and its gradient (tree_learn.py:98 `output.features[v2p_map]`; tools/training/train.py:40):
+ *   tl_gather_rows     : out[p, :] = in[idx[p], :] for p < N (idx < 0 counts from the end like torch indexing; in [n_rows, C]);
+ *   tl_scatter_add_rows: gin[v, :] = sum over the points p with idx[p] == v of g[p, :], added in ascending p in fp32; `order` i64[N] =
+ *                        the STABLE argsort of idx, sorted_idx = idx[order]; gin [n_rows, C] contiguous, fully written (rows without a
+ *                        point are zero).  Deterministic, no atomics.  C * sizeof(elem) % 16 == 0, 16-B aligned rows. */
+int tl_gather_rows(const void* in, int64_t in_ld, int dtype, int C, int64_t n_rows, const int64_t* idx, int64_t N, void* out, int64_t out_ld, tl_stream_t stream);
+int tl_scatter_add_rows(const void* g, int64_t g_ld, int dtype, int C, const int64_t* order, const int64_t* sorted_idx, int64_t N, int64_t n_rows, void* gin,
+                        int64_t gin_ld, tl_stream_t stream);
 
 /* Keep rows where mask != 0 (masks_inner filtering before D2H, util/pipeline.py:100-103).
  * in f32[n,C] -> out f32[count,C]; count i32[1] device.  Stable (input order kept).

@@ -828,6 +828,7 @@ def test_inverse_conv_one_hot_form(cin, cout, n_out):
                                                (64, 32, 1, 6000), (224, 224, 27, 223), (96, 96, 27, 3000), (192, 96, 27, 1500),
                                                (96, 96, 27, 120000), (192, 96, 27, 100100),       # big levels: the dense-over-taps form (tl_wgrad_dense.hip)
                                                (32, 2, 1, 50000), (32, 3, 1, 70001), (64, 4, 1, 3000),     # the heads' output Linears (tl_linear_small.hip)
+                                               (32, 32, 1, 100003), (64, 32, 1, 70000), (128, 64, 1, 40001), (192, 96, 1, 33000), (256, 128, 1, 31000),   # tl_wgrad_rows.hip
                                                (32, 32, 27, 70001), (64, 32, 27, 65000), (64, 64, 27, 99999), (128, 64, 27, 61000),
                                                (96, 96, 27, 50000), (192, 96, 27, 40000)])        # multiples of 96 below the dense form's row threshold: 96 x 96 pair-list blocks
 def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):

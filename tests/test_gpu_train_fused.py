@@ -81,10 +81,12 @@ def test_conv_epilogue_bn_backward(cin, cout, K, n, relu):
     assert err < 1e-2                                                                       # one bf16 rounding of dx
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_fused_training_nodes_equal_separate_passes(dtype):
-    """One training step of a 4-level model on a 14 m tile (120 k voxels at level 1: the big levels take the epilogue-fused kernels,
-    the small ones the separate passes) with TL_TRAIN_FUSE on and off: same loss, running statistics and gradients."""
+def test_fused_training_nodes_equal_separate_passes():
+    """One training step of a 4-level model on two 14 m tiles (the big levels take the epilogue-fused kernels, the small ones the separate
+    passes) with the fusion on and off (autograd.FUSE_BN).  fp32: same loss, running statistics and gradients up to summation order.
+    bf16: the two paths differ by rounding flips that the small deep levels amplify (a channel whose batch mean is several standard
+    deviations sees a bf16 ulp as per cents of its normalised value), so the check is that the fused gradients are as close to the fp32
+    gradients as the separate-pass gradients are -- a bias in the fused path would show as a larger distance."""
     from treelearn_amd import autograd as ag
     from treelearn_amd.model import TreeLearn
     from treelearn_amd.synth import make_batch, make_tile, random_state_dict
@@ -92,29 +94,64 @@ def test_fused_training_nodes_equal_separate_passes(dtype):
     batch = make_batch([make_tile(extent=14.0, voxel=0.1, n_trees=8, fill=0.10, seed=s) for s in (3, 4)])
     gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
     res = {}
-    for fuse in (True, False):
-        ag.FUSE_BN = fuse
-        try:
-            model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, compute_dtype=dtype, **cfg)
-            model.load_state_dict(random_state_dict(5, **cfg), strict=True)
-            model = model.cuda().train()
-            loss, _ = model(gb, return_loss=True)
-            loss.backward()
-            res[fuse] = (float(loss), {n: p.grad.detach().float().cpu().numpy() for n, p in model.named_parameters()},
-                         {n: b.detach().float().cpu().numpy() for n, b in model.named_buffers() if "running" in n})
-        finally:
-            ag.FUSE_BN = True
-    (la, ga, ba), (lb, gb_, bb) = res[True], res[False]
-    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
-    assert la == pytest.approx(lb, rel=tol)
-    for n in bb:                                                                  # bf16: activations that differ by a rounding shift a channel mean by ~1e-4
-        np.testing.assert_allclose(ba[n], bb[n], rtol=1e-3, atol=(3e-3 if dtype == torch.bfloat16 else 1e-5) * max(1e-3, float(np.abs(bb[n]).max())))
-    worst = 0.0
-    for n in ga:
-        a, b = ga[n].ravel(), gb_[n].ravel()
-        assert np.isfinite(a).all()
-        if np.linalg.norm(b) > 0:
-            cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
-            worst = max(worst, 1 - cos)
-            assert cos > (0.995 if dtype == torch.bfloat16 else 0.99999), (n, cos)
-            assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < (5e-2 if dtype == torch.bfloat16 else 1e-3), n
+    for dtype in (torch.float32, torch.bfloat16):
+        for fuse in (True, False):
+            ag.FUSE_BN = fuse
+            try:
+                model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, compute_dtype=dtype, **cfg)
+                model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+                model = model.cuda().train()
+                loss, _ = model(gb, return_loss=True)
+                loss.backward()
+                res[dtype, fuse] = (float(loss.detach()), {n: p.grad.detach().float().cpu().numpy().ravel() for n, p in model.named_parameters()},
+                                    {n: b.detach().float().cpu().numpy() for n, b in model.named_buffers() if "running" in n})
+            finally:
+                ag.FUSE_BN = True
+
+    def cosd(a, b):
+        return 1 - float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    # a Linear bias in front of a BatchNorm has a zero gradient in exact arithmetic: what is computed there is rounding noise
+    names = [n for n in res[torch.float32, False][1] if n not in ("semantic_linear.0.bias", "offset_linear.0.bias")]
+    (la, ga, ba), (lb, gb_, bb) = res[torch.float32, True], res[torch.float32, False]
+    assert la == pytest.approx(lb, rel=1e-5)
+    for n in bb:
+        np.testing.assert_allclose(ba[n], bb[n], rtol=1e-4, atol=1e-6)
+    for n in names:
+        assert np.isfinite(ga[n]).all()
+        if np.linalg.norm(gb_[n]) > 0:
+            assert cosd(ga[n], gb_[n]) < 1e-4, n
+            assert abs(np.linalg.norm(ga[n]) / np.linalg.norm(gb_[n]) - 1) < 2e-3, n
+    (lf, gf, bf), (ls, gs, bs) = res[torch.bfloat16, True], res[torch.bfloat16, False]
+    assert lf == pytest.approx(ls, rel=2e-3) and lf == pytest.approx(lb, rel=2e-2)
+    for n in bs:
+        np.testing.assert_allclose(bf[n], bs[n], rtol=1e-3, atol=3e-3 * max(1e-3, float(np.abs(bs[n]).max())))
+    df = np.array([cosd(gf[n], gb_[n]) for n in names if np.linalg.norm(gb_[n]) > 0])
+    ds = np.array([cosd(gs[n], gb_[n]) for n in names if np.linalg.norm(gb_[n]) > 0])
+    assert np.isfinite(df).all() and df.mean() < 1.25 * ds.mean() + 1e-3, (df.mean(), ds.mean())
+    assert df.max() < 1.5 * ds.max() + 1e-2, (df.max(), ds.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gather_rows_and_scatter_add_vs_torch(dtype):
+    """features[v2p] (tl_gather_rows) and its gradient (tl_scatter_add_rows over the stable argsort): duplicates, voxels without a point,
+    a negative index (counts from the end, as torch indexing does); bit-reproducible."""
+    from treelearn_amd.autograd import gather_rows
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, N, C = 50000, 140001, 32
+    idx = torch.randint(0, n - 100, (N,), generator=g)
+    idx[:5000] = torch.arange(5000) // 3                                          # up to three points per voxel
+    idx[7] = -1
+    idx = idx.to(d)
+    x = torch.randn(n, C, generator=g).to(d).to(dtype).requires_grad_(True)
+    w = torch.randn(N, C, generator=g).to(d).to(dtype)
+    cache = {}
+    y = gather_rows(x, idx, cache)
+    assert torch.equal(y.detach(), x.detach()[idx])
+    (y.float() * w.float()).sum().backward()
+    g1 = x.grad.clone(); x.grad = None
+    y2 = gather_rows(x, idx, cache); (y2.float() * w.float()).sum().backward()
+    assert torch.equal(g1, x.grad) and "v2p_sort" in cache
+    ref = torch.zeros(n, C, dtype=torch.float64, device=d).index_add_(0, torch.where(idx < 0, idx + n, idx), w.double())
+    err = float((g1.double() - ref).abs().max() / ref.abs().max())
+    assert err < (1e-2 if dtype == torch.bfloat16 else 1e-6)

@@ -78,6 +78,7 @@ PROTOTYPES = {
     "tl_bn_train_bwd_from_parts": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "tl_pack_weight_dgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_conv_wgrad_ws_floats": (_i64, [_i64, _i32, _i32, _i32]),
     "tl_conv_wgrad": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "tl_head_mlp": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -85,6 +86,8 @@ PROTOTYPES = {
     "tl_bn_ws_doubles": (_i64, [_i64, _i32]),
     "tl_bn_train_stats": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_bn_train_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "tl_gather_rows": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "tl_scatter_add_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "tl_compact_ws_words": (_i64, [_i64]),
     "tl_compact_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tl_tile_crop_ws_words": (_i64, [_i64]),

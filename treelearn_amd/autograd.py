@@ -58,7 +58,8 @@ class _SparseConvFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         from . import backward as bw
         x, weight = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
+        if grad_out.stride(1) != 1 or grad_out.stride(0) % 8 or grad_out.data_ptr() % 16:
+            grad_out = grad_out.contiguous()
         gx, gw = bw.conv_backward(x, weight, ctx.ref, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, None, (grad_out if ctx.needs_input_grad[3] else None), None      # d(out)/d(residual) = identity: no kernel
 
@@ -112,8 +113,10 @@ class _BNReLUConvFn(torch.autograd.Function):
     def backward(ctx, gy, gskip=None):
         from . import backward as bw
         x, a, st, weight = ctx.saved_tensors
-        gy = gy.contiguous()
-        if gskip is not None:
+        # the gradient of a skip concat arrives as column views of one [n, 2C] tensor: the kernels take a row stride, no copies
+        if gy.stride(1) != 1 or gy.stride(0) % 8 or gy.data_ptr() % 16:
+            gy = gy.contiguous()
+        if gskip is not None and (gskip.dtype != x.dtype or gskip.stride(1) != 1 or gskip.stride(0) % 8 or gskip.data_ptr() % 16):
             gskip = gskip.to(x.dtype).contiguous()
         need_gw = ctx.needs_input_grad[3]
         dx, dgamma, dbeta, gw = bw.bn_conv_backward(x, a, st, ctx.relu, weight, ctx.ref, gy, need_gw, gskip)
@@ -157,10 +160,11 @@ class _BNReLUTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         x, st = ctx.saved_tensors
-        dy = dy.contiguous()
+        if dy.stride(1) != 1 or dy.stride(0) % 8 or dy.data_ptr() % 16:
+            dy = dy.contiguous()
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
-        if dskip is not None:
+        if dskip is not None and (dskip.dtype != x.dtype or dskip.stride(1) != 1 or dskip.stride(0) % 8 or dskip.data_ptr() % 16):
             dskip = dskip.to(x.dtype).contiguous()
         dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu, dx_add=dskip)    # dx in x's dtype (bf16 stays bf16 under mixed precision)
         return dx, dgamma, dbeta, None, None, None, None
@@ -211,3 +215,38 @@ def fusable_bn(module, x):
     """True when `module` is a BatchNorm1d that the HIP training kernels serve for x (batch statistics, affine, CUDA, C % 4 == 0)."""
     return (isinstance(module, torch.nn.BatchNorm1d) and module.training and module.affine and module.momentum is not None and x.is_cuda
             and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16))
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """point_feats = voxel_feats[v2p] (reference tree_learn.py:98) on tl_gather_rows; backward = tl_scatter_add_rows over the stable argsort
+    of v2p (cached on the geometry object: one sort per batch), deterministic."""
+
+    @staticmethod
+    def forward(ctx, feats, idx, cache):
+        feats = feats.contiguous()
+        out = ops.gather_rows(feats, idx)
+        ctx.save_for_backward(idx)
+        ctx.n_rows, ctx.cache = feats.shape[0], cache
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        srt = ctx.cache.get("v2p_sort") if ctx.cache is not None else None
+        if srt is None:
+            sidx, order = torch.sort(idx, stable=True)
+            srt = (order, sidx)
+            if ctx.cache is not None:
+                ctx.cache["v2p_sort"] = srt
+        return ops.scatter_add_rows(g, srt[0], srt[1], ctx.n_rows), None, None
+
+
+def gather_rows(feats, idx, cache=None):
+    """feats[idx] for a 2-D feature matrix and an int64 index vector; differentiable w.r.t. feats.  `cache`: a dict that lives as long
+    as idx is valid (TileGeometry.cache) and keeps the argsort the backward pass needs."""
+    if feats.is_cuda and feats.dim() == 2 and idx.dtype == torch.int64 and feats.dtype in (torch.float32, torch.bfloat16) \
+            and (feats.shape[1] * feats.element_size()) % 16 == 0 and feats.shape[0] > 0 and idx.numel() > 0:
+        return _GatherRowsFn.apply(feats, idx, cache)
+    return feats[idx]

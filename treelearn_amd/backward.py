@@ -40,12 +40,7 @@ def _side_stream(device):
 
 def _dgrad_weight(weight, ref, dtype):
     """[K]["Cout" = Cin]["Cin" = Cout] weights of the input-gradient conv: W[k]^T, taps flipped for SubM."""
-    co, ci = weight.shape[0], weight.shape[-1]
-    K = weight.numel() // (co * ci)
-    w = weight.detach().reshape(co, K, ci).permute(1, 2, 0)
-    if ref.flip:
-        w = w.flip(0)
-    return w.contiguous().to(dtype)
+    return ops.pack_weight_dgrad(weight, dtype, ref.flip)
 
 
 def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, gskip):
@@ -67,21 +62,34 @@ def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, g
             gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
         gw.record_stream(cur)
     wt = _dgrad_weight(weight, ref, grad_out.dtype)
+    # the transposed conv is computed in column slices when it has > 224 output channels (the MFMA kernels' limit) and for the
+    # 2C -> C convs of the decoder from 128 channels on: two C -> C launches run faster than one C -> 2C (level 2: 2 x 0.6 vs 2.4 ms)
+    step = ci
+    if ci > 224:
+        step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
+    elif K == 27 and ci == 2 * co and ci >= 128:
+        step = co
+    slices = [(s0, step) for s0 in range(0, ci, step)]
+    wts = [wt] if len(slices) == 1 else [wt[:, s0:s0 + w_].contiguous() for s0, w_ in slices]
     res = None
-    if FUSE_BN and ci <= 224 and x.dtype == grad_out.dtype:
-        r = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in, one_hot=ref.t_one_hot, epi=("bn_bwd", x, st, relu))
-        if r is not None:
-            res = ops.bn_train_bwd_from_parts(x, r[0], st, r[1], r[2], dx_add=gskip)
-            if res is None:                                                    # views the vector kernel cannot take: g is masked already
-                res = ops.bn_train_bwd(x, r[0], st, False, dx_add=gskip)
+    if FUSE_BN and x.dtype == grad_out.dtype:
+        g = torch.empty((ref.n_in, ci), dtype=grad_out.dtype, device=grad_out.device)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, ci), dtype=torch.float32, device=x.device)
+        ok = True
+        for (s0, w_), wsl in zip(slices, wts):
+            sl = slice(s0, s0 + w_)
+            r = ops.conv_fwd(grad_out, wsl, ref.t_table, ref.n_in, out=g[:, sl], one_hot=ref.t_one_hot, epi=("bn_bwd", x[:, sl], st[:, sl], relu))
+            if r is None or ops.bn_train_bwd_from_parts(x[:, sl], g[:, sl], st[:, sl], r[1], r[2], dx_add=gskip[:, sl] if gskip is not None else None,
+                                                        dx=dx[:, sl], dgb=dgb[:, sl]) is None:
+                ok = False                                                     # no such epilogue for this shape (nothing launched): plain path
+                break
+        if ok:
+            res = (dx, dgb[0], dgb[1])
     if res is None:
-        if ci <= 224:
-            ga = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in, one_hot=ref.t_one_hot)
-        else:
-            ga = torch.empty((ref.n_in, ci), dtype=grad_out.dtype, device=grad_out.device)
-            step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
-            for s in range(0, ci, step):
-                ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=ga[:, s:s + step], one_hot=ref.t_one_hot)
+        ga = torch.empty((ref.n_in, ci), dtype=grad_out.dtype, device=grad_out.device)
+        for (s0, w_), wsl in zip(slices, wts):
+            ops.conv_fwd(grad_out, wsl, ref.t_table, ref.n_in, out=ga[:, s0:s0 + w_], one_hot=ref.t_one_hot)
         res = ops.bn_train_bwd(x, ga, st, relu, dx_add=gskip)
     if need_gw and not overlap:
         gw = ops.conv_wgrad(a, grad_out, ref.table, ref.n_out, K)
@@ -109,10 +117,7 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
             gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
         gw.record_stream(cur)
     if need_gx:
-        w = weight.detach().reshape(co, K, ci).permute(1, 2, 0)            # [K][Cin][Cout] = W[k]^T
-        if ref.flip:
-            w = w.flip(0)
-        wt = w.contiguous().to(grad_out.dtype)                             # kernel layout [K]["Cout"=Cin]["Cin"=Cout]
+        wt = _dgrad_weight(weight, ref, grad_out.dtype)                    # kernel layout [K]["Cout"=Cin]["Cin"=Cout] = W[k]^T (taps flipped for SubM)
         if ci <= 224:
             gx = ops.conv_fwd(grad_out, wt, ref.t_table, ref.n_in, one_hot=ref.t_one_hot)
         else:

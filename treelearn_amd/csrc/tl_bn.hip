@@ -87,24 +87,37 @@ __global__ void __launch_bounds__(kThreads) k_bn_stats(const T* __restrict__ x, 
   block_reduce_store<2>(acc, pt, C, part);
 }
 
-// fixed-order sum of the block partials of one (quantity, channel): lane l adds partials l, l + 64, ... in that order, then the 64
-// lane sums go through a fixed xor tree -- deterministic, and 64 loads in flight instead of one dependent chain of `blocks` loads
-static __device__ __forceinline__ double sum_partials(const double* __restrict__ part, int blocks, int64_t stride, int64_t off) {
-  double s = 0.0;
-  for (int b = threadIdx.x; b < blocks; b += 64) s += part[(int64_t)b * stride + off];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  return s;
+// fixed-order sum of the block partials of one (quantity, channel) by a 256-thread workgroup: thread t adds partials t, t + 256, ...
+// (four independent sums, so many loads are in flight: a conv epilogue leaves up to 15 000 partial rows), the 256 thread sums go
+// through a fixed LDS tree -- deterministic.  Every thread returns the total.
+constexpr int kFin = 256;
+static __device__ __forceinline__ double sum_partials(const double* __restrict__ part, int blocks, int64_t stride, int64_t off, double* red) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 3 * kFin < blocks; b += 4 * kFin) {
+    s0 += part[(int64_t)b * stride + off]; s1 += part[(int64_t)(b + kFin) * stride + off];
+    s2 += part[(int64_t)(b + 2 * kFin) * stride + off]; s3 += part[(int64_t)(b + 3 * kFin) * stride + off];
+  }
+  for (; b < blocks; b += kFin) s0 += part[(int64_t)b * stride + off];
+  __syncthreads();                                         // red is reused by consecutive calls
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int w = kFin / 2; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  return red[0];
 }
 
 // one wave per channel: block partials -> mean, biased var, scale / shift, running statistics
-__global__ void __launch_bounds__(64) k_bn_stats_finish(const double* __restrict__ part, int blocks, int64_t n, int C, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(kFin) k_bn_stats_finish(const double* __restrict__ part, int blocks, int64_t n, int C, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
                                                         float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         int64_t* __restrict__ num_batches_tracked) {
+  __shared__ double red[kFin];
   const int c = blockIdx.x;
-  const double s = sum_partials(part, blocks, 2 * (int64_t)C, c), ss = sum_partials(part, blocks, 2 * (int64_t)C, C + c);
+  const double s = sum_partials(part, blocks, 2 * (int64_t)C, c, red), ss = sum_partials(part, blocks, 2 * (int64_t)C, C + c, red);
   if (threadIdx.x != 0) return;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   const double m = s / (double)n;
@@ -150,9 +163,10 @@ __global__ void __launch_bounds__(kThreads) k_bn_bwd_reduce(const TX* __restrict
   block_reduce_store<2>(acc, pt, C, part);
 }
 
-__global__ void __launch_bounds__(64) k_bn_bwd_finish(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void __launch_bounds__(kFin) k_bn_bwd_finish(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[kFin];
   const int c = blockIdx.x;
-  const double s = sum_partials(part, blocks, 2 * (int64_t)C, c), sx = sum_partials(part, blocks, 2 * (int64_t)C, C + c);
+  const double s = sum_partials(part, blocks, 2 * (int64_t)C, c, red), sx = sum_partials(part, blocks, 2 * (int64_t)C, C + c, red);
   if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)sx; }
 }
 
@@ -277,7 +291,7 @@ int tl_bn_train_finish(const double* part, int64_t nparts, int64_t n, int C, con
                        float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int64_t* num_batches_tracked, tl_stream_t stream) {
   if (!part || nparts <= 0 || nparts > 0x7FFFFFFF || !gamma || !beta || !mean || !rstd || !scale || !shift || n <= 0 || C <= 0) return TL_ERR_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return TL_ERR_ARG;
-  k_bn_stats_finish<<<C, 64, 0, tl_s(stream)>>>(part, (int)nparts, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
+  k_bn_stats_finish<<<C, kFin, 0, tl_s(stream)>>>(part, (int)nparts, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
                                               num_batches_tracked);
   TL_CHECK_LAUNCH();
   return TL_OK;
@@ -289,7 +303,7 @@ int tl_bn_train_bwd_from_parts(const void* x, int64_t ld, int x_dtype, const voi
   if (!x || !g || !mean || !rstd || !scale || !shift || !part || nparts <= 0 || nparts > 0x7FFFFFFF || !dgamma || !dbeta || !dx || n <= 0 || C <= 0) return TL_ERR_ARG;
   if ((x_dtype != TL_F32 && x_dtype != TL_BF16) || (g_dtype != TL_F32 && g_dtype != TL_BF16)) return TL_ERR_ARG;
   hipStream_t s = tl_s(stream);
-  k_bn_bwd_finish<<<C, 64, 0, s>>>(part, (int)nparts, C, dgamma, dbeta);
+  k_bn_bwd_finish<<<C, kFin, 0, s>>>(part, (int)nparts, C, dgamma, dbeta);
   TL_CHECK_LAUNCH();
   if (!launch_apply_v8(x, ld, x_dtype, g, gld, g_dtype, n, C, mean, rstd, scale, shift, false, dgamma, dbeta, dx, xld, dx_add, ald, s)) return TL_ERR_UNSUPPORTED;
   TL_CHECK_LAUNCH();
@@ -316,7 +330,7 @@ int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, co
   else if (dtype == TL_BF16) k_bn_stats<__hip_bfloat16><<<blocks, kThreads, lds, s>>>((const __hip_bfloat16*)x, ld, n, C, pt, ws);
   else return TL_ERR_ARG;
   TL_CHECK_LAUNCH();
-  k_bn_stats_finish<<<C, 64, 0, s>>>(ws, blocks, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
+  k_bn_stats_finish<<<C, kFin, 0, s>>>(ws, blocks, n, C, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var,
                                                  num_batches_tracked);
   TL_CHECK_LAUNCH();
   return TL_OK;
@@ -337,7 +351,7 @@ int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int6
   do {                                                                                                                                 \
     k_bn_bwd_reduce<TX, TG><<<blocks, kThreads, lds, s>>>((const TX*)x, ld, (const TG*)dy, dld, n, C, pt, mean, rstd, scale, shift, relu, ws); \
     TL_CHECK_LAUNCH();                                                                                                                 \
-    k_bn_bwd_finish<<<C, 64, 0, s>>>(ws, blocks, C, dgamma, dbeta);                                                        \
+    k_bn_bwd_finish<<<C, kFin, 0, s>>>(ws, blocks, C, dgamma, dbeta);                                                        \
     TL_CHECK_LAUNCH();                                                                                                                 \
     if (relu && launch_apply_v8(x, ld, x_dtype, dy, dld, dy_dtype, n, C, mean, rstd, scale, shift, true, dgamma, dbeta, dx, xld, dx_add, ald, s)) { TL_CHECK_LAUNCH(); break; } \
     if (!relu && launch_apply_v8(x, ld, x_dtype, dy, dld, dy_dtype, n, C, mean, rstd, scale, shift, false, dgamma, dbeta, dx, xld, dx_add, ald, s)) { TL_CHECK_LAUNCH(); break; } \

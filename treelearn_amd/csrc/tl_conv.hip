@@ -208,6 +208,17 @@ __global__ void k_pack_weight(const float* __restrict__ w, int Cout, int K, int 
   }
 }
 
+// weights of the input-gradient conv straight from the reference layout: o[k][ci][co] = w[co][flip ? K-1-k : k][ci]
+__global__ void k_pack_weight_dgrad(const float* __restrict__ w, int Cout, int K, int Cin, int flip, void* __restrict__ o, int dtype) {
+  const int64_t total = (int64_t)Cout * K * Cin;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(t % Cout); const int64_t r = t / Cout; const int ci = (int)(r % Cin); const int k = (int)(r / Cin);
+    const float v = w[((int64_t)co * K + (flip ? K - 1 - k : k)) * Cin + ci];
+    if (dtype == TL_F32) reinterpret_cast<float*>(o)[t] = v;
+    else reinterpret_cast<__hip_bfloat16*>(o)[t] = __float2bfloat16(v);
+  }
+}
+
 // fragment order: vector v = ((((k*CB + cb)*CH + ch)*J + j)*64 + lane) holds 16 B = W[k][32cb + (lane&31)][32ch + (32j + 16(lane>>5))/EB ..]
 __global__ void k_pack_weight_frag(const float* __restrict__ w, int Cout, int K, int Cin, void* __restrict__ o, int dtype) {
   const int EB = dtype == TL_F32 ? 4 : 2, J = 32 * EB / 32, EPV = 16 / EB;
@@ -288,6 +299,7 @@ extern int g_small_mode;                          // tl_conv_small.hip
 extern int g_head_mode;                           // tl_head.hip
 extern int g_wgrad_dense;                         // tl_wgrad_dense.hip
 extern int64_t g_wgrad_dense_min_rows;
+extern int g_wgrad_rows;                          // tl_wgrad_rows.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
@@ -314,6 +326,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "head_mode")) { g_head_mode = (int)value; return TL_OK; }
   if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
   if (!strcmp(key, "wgrad_dense")) { g_wgrad_dense = (int)value; return TL_OK; }
+  if (!strcmp(key, "wgrad_rows")) { g_wgrad_rows = (int)value; return TL_OK; }
   if (!strcmp(key, "wgrad_dense_min_rows")) { g_wgrad_dense_min_rows = value; return TL_OK; }
   return TL_ERR_ARG;
 }
@@ -427,6 +440,13 @@ int64_t tl_conv_red_parts(int64_t n_out) {
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream) {
   if (!w_ref || !w_packed || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
   k_pack_weight<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_packed, dtype);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_pack_weight_dgrad(const float* w_ref, int Cout, int K, int Cin, int flip, void* w_t, int dtype, tl_stream_t stream) {
+  if (!w_ref || !w_t || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  k_pack_weight_dgrad<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, flip, w_t, dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

@@ -507,6 +507,9 @@ int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, in
                           int Cout, float* gw, float* ws, hipStream_t s);
 int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s);
 // tl_linear_small.hip: K = 1 with <= 4 output channels (the heads' output Linears)
+// tl_wgrad_rows.hip: K = 1 (1x1 convs, the heads' hidden Linears) as a row-streaming GEMM
+int tl_wgrad_rows_parts(int64_t n, int Cin, int Cout);
+int tl_launch_wgrad_rows(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, int64_t n, int Cin, int Cout, float* gw, float* ws, hipStream_t s);
 int64_t tl_wgrad_tinycout_parts(int64_t n);
 int tl_launch_wgrad_tinycout(const void* x, int64_t x_ld, const void* g, int64_t g_ld, int dtype, int64_t n, int Cin, int Cout, float* gw, float* ws, hipStream_t s);
 
@@ -525,6 +528,7 @@ int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
   const int64_t dense = tl_wgrad_dense_slots(n_out, K, Cin, Cout);
   if (dense > nparts) nparts = dense;
   if (K == 1 && Cout <= 4 && tl_wgrad_tinycout_parts(n_out) > nparts) nparts = tl_wgrad_tinycout_parts(n_out);
+  if (K == 1 && tl_wgrad_rows_parts(n_out, Cin, Cout) > nparts) nparts = tl_wgrad_rows_parts(n_out, Cin, Cout);
   return nparts * K * Cout * Cin;
 }
 
@@ -542,6 +546,10 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
                          ((uintptr_t)gout) % 16 == 0 && g_wgrad_bf16_mfma;
   if (K == 1 && !table && Cout <= 4 && n_in == n_out) {
     const int rc = tl_launch_wgrad_tinycout(x, x_ld, gout, g_ld, dtype, n_out, Cin, Cout, gw, ws, s);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
+  if (bf16_mfma && K == 1 && !table && n_in == n_out) {
+    const int rc = tl_launch_wgrad_rows((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, n_out, Cin, Cout, gw, ws, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (bf16_mfma && table) {

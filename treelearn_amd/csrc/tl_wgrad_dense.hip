@@ -209,22 +209,33 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense(const uint16_t* __restr
       }
 }
 
-// gw[e] = sum over the partial tile sets.  A workgroup = 64 float4 elements x 4 part lanes: lane pl adds parts pl, pl + 4, ... in that
-// order (two interleaved sums, many loads in flight), the four lane sums are combined through LDS in a fixed order: deterministic.
+// gw[e] = sum over the partial tile sets.  A workgroup = 16 float4 elements x 16 part lanes: lane pl adds parts pl, pl + 16, ... (up to
+// 8 loads, all in flight together), the sixteen lane sums are added in lane order through LDS: deterministic, and the partials -- just
+// written by the weight-gradient kernel -- stream out of L2 / Infinity Cache with thousands of loads in flight instead of one chain
+// per element.
 __global__ void __launch_bounds__(256) k_wgrad_reduce_par(const float* __restrict__ ws, int nparts, int64_t per, float* __restrict__ gw) {
-  __shared__ f32x4 red[4][64];
-  const int e = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int64_t v = (int64_t)blockIdx.x * 64 + e, stride = per / 4;
-  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+  __shared__ f32x4 red[16][16];
+  const int e = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 16 + e, stride = per / 4;
+  f32x4 s = {0, 0, 0, 0};
   if (v < stride) {
     const f32x4* src = reinterpret_cast<const f32x4*>(ws) + v;
-    int p = pl;
-    for (; p + 4 < nparts; p += 8) { s0 += src[(int64_t)p * stride]; s1 += src[(int64_t)(p + 4) * stride]; }
-    if (p < nparts) s0 += src[(int64_t)p * stride];
+    for (int p0 = pl; p0 < nparts; p0 += 128) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int p = p0 + 16 * u; t[u] = p < nparts ? src[(int64_t)p * stride] : f32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
   }
-  red[pl][e] = s0 + s1;
+  red[pl][e] = s;
   __syncthreads();
-  if (pl == 0 && v < stride) reinterpret_cast<f32x4*>(gw)[v] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  if (pl == 0 && v < stride) {
+    f32x4 a = red[0][e];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) a += red[l][e];
+    reinterpret_cast<f32x4*>(gw)[v] = a;
+  }
 }
 
 template <int NBO, int NBIW, int KS, int PD, int NW>
@@ -248,7 +259,7 @@ int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, con
 
 // shared with tl_wgrad.hip: gw = ordered sum of `nparts` partial tile sets of `per` floats (per % 4 == 0, 16-B aligned)
 int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s) {
-  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 64), 256, 0, s>>>(ws, (int)nparts, per, gw);
+  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 16), 256, 0, s>>>(ws, (int)nparts, per, gw);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 

@@ -173,7 +173,15 @@ class TreeLearn(nn.Module):
             output['semantic_prediction_logits'] = logits
             output['offset_predictions'] = offsets
             return output
-        backbone_feats = backbone_output.features[v2p_map]
+        from ..autograd import gather_rows
+        cache = getattr(v2p_map, "_tl_cache", None)                  # lives with the batch's v2p map: the argsort the gather's backward needs
+        if cache is None and v2p_map.is_cuda:
+            cache = {}
+            try:
+                v2p_map._tl_cache = cache
+            except AttributeError:
+                pass
+        backbone_feats = gather_rows(backbone_output.features, v2p_map, cache)
         if not (self.training and backbone_feats.dtype == torch.bfloat16 and os.environ.get("TL_HEAD_FP32") != "1"):
             backbone_feats = backbone_feats.float()
         # mixed-precision TRAINING keeps the heads in bf16 like the backbone (the reference's autocast runs their nn.Linear layers in

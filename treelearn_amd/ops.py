@@ -32,6 +32,21 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+def pack_weight_dgrad(w_ref: torch.Tensor, dtype: torch.dtype, flip: bool) -> torch.Tensor:
+    """Reference conv weight [Cout,k,k,k,Cin] -> the [K, Cin, Cout] weights of the layer's input-gradient conv (W[k]^T, taps flipped
+    for SubM), in `dtype`: one kernel instead of reshape / permute / flip / contiguous / cast."""
+    L = _hip.lib()
+    w = w_ref.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    _hip.require_cuda(w, "weight")
+    co, ci = w.shape[0], w.shape[-1]
+    K = w.numel() // (co * ci)
+    out = torch.empty((K, ci, co), dtype=dtype, device=w.device)
+    _hip.check(L.tl_pack_weight_dgrad(_hip.ptr(w), co, K, ci, int(bool(flip)), _hip.ptr(out), _hip.dtype_code(dtype), _hip.stream()), "tl_pack_weight_dgrad")
+    return out
+
+
 def _check_table(table, K, n_out, device):
     """The C ABI takes the rulebook as a bare pointer: a table of the wrong level (too few columns) would be read out of bounds on the
     device, so its shape is checked here."""
@@ -221,13 +236,16 @@ def bn_train_finish(segments, n, gamma, beta, eps, momentum, running_mean=None, 
     return st
 
 
-def bn_train_bwd_from_parts(x, g, st, parts, nparts, dx_add=None):
+def bn_train_bwd_from_parts(x, g, st, parts, nparts, dx_add=None, dx=None, dgb=None):
     """(dx, dgamma, dbeta) from an already masked g and the conv epilogue's partial sums of g and g * xhat (tl_bn_train_bwd_from_parts);
-    None if the views do not allow the vector kernel."""
+    None if the views do not allow the vector kernel.  x, g, st, dx_add, dx (out) and dgb (out, [2, C]) may be column slices of wider
+    tensors: a layer whose input gradient is computed in channel slices runs this once per slice."""
     L = _hip.lib()
     n, C = x.shape
-    dx = torch.empty((n, C), dtype=x.dtype, device=x.device)
-    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    if dx is None:
+        dx = torch.empty((n, C), dtype=x.dtype, device=x.device)
+    if dgb is None:
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
     if dx_add is not None and (dx_add.shape != x.shape or dx_add.dtype != x.dtype or dx_add.stride(1) != 1):
         raise ValueError("dx_add must match x in shape and dtype")
     rc = L.tl_bn_train_bwd_from_parts(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(g), g.stride(0), _hip.dtype_code(g.dtype), n, C,
@@ -266,3 +284,22 @@ def bn_train_bwd(x, dy, st, relu, dx_add=None):
                                  _hip.ptr(dgb[0]), _hip.ptr(dgb[1]), _hip.ptr(dx), dx.stride(0), _hip.ptr(dx_add),
                                  dx_add.stride(0) if dx_add is not None else 0, _hip.stream()), "tl_bn_train_bwd")
     return dx, dgb[0], dgb[1]
+
+
+def gather_rows(x, idx):
+    """x[idx] (tl_gather_rows): x [n, C] f32 / bf16 with 16-B rows, idx i64[N]."""
+    L = _hip.lib()
+    _hip.require_cuda(x, "x")
+    out = torch.empty((idx.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    _hip.check(L.tl_gather_rows(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), x.shape[1], x.shape[0], _hip.ptr(idx), idx.shape[0], _hip.ptr(out),
+                                out.stride(0), _hip.stream()), "tl_gather_rows")
+    return out
+
+
+def scatter_add_rows(g, order, sorted_idx, n_rows):
+    """out[v] = sum of g[p] over idx[p] == v in ascending p (tl_scatter_add_rows); order / sorted_idx = stable argsort of idx / idx[order]."""
+    L = _hip.lib()
+    out = torch.empty((n_rows, g.shape[1]), dtype=g.dtype, device=g.device)
+    _hip.check(L.tl_scatter_add_rows(_hip.ptr(g), g.stride(0), _hip.dtype_code(g.dtype), g.shape[1], _hip.ptr(order), _hip.ptr(sorted_idx), g.shape[0], n_rows,
+                                     _hip.ptr(out), out.stride(0), _hip.stream()), "tl_scatter_add_rows")
+    return out
