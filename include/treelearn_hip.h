@@ -220,6 +220,10 @@ int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_fr
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout);
 int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out,
                   int64_t n_in, int K, int Cin, int Cout, float* gw, float* ws, tl_stream_t stream);
+/* the same with gw written in the reference parameter layout f32[Cout][K][Cin] (= spconv `.weight` [Cout,k,k,k,Cin]: the `.grad` of the
+ * module parameter, no transposing copy afterwards); Cin % 4 == 0 */
+int tl_conv_wgrad_ref(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out,
+                      int64_t n_in, int K, int Cin, int Cout, float* gw, float* ws, tl_stream_t stream);
 
 /* ------------------------------------------------------------------ per-point heads
  * Replaces forward_head (tree_learn.py:97-103): features[v2p] gather, output_layer BN+ReLU

@@ -829,7 +829,7 @@ def test_inverse_conv_one_hot_form(cin, cout, n_out):
                                                (96, 96, 27, 120000), (192, 96, 27, 100100),       # big levels: the dense-over-taps form (tl_wgrad_dense.hip)
                                                (32, 2, 1, 50000), (32, 3, 1, 70001), (64, 4, 1, 3000),     # the heads' output Linears (tl_linear_small.hip)
                                                (32, 32, 1, 100003), (64, 32, 1, 70000), (128, 64, 1, 40001), (192, 96, 1, 33000), (256, 128, 1, 31000),   # tl_wgrad_rows.hip
-                                               (32, 32, 27, 70001), (64, 32, 27, 65000), (64, 64, 27, 99999), (128, 64, 27, 61000),
+                                               (4, 32, 27, 50001), (128, 128, 27, 60500), (256, 128, 27, 60100), (32, 32, 27, 70001), (64, 32, 27, 65000), (64, 64, 27, 99999), (128, 64, 27, 61000),
                                                (96, 96, 27, 50000), (192, 96, 27, 40000)])        # multiples of 96 below the dense form's row threshold: 96 x 96 pair-list blocks
 def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     """tl_conv_wgrad (present pairs only, fp32 MFMA, deterministic) vs gather + matmul in float64."""
@@ -860,6 +860,9 @@ def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     e = ops.conv_wgrad(xb.float(), gb.float(), tab, n_out, K)
     assert torch.equal(c, c2)
     assert rel_err(c.cpu().numpy(), e.cpu().numpy()) < 2e-5
+    if cin % 4 == 0:                                                                 # the parameter's own layout [Cout, K, Cin] straight from the reduction
+        assert torch.equal(ops.conv_wgrad(xb, gb, tab, n_out, K, ref_layout=True), c.permute(1, 0, 2).contiguous())
+        assert torch.equal(ops.conv_wgrad(wide[:, 8:], torch.from_numpy(g).to(d), tab, n_out, K, ref_layout=True), a.permute(1, 0, 2).contiguous())
 
 
 def test_compact_rulebook_equals_table():

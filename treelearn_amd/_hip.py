@@ -81,6 +81,7 @@ PROTOTYPES = {
     "tl_pack_weight_dgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_conv_wgrad_ws_floats": (_i64, [_i64, _i32, _i32, _i32]),
     "tl_conv_wgrad": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "tl_conv_wgrad_ref": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "tl_head_mlp": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_affine_relu": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "tl_bn_ws_doubles": (_i64, [_i64, _i32]),

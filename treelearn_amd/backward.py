@@ -38,6 +38,15 @@ def _side_stream(device):
     return st
 
 
+def _wgrad_param(x, grad_out, ref, K, weight):
+    """Weight gradient in the parameter's own layout and dtype ([Cout, k, k, k, Cin]; tl_conv_wgrad_ref: no transposing copy)."""
+    gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K, ref_layout=True)
+    if gw.shape[0] != weight.shape[0]:                                      # Cin % 4 != 0: [K, Cout, Cin] came back
+        gw = gw.permute(1, 0, 2)
+    gw = gw.reshape(weight.shape)
+    return gw if gw.dtype == weight.dtype else gw.to(weight.dtype)
+
+
 def _dgrad_weight(weight, ref, dtype):
     """[K]["Cout" = Cin]["Cin" = Cout] weights of the input-gradient conv: W[k]^T, taps flipped for SubM."""
     return ops.pack_weight_dgrad(weight, dtype, ref.flip)
@@ -58,8 +67,7 @@ def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, g
         side = _side_stream(grad_out.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            gw = ops.conv_wgrad(a, grad_out, ref.table, ref.n_out, K)
-            gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+            gw = _wgrad_param(a, grad_out, ref, K, weight)
         gw.record_stream(cur)
     wt = _dgrad_weight(weight, ref, grad_out.dtype)
     # the transposed conv is computed in column slices when it has > 224 output channels (the MFMA kernels' limit) and for the
@@ -92,8 +100,7 @@ def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, g
             ops.conv_fwd(grad_out, wsl, ref.t_table, ref.n_in, out=ga[:, s0:s0 + w_], one_hot=ref.t_one_hot)
         res = ops.bn_train_bwd(x, ga, st, relu, dx_add=gskip)
     if need_gw and not overlap:
-        gw = ops.conv_wgrad(a, grad_out, ref.table, ref.n_out, K)
-        gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+        gw = _wgrad_param(a, grad_out, ref, K, weight)
     if overlap:
         cur.wait_stream(side)
     return res[0], res[1], res[2], gw
@@ -113,8 +120,7 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
         side = _side_stream(grad_out.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K)
-            gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+            gw = _wgrad_param(x, grad_out, ref, K, weight)
         gw.record_stream(cur)
     if need_gx:
         wt = _dgrad_weight(weight, ref, grad_out.dtype)                    # kernel layout [K]["Cout"=Cin]["Cin"=Cout] = W[k]^T (taps flipped for SubM)
@@ -128,8 +134,7 @@ def conv_backward(x, weight, ref: TableRef, grad_out, need_gx, need_gw):
             for s in range(0, ci, step):
                 ops.conv_fwd(grad_out, wt[:, s:s + step].contiguous(), ref.t_table, ref.n_in, out=gx[:, s:s + step], one_hot=ref.t_one_hot)
     if need_gw and not overlap:
-        gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K)               # [K, Cout, Cin] fp32, present pairs only
-        gw = gw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+        gw = _wgrad_param(x, grad_out, ref, K, weight)
     if overlap:
         cur.wait_stream(side)
     return gx, gw

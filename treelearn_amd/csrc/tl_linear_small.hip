@@ -10,7 +10,7 @@
 //                                                                                       tl_launch_wgrad_reduce: deterministic
 #include "tl_conv_internal.h"
 
-int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s);   // tl_wgrad_dense.hip
+int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K = 1, int Cout = 0, int Cin = 0, int ref_layout = 0);   // tl_wgrad_dense.hip
 
 namespace {
 

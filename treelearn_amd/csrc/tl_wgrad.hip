@@ -504,12 +504,15 @@ static int g_wgrad_bf16_mfma = 1;          // developer A/B (tl_dev_wgrad_mode):
 // tl_wgrad_dense.hip: the dense-over-taps form of the 27-tap convs of the big levels
 int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout);
 int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
-                          int Cout, float* gw, float* ws, hipStream_t s);
-int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s);
+                          int Cout, float* gw, float* ws, hipStream_t s, int ref_layout);
+int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K = 1, int Cout = 0, int Cin = 0, int ref_layout = 0);
 // tl_linear_small.hip: K = 1 with <= 4 output channels (the heads' output Linears)
 // tl_wgrad_rows.hip: K = 1 (1x1 convs, the heads' hidden Linears) as a row-streaming GEMM
 int tl_wgrad_rows_parts(int64_t n, int Cin, int Cout);
 int tl_launch_wgrad_rows(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, int64_t n, int Cin, int Cout, float* gw, float* ws, hipStream_t s);
+int tl_wgrad_in4_parts(int64_t n, int K, int Cin, int Cout);
+int tl_launch_wgrad_in4(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n, int64_t n_in, float* gw, float* ws,
+                        hipStream_t s, int ref_layout);
 int64_t tl_wgrad_tinycout_parts(int64_t n);
 int tl_launch_wgrad_tinycout(const void* x, int64_t x_ld, const void* g, int64_t g_ld, int dtype, int64_t n, int Cin, int Cout, float* gw, float* ws, hipStream_t s);
 
@@ -529,11 +532,12 @@ int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout) {
   if (dense > nparts) nparts = dense;
   if (K == 1 && Cout <= 4 && tl_wgrad_tinycout_parts(n_out) > nparts) nparts = tl_wgrad_tinycout_parts(n_out);
   if (K == 1 && tl_wgrad_rows_parts(n_out, Cin, Cout) > nparts) nparts = tl_wgrad_rows_parts(n_out, Cin, Cout);
+  if (tl_wgrad_in4_parts(n_out, K, Cin, Cout) > nparts) nparts = tl_wgrad_in4_parts(n_out, K, Cin, Cout);
   return nparts * K * Cout * Cin;
 }
 
-int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
-                  int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
+static int wgrad_impl(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
+                      int Cin, int Cout, float* gw, float* ws, tl_stream_t stream, int ref_layout) {
   if (!x || !gout || !gw || !ws || n_out <= 0 || n_in <= 0 || K <= 0 || Cin <= 0 || Cout <= 0 || x_ld < Cin || g_ld < Cout) return TL_ERR_ARG;
   if (!table && K != 1) return TL_ERR_ARG;
   if (dtype != TL_F32 && dtype != TL_BF16) return TL_ERR_ARG;
@@ -548,12 +552,16 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
     const int rc = tl_launch_wgrad_tinycout(x, x_ld, gout, g_ld, dtype, n_out, Cin, Cout, gw, ws, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
+  if (dtype == TL_BF16 && K == 27 && Cin == 4 && Cout == 32 && table) {
+    const int rc = tl_launch_wgrad_in4((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, table, n_out, n_in, gw, ws, s, ref_layout);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
   if (bf16_mfma && K == 1 && !table && n_in == n_out) {
     const int rc = tl_launch_wgrad_rows((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, n_out, Cin, Cout, gw, ws, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (bf16_mfma && table) {
-    const int rc = tl_launch_wgrad_dense((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, table, n_out, n_in, K, Cin, Cout, gw, ws, s);
+    const int rc = tl_launch_wgrad_dense((const uint16_t*)x, x_ld, (const uint16_t*)gout, g_ld, table, n_out, n_in, K, Cin, Cout, gw, ws, s, ref_layout);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (bf16_mfma) {
@@ -618,10 +626,21 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
   }
   const int64_t per = (int64_t)K * Cout * Cin;
   const int64_t nparts = bf16_mfma ? nchunks_used : nchunks * kWaves;
-  if (per % 4 == 0 && ((uintptr_t)ws) % 16 == 0 && ((uintptr_t)gw) % 16 == 0) return tl_launch_wgrad_reduce(ws, nparts, per, gw, s);
+  if (per % 4 == 0 && Cin % 4 == 0 && ((uintptr_t)ws) % 16 == 0 && ((uintptr_t)gw) % 16 == 0) return tl_launch_wgrad_reduce(ws, nparts, per, gw, s, K, Cout, Cin, ref_layout);
+  if (ref_layout && K > 1) return TL_ERR_UNSUPPORTED;
   k_wgrad_reduce<<<tl_grid(per, 256), 256, 0, s>>>(ws, nparts, per, gw);
   TL_CHECK_LAUNCH();
   return TL_OK;
+}
+
+int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
+                  int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
+  return wgrad_impl(x, x_ld, gout, g_ld, dtype, table, n_out, n_in, K, Cin, Cout, gw, ws, stream, 0);
+}
+
+int tl_conv_wgrad_ref(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
+                      int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
+  return wgrad_impl(x, x_ld, gout, g_ld, dtype, table, n_out, n_in, K, Cin, Cout, gw, ws, stream, 1);
 }
 
 }  // extern "C"

@@ -213,7 +213,8 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense(const uint16_t* __restr
 // 8 loads, all in flight together), the sixteen lane sums are added in lane order through LDS: deterministic, and the partials -- just
 // written by the weight-gradient kernel -- stream out of L2 / Infinity Cache with thousands of loads in flight instead of one chain
 // per element.
-__global__ void __launch_bounds__(256) k_wgrad_reduce_par(const float* __restrict__ ws, int nparts, int64_t per, float* __restrict__ gw) {
+// KR > 0: gw is written in the REFERENCE parameter layout [Cout][K][Cin] (ws / the default output are [K][Cout][Cin]); Cin % 4 == 0
+__global__ void __launch_bounds__(256) k_wgrad_reduce_par(const float* __restrict__ ws, int nparts, int64_t per, float* __restrict__ gw, int KR, int CoutR, int CinR) {
   __shared__ f32x4 red[16][16];
   const int e = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int64_t v = (int64_t)blockIdx.x * 16 + e, stride = per / 4;
@@ -234,7 +235,12 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_par(const float* __restric
     f32x4 a = red[0][e];
 #pragma unroll
     for (int l = 1; l < 16; ++l) a += red[l][e];
-    reinterpret_cast<f32x4*>(gw)[v] = a;
+    int64_t o = v * 4;
+    if (KR > 0) {
+      const int ci = (int)(o % CinR); const int64_t r = o / CinR; const int co = (int)(r % CoutR); const int k = (int)(r / CoutR);
+      o = ((int64_t)co * KR + k) * CinR + ci;
+    }
+    *reinterpret_cast<f32x4*>(gw + o) = a;
   }
 }
 
@@ -258,8 +264,9 @@ int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, con
 }  // namespace
 
 // shared with tl_wgrad.hip: gw = ordered sum of `nparts` partial tile sets of `per` floats (per % 4 == 0, 16-B aligned)
-int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s) {
-  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 16), 256, 0, s>>>(ws, (int)nparts, per, gw);
+int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K, int Cout, int Cin, int ref_layout) {
+  const bool remap = ref_layout && K > 1 && Cin % 4 == 0;
+  k_wgrad_reduce_par<<<(unsigned)tl_cdiv(per / 4, 16), 256, 0, s>>>(ws, (int)nparts, per, gw, remap ? K : 0, Cout, Cin);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -276,12 +283,14 @@ int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout) {
     case 128064: return 40;                              // 54 jobs: 6 workgroups of 9 waves per slot
     case 96096: return 40;                               // 81 jobs (27 taps x 3 slices of 32 channels): 6 workgroups per slot
     case 192096: return 16;                              // 162 jobs: 12 workgroups per slot
+    case 128128: return 32;                              // 108 jobs (27 taps x 4 slices): 8 workgroups per slot
+    case 256128: return 16;                              // 216 jobs: 16 workgroups per slot
   }
   return 0;
 }
 
 int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
-                          int Cout, float* gw, float* ws, hipStream_t s) {
+                          int Cout, float* gw, float* ws, hipStream_t s, int ref_layout) {
   const int gx = tl_wgrad_dense_slots(n_out, K, Cin, Cout);
   if (!gx || !table) return TL_ERR_UNSUPPORTED;
   int rc = TL_ERR_UNSUPPORTED;
@@ -292,8 +301,10 @@ int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, in
     case 128064: rc = launch<2, 2, 1, 4, 9>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 2, gx, ws, s); break;
     case 96096: rc = launch<3, 1, 2, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 3, gx, ws, s); break;
     case 192096: rc = launch<3, 1, 2, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 6, gx, ws, s); break;
+    case 128128: rc = launch<4, 1, 1, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 4, gx, ws, s); break;
+    case 256128: rc = launch<4, 1, 1, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 8, gx, ws, s); break;
   }
   if (rc != TL_OK) return rc;
   const int64_t per = (int64_t)K * Cout * Cin;
-  return tl_launch_wgrad_reduce(ws, gx, per, gw, s);
+  return tl_launch_wgrad_reduce(ws, gx, per, gw, s, K, Cout, Cin, ref_layout);
 }

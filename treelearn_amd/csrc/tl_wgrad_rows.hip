@@ -10,7 +10,7 @@
 #include "tl_conv_internal.h"
 #include <atomic>
 
-int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s);   // tl_wgrad_dense.hip
+int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K = 1, int Cout = 0, int Cin = 0, int ref_layout = 0);   // tl_wgrad_dense.hip
 
 namespace {
 
@@ -150,6 +150,118 @@ __global__ void __launch_bounds__(kRW * 64) k_wgrad_rows(const uint16_t* __restr
   }
 }
 
+// The 4-channel input conv (tree_learn.py:37-39 `input_conv`, K = 27, Cin = 4, Cout = 32): gW[k][co][ci] = sum_o gout[o][co] * x[nbr[k][o]][ci].
+// With (tap, channel) = 108 (padded to 128) as ONE "input channel" axis this is the same row-streaming GEMM: per 16-row step a wave
+// gathers the 27 neighbours' 8-byte rows (absent = index -1 = out of range = zeros) into a [16][256 B] tile next to the gout tile and
+// runs four MFMAs.  The fp32-MFMA pair kernel took 1.3 ms for this layer; this form is bound by the 108 B / voxel rulebook read.
+__global__ void __launch_bounds__(kRW * 64) k_wgrad_in4(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
+                                                       const int32_t* __restrict__ table, int64_t n, int64_t n_in, float* __restrict__ ws) {
+  constexpr int K = 27, PG = 64, PX = 256, ROWS = 16, NI = (ROWS * K + 63) / 64, PD = 2;
+  constexpr int TILE = ROWS * (PG + PX);
+  __shared__ __attribute__((aligned(16))) char smem[kRW * 2 * TILE];
+  typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* Gw = smem + wv * (2 * TILE);
+  char* Xw = Gw + 2 * ROWS * PG;
+  for (int e = lane; e < 2 * ROWS * PX / 16; e += 64) *reinterpret_cast<u32x4*>(Xw + e * 16) = u32x4{0u, 0u, 0u, 0u};     // the 20 padding channels stay zero
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, (n_in - 1) * x_ld * 2 + 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n * g_ld * 2), 0x00020000);
+  const unsigned x_ld_b = (unsigned)(x_ld * 2), g_ld_b = (unsigned)(g_ld * 2);
+  const int fi = lane & 31, fh = lane >> 5, ti = lane & 15, tg = (lane >> 4) & 1;
+  const int prow = 8 * fh + (ti >> 2);
+  const int ga = prow * PG + ((2 * tg + ((ti & 3) >> 1)) << 4) + 8 * (ti & 1);
+  int xa[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) xa[b] = prow * PX + (((4 * b + 2 * tg + ((ti & 3) >> 1)) ^ swz<PX>(prow)) << 4) + 8 * (ti & 1);
+  int xr[NI], xk[NI], xl[NI];                                   // this lane's (row, tap) items of a step and their place in the tile
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int q = lane + 64 * i;
+    xr[i] = q / K; xk[i] = q % K;
+    xl[i] = xr[i] * PX + ((((xk[i] >> 1)) ^ swz<PX>(xr[i])) << 4) + 8 * (xk[i] & 1);
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+  const int64_t nsteps = (n + ROWS - 1) / ROWS;
+  const int64_t first = (int64_t)blockIdx.x * kRW + wv, stride = (int64_t)gridDim.x * kRW;
+  auto idx_load = [&](int64_t st, int (&dst)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int64_t row = st * ROWS + xr[i];
+      dst[i] = (st < nsteps && row < n && lane + 64 * i < ROWS * K) ? table[(int64_t)xk[i] * n + row] : -1;
+    }
+  };
+  auto issue = [&](int64_t st, const int (&idx)[NI], u32x4& gq, u32x2_ (&xq)[NI]) __attribute__((always_inline)) {
+    const int64_t row = st * ROWS + (lane >> 2);
+    const unsigned off = (st < nsteps && row < n) ? (unsigned)row * g_ld_b + (unsigned)((lane & 3) * 16) : 0xFFFFFFFFu;
+    gq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 0));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) xq[i] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(rx, (int)((unsigned)idx[i] * x_ld_b), 0, 0));
+  };
+  int ia[PD][NI];
+  u32x4 gb[PD]; u32x2_ xb[PD][NI];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) idx_load(first + d * stride, ia[d]);
+#pragma unroll
+  for (int d = 0; d < PD; ++d) { issue(first + d * stride, ia[d], gb[d], xb[d]); idx_load(first + (d + PD) * stride, ia[d]); }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t s0 = first; s0 < nsteps; s0 += PD * stride) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      char* Gc = Gw + (d & 1) * (ROWS * PG);
+      char* Xc = Xw + (d & 1) * (ROWS * PX);
+      *reinterpret_cast<u32x4*>(Gc + (lane >> 2) * PG + ((lane & 3) << 4)) = gb[d];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (ROWS * K % 64 == 0 || lane + 64 * i < ROWS * K) *reinterpret_cast<u32x2_*>(Xc + xl[i]) = xb[d][i];
+      issue(s0 + (d + PD) * stride, ia[d], gb[d], xb[d]);           // entries requested one round earlier
+      idx_load(s0 + (d + 2 * PD) * stride, ia[d]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      u32x4 A, B[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Gc + 4 * q * PG + ga)));
+        A[2 * q] = v[0]; A[2 * q + 1] = v[1];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Xc + 4 * q * PX + xa[b])));
+          B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
+        }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B[b]), acc[b], 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // waves added in wave order -> ws[blockIdx.x][k][co][ci], (k, ci) = the MFMA column n = 4 k + ci
+  __syncthreads();
+  float (*Rs)[129] = reinterpret_cast<float (*)[129]>(smem);
+  float* wp = ws + (int64_t)blockIdx.x * (K * 32 * 4);
+  for (int w = 0; w < kRW; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * fh, nn = b * 32 + fi;
+          float v = acc[b][r];
+          if (w > 0) v += Rs[co][nn];
+          if (w < kRW - 1) Rs[co][nn] = v;
+          else if (nn < 4 * K) wp[((nn >> 2) * 32 + co) * 4 + (nn & 3)] = v;
+        }
+    }
+    __syncthreads();
+  }
+}
+
 template <int NBO, int NBIW, int KS, int PD>
 int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, int64_t n, int Cin, int gx, float* ws, hipStream_t s) {
   const size_t lds = (size_t)kRW * 2 * (16 * KS) * (NBO * 64 + NBIW * 64);
@@ -191,4 +303,20 @@ int tl_launch_wgrad_rows(const uint16_t* x, int64_t x_ld, const uint16_t* g, int
   }
   if (rc != TL_OK) return rc;
   return tl_launch_wgrad_reduce(ws, gx, (int64_t)Cout * Cin, gw, s);
+}
+
+// the 4 -> 32 input conv (K = 27): partial tile sets / launch
+int tl_wgrad_in4_parts(int64_t n, int K, int Cin, int Cout) {
+  if (!g_wgrad_rows || K != 27 || Cin != 4 || Cout != 32 || n < 30000) return 0;
+  const int64_t cap = (n / 16 + 7) / 8;
+  return (int)(512 < cap ? 512 : cap);
+}
+
+int tl_launch_wgrad_in4(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n, int64_t n_in, float* gw, float* ws,
+                        hipStream_t s, int ref_layout) {
+  const int gx = tl_wgrad_in4_parts(n, 27, 4, 32);
+  if (!gx || !table || x_ld % 4 || ((uintptr_t)x) % 8 || g_ld % 8 || ((uintptr_t)g) % 16 || (n_in - 1) * x_ld * 2 + 8 > 0x7FFF0000ll) return TL_ERR_UNSUPPORTED;
+  k_wgrad_in4<<<gx, kRW * 64, 0, s>>>(x, x_ld, g, g_ld, table, n, n_in, ws);
+  if (hipGetLastError() != hipSuccess) return TL_ERR_LAUNCH;
+  return tl_launch_wgrad_reduce(ws, gx, 27 * 32 * 4, gw, s, 27, 32, 4, ref_layout);
 }

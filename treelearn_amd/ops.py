@@ -143,8 +143,9 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     return out
 
 
-def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: int) -> torch.Tensor:
-    """gW[k][co][ci] = sum_o grad_out[o][co] * x[table[k][o]][ci] (fp32, present entries only) -> [K, Cout, Cin]."""
+def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: int, ref_layout: bool = False) -> torch.Tensor:
+    """gW[k][co][ci] = sum_o grad_out[o][co] * x[table[k][o]][ci] (fp32, present entries only) -> [K, Cout, Cin]; with ref_layout the
+    result comes back as [Cout, K, Cin], the layout of the module parameter (spconv `.weight` [Cout,k,k,k,Cin])."""
     L = _hip.lib()
     if x.dtype == torch.bfloat16 and grad_out.dtype == torch.bfloat16:
         g = grad_out                                     # mixed precision: the kernel widens bf16 in registers
@@ -158,9 +159,10 @@ def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: in
     if g.shape[0] != n_out:
         raise ValueError(f"grad_out has {g.shape[0]} rows, the rulebook {n_out}")
     _check_table(table, K, n_out, x.device)
-    gw = torch.empty((K, co, ci), dtype=torch.float32, device=x.device)
+    ref_layout = bool(ref_layout) and ci % 4 == 0
+    gw = torch.empty((co, K, ci) if ref_layout else (K, co, ci), dtype=torch.float32, device=x.device)
     ws = torch.empty(int(L.tl_conv_wgrad_ws_floats(n_out, K, ci, co)), dtype=torch.float32, device=x.device)
-    _hip.check(L.tl_conv_wgrad(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(table) if table is not None else None, n_out, x.shape[0],
+    _hip.check((L.tl_conv_wgrad_ref if ref_layout else L.tl_conv_wgrad)(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(table) if table is not None else None, n_out, x.shape[0],
                                K, ci, co, _hip.ptr(gw), _hip.ptr(ws), _hip.stream()), "tl_conv_wgrad")
     return gw
 
