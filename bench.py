@@ -241,6 +241,57 @@ def training_step_bench(args, rank, world, dist):
                 cpu_baseline=None)
 
 
+def forward_block(workload, dtype_name, steps, warmup, nfl):
+    """A compact forward measurement of another BASELINE config inside the default run (config 5: the 0.05 m stress tile), so that the
+    driver's one line carries it: same step definition as the headline (model(batch, return_loss=False), inputs resident in HBM, `nfl`
+    independent tiles in flight), its own conv-family roofline from a live HIP-event pass."""
+    from treelearn_amd import ops
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
+    cfg = CONFIGS[workload]
+    batch = make_batch([make_tile(**cfg, seed=0)])
+    n_pts = batch["coords"].shape[0]
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000] if cfg["voxel"] >= 0.1 else None, voxel_size=cfg["voxel"], compute_dtype=dtype)
+    model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
+    model = model.cuda().eval()
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def step():
+        with torch.no_grad():
+            return model(gb, return_loss=False)
+    streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else []
+
+    def run(k):
+        if not streams:
+            for _ in range(k): step()
+            return
+        cur = torch.cuda.current_stream()
+        for st in streams: st.wait_stream(cur)
+        for i in range(k):
+            with torch.cuda.stream(streams[i % nfl]): step()
+        for st in streams: cur.wait_stream(st)
+    step(); torch.cuda.synchronize()
+    run(max(nfl, 1)); torch.cuda.synchronize()
+    run(max(warmup, 1)); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(steps); torch.cuda.synchronize(); sec = (time.perf_counter() - t0) / steps
+    ops.PROFILE = []; step(); torch.cuda.synchronize(); ops.PROFILE = []
+    step(); torch.cuda.synchronize()
+    recs = ops.PROFILE; ops.PROFILE = None
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+    fl = by = 0.0
+    for _, _, m in recs:
+        f, b, _ = conv_work(m); fl += f; by += b
+    ach = by / (ms * 1e-3) / 1e9
+    out = dict(value=n_pts / sec / 1e6, unit="Mpoints/s", ms_per_step=sec * 1e3, steps=steps, warmup=warmup, dtype=dtype_name, tiles_in_flight=nfl,
+               workload=f"{workload}: single {cfg['extent']:.0f}x{cfg['extent']:.0f} m tile, voxel {cfg['voxel']} m, {n_pts} points, {model.num_blocks}-level 32-ch sparse U-Net fwd",
+               roofline=dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, launches_per_step=len(recs),
+                             conv_ms_per_step=ms, algorithmic_gb_per_step=by / 1e9, mfma_tflops=fl / (ms * 1e-3) / 1e12))
+    del model, gb
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -282,6 +333,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the config-3 training step and the config-5 tile that ride along in the default line")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
     ap.add_argument("--tiles-in-flight", type=int, default=3, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
     ap.add_argument("--layer-table", default=None, help="write the per-launch table of the conv event pass (time, work, both roofs) to this file")
@@ -448,6 +500,7 @@ def main():
             roof["traffic"] = tr[0]["hbm_gb_per_step"]
             roof["traffic_unit"] = "GB per step (sum over the conv launches; PMC 2*FETCH_SIZE+WRITE_SIZE)"
             roof["traffic_source"] = os.path.relpath(tr[1], REPO)
+            roof["traffic_measured_in_run"] = False          # PMC passes are collected offline (rocprofv3 --pmc, profiles/*/traffic.json), never in this run
             # the north-star's "HBM bandwidth on the rulebook gather": PMC bytes of the conv kernels / their measured time
             roof["traffic_gbs"] = roof["traffic"] / (tot_ms * 1e-3)
             roof["traffic_frac_of_peak"] = roof["traffic_gbs"] / PEAK_HBM_GBS
@@ -481,6 +534,20 @@ def main():
                 torch.cuda.synchronize(); d32 = (time.perf_counter() - t1) / 5
             res["fp32_parity_mode"] = dict(value=n_pts / d32 / 1e6, unit="Mpoints/s", ms_per_step=d32 * 1e3)
             del m32
+        if world == 1 and args.workload == "config2" and not args.no_extra_workloads:
+            # BASELINE configs 3 and 5 ride along in the default line (each with its own ms_per_step / value / roofline), so the driver's
+            # one run carries them: the training step (config 3) and the 0.05 m stress tile (config 5)
+            import types
+            try:
+                ts = training_step_bench(types.SimpleNamespace(steps=5, warmup=2, dtype=args.dtype), 0, 1, None)
+                res["training_step"] = {k: ts[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
+            except Exception as e:                                      # noqa: BLE001
+                res["training_step"] = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
+            try:
+                res["config5"] = forward_block("config5", args.dtype, 5, 2, nfl)
+            except Exception as e:                                      # noqa: BLE001
+                res["config5"] = dict(error=f"{type(e).__name__}: {e}")
         if world == 1 and not args.no_power_probe:
             pw = power_probe(step)
             if pw:

@@ -186,6 +186,10 @@ typedef struct tl_conv_args {
    * red_part must hold tl_conv_red_parts(n_out) rows; *red_nparts (HOST, optional) receives the rows actually written.
    * Only the direct / stream kernel families carry these epilogues: other shapes return TL_ERR_UNSUPPORTED (nothing launched)
    * and the caller runs the separate passes (tl_bn_train_stats / tl_bn_train_bwd).  Deterministic. */
+  /* != 0: every element of `in` is 1 (the reference's default use_feats = False, use_coords = False feeds all-ones voxel features,
+   * tree_learn.py:129-167): out[o] = sum over the present taps of sum_c W[k][:][c].  Served without reading `in` when K = 27,
+   * Cout = 32, bf16 and table_compact is given; otherwise the flag is ignored (the general kernels read the ones). */
+  int32_t in_all_ones;
   int32_t epi_mode;
   double* red_part;
   int32_t* red_nparts;

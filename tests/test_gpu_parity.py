@@ -894,6 +894,32 @@ def test_compact_rulebook_equals_table():
         assert torch.equal(a, b)
 
 
+def test_input_conv_of_all_ones_by_presence_mask_table():
+    """tl_conv_args.in_all_ones (the reference's default use_feats = False, use_coords = False feeds ones, tree_learn.py:129-167): the
+    27-entry table indexed by the rulebook's presence mask equals the gather kernel on an all-ones input (fp32 sums in another order,
+    one bf16 rounding) and float64, with the BatchNorm + ReLU second view."""
+    from treelearn_amd import ops
+    from treelearn_amd.geometry import build_geometry
+    from treelearn_amd.synth import make_tile
+    t = make_tile(extent=16.0, voxel=0.1, n_trees=8, fill=0.10, seed=4)
+    pts = torch.from_numpy(t["points"]).cuda(); bid = torch.zeros(len(pts), dtype=torch.int64, device="cuda")
+    lv = build_geometry(pts, bid, 1, 0.1, 7, [500, 500, 1000]).levels[0]
+    assert getattr(lv.nbr, "_tl_compact", None) is not None
+    x = torch.ones(lv.n, 4, device="cuda", dtype=torch.bfloat16)
+    wr = torch.randn(32, 3, 3, 3, 4, device="cuda") * 0.2
+    w = ops.pack_weight(wr, torch.bfloat16)
+    sc = torch.rand(32, device="cuda") + 0.5; sh = torch.randn(32, device="cuda") * 0.2
+    o2a = torch.empty(lv.n, 32, device="cuda", dtype=torch.bfloat16); o2b = torch.empty_like(o2a)
+    a = ops.conv_fwd(x, w, lv.nbr, lv.n, out2=(o2a, sc, sh, True), all_ones=True)
+    b = ops.conv_fwd(x, w, lv.nbr, lv.n, out2=(o2b, sc, sh, True))
+    present = (lv.nbr >= 0).double().T                                       # [n, 27]
+    ref = present @ w.double().sum(-1)                                       # sum over taps of sum_c W[k][co][c]  -> [n, 32]
+    assert float((a.double() - ref).abs().max()) <= 8e-3 * float(ref.abs().max())
+    assert float((a.float() - b.float()).abs().max()) <= 8e-3 * float(ref.abs().max())
+    ref2 = torch.relu(ref * sc.double() + sh.double())
+    assert float((o2a.double() - ref2).abs().max()) <= 8e-3 * float(ref2.abs().max())
+
+
 @pytest.mark.parametrize("extent,shape", [(6.0, None), (21.0, [500, 500, 1000]), (9.3, None)])
 def test_pyramid_calls_equal_per_level_calls(extent, shape):
     """tl_pyramid_build + tl_rulebooks_build (what build_geometry uses: deep levels built by one workgroup / shared launches, one

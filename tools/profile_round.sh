@@ -4,7 +4,7 @@
 # time: cleaner per-kernel attribution; counters never combined with trace domains other than the kernel trace).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_${1:-r2}; mkdir -p $O
-Q="--no-cpu-baseline --no-fp32-mode --no-power-probe"
+Q="--no-cpu-baseline --no-fp32-mode --no-power-probe --no-extra-workloads"
 python bench.py > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
 python bench.py --tiles-in-flight 1 $Q > $O/bench_unprofiled_1_in_flight.json 2>> $O/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --steps 6 --warmup 2 $Q > $O/bench_line.json 2> $O/stats.err

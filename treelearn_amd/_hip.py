@@ -32,7 +32,7 @@ class ConvArgs(_c.Structure):
         ("out3", _vp), ("out3_ld", _i64), ("out3_scale", _vp), ("out3_shift", _vp), ("out3_relu", _i32),
         ("weight_frag", _vp), ("table_one_hot", _i32), ("table_compact", _vp),
         # training-mode epilogue reductions (include/treelearn_hip.h: TL_EPI_STATS / TL_EPI_BN_BWD)
-        ("epi_mode", _i32), ("red_part", _vp), ("red_nparts", _c.POINTER(_i32)),
+        ("in_all_ones", _i32), ("epi_mode", _i32), ("red_part", _vp), ("red_nparts", _c.POINTER(_i32)),
         ("bn_x", _vp), ("bn_x_ld", _i64), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_scale", _vp), ("bn_shift", _vp), ("bn_relu", _i32),
     ]
 

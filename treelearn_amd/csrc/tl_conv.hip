@@ -364,6 +364,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
                        (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));
+  if (a->in_all_ones && !train && a->dtype == TL_BF16 && out_vec && g_direct && ((uintptr_t)a->weight) % 2 == 0 && !a->residual) {
+    const int rc = tl_launch_conv_ones27(p, s);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
   if (a->dtype == TL_BF16 && a->Cin == 4 && a->Cout == 32 && g_direct && out_vec && ((uintptr_t)a->in) % 8 == 0 && ((uintptr_t)a->weight) % 16 == 0 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0))) {
     const int rc = tl_launch_conv_direct(p, TL_BF16, s);

@@ -381,6 +381,36 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
   }
 }
 
+// ------------------------------------------------------------------ the input conv of an all-ones input
+// With use_feats = False and use_coords = False (the reference's default flags: tree_learn.py:129-167 `voxelize` then feeds ones) every
+// voxel feature is 1, so out[o][co] = sum over the PRESENT taps k of S[k][co], S[k][co] = sum_c W[k][co][c]: no gather at all, just the
+// 27-bit presence mask of the column-form rulebook (4 B / voxel) and a 27 x 32 table in LDS.  Write-bound (the output views).
+// One thread = one row x 8 channels.
+__global__ void __launch_bounds__(256) k_conv_ones27(ConvP p) {
+  __shared__ __attribute__((aligned(16))) float S[27][32];
+  const uint16_t* w = (const uint16_t*)p.w;                                 // [27][32][Cin] bf16
+  for (int e = threadIdx.x; e < 27 * 32; e += 256) {
+    float t = 0.f;
+    for (int c = 0; c < p.Cin; ++c) t += bf16_lo((uint32_t)w[(int64_t)e * p.Cin + c]);
+    S[e >> 5][e & 31] = t;
+  }
+  __syncthreads();
+  const int32_t* mask = p.ctab + (int64_t)9 * p.n_out;
+  const int64_t total = p.n_out * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t row = t >> 2; const int c0 = (int)(t & 3) * 8;
+    uint32_t m = (uint32_t)mask[row];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    while (m) {
+      const int k = __builtin_ctz(m); m &= m - 1;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&S[k][c0]), b = *reinterpret_cast<const f32x4*>(&S[k][c0 + 4]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] += a[q]; v[q + 4] += b[q]; }
+    }
+    epi_views8<true>(p, row, c0, v);
+  }
+}
+
 int g_direct_walk = 0;
 
 template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false>
@@ -457,6 +487,14 @@ int dispatch(const ConvP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// all-ones input (tl_conv_args.in_all_ones): bf16, K = 27 with the column-form rulebook, Cout = 32
+int tl_launch_conv_ones27(const ConvP& p, hipStream_t s) {
+  if (p.K != 27 || p.Cout != 32 || !p.ctab || p.Cin <= 0 || p.Cin > 64 || p.in_scale || p.in_relu || p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
+  k_conv_ones27<<<tl_grid(p.n_out * 4, 256), 256, 0, s>>>(p);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
 
 #ifdef TL_DEV
 // developer hook (dev build only), not part of the C ABI: mode 0..99 = ablation variant of the 32->32 kernel, 1000 / 1001 = tile walk of every direct launch

@@ -289,6 +289,7 @@ int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   
 
 // tl_conv_direct.hip
 int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s);   // whole weight tensor resident in LDS, per-wave tiles
+int tl_launch_conv_ones27(const ConvP& p, hipStream_t s);               // every input element is 1: presence-mask table, no gather
 
 // tl_conv_stream.hip
 int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s);   // per-wave register gathers, weights streamed through LDS per tap

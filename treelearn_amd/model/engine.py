@@ -42,13 +42,13 @@ RAW = lambda buf=None: View(buf=buf)                                   # noqa: E
 ACT = lambda aff, buf=None: View(aff[0], aff[1], True, buf)            # noqa: E731
 
 
-def _conv_views(x, w, table, n, views, residual=None, one_hot=False):
+def _conv_views(x, w, table, n, views, residual=None, one_hot=False, all_ones=False):
     """Run one conv producing up to three views; returns the list of result tensors (same order)."""
     outs = [v.buf if v.buf is not None else torch.empty((n, w.shape[1]), dtype=x.dtype, device=x.device) for v in views]
     v0 = views[0]
     extra = [(o, v.scale, v.shift, v.relu) for o, v in zip(outs[1:], views[1:])]
     ops.conv_fwd(x, w, table, n, out=outs[0], residual=residual, out_scale=v0.scale, out_shift=v0.shift, out_relu=v0.relu,
-                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None, one_hot=one_hot)
+                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None, one_hot=one_hot, all_ones=all_ones)
     return outs
 
 
@@ -174,11 +174,13 @@ class InferencePlan:
         self.w2 = torch.cat([model.semantic_linear[3].weight.detach().float(), model.offset_linear[3].weight.detach().float()]).contiguous()
         self.b2 = torch.cat([model.semantic_linear[3].bias.detach().float(), model.offset_linear[3].bias.detach().float()]).contiguous()
 
-    def run(self, voxel_feats, geom: TileGeometry, want_backbone=True):
+    def run(self, voxel_feats, geom: TileGeometry, want_backbone=True, all_ones=False):
+        """`all_ones`: the caller built voxel_feats as ones (use_feats = False, use_coords = False): the input conv then needs no gather."""
         lv = geom.levels[0]
         vf = voxel_feats.to(self.dtype).contiguous()
         if self.preact:
-            x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)])
+            x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)],
+                                       all_ones=all_ones and os.environ.get("TL_NO_ONES_TABLE") != "1")
             (x,) = self.unet.run(x_raw, x_act, geom, 0, [RAW()])
         else:
             x = ops.conv_fwd(vf, self.w_in, lv.nbr, lv.n)

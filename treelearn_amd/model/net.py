@@ -159,7 +159,8 @@ class TreeLearn(nn.Module):
         main = torch.cuda.current_stream()
         main.wait_event(ev)
         with torch.no_grad():
-            bb, logits, offsets = self._plan.run(vfeats, geom, want_backbone=self.return_backbone_feats)
+            bb, logits, offsets = self._plan.run(vfeats, geom, want_backbone=self.return_backbone_feats,
+                                                 all_ones=not (self.use_coords or self.use_feats))
         for t in geom.tensors() + [vfeats]:                            # allocated on the side stream, consumed on this one
             t.record_stream(main)
         return dict(backbone_feats=bb, semantic_prediction_logits=logits, offset_predictions=offsets)
@@ -168,7 +169,8 @@ class TreeLearn(nn.Module):
         output = dict()
         if isinstance(backbone_output, tuple):                       # fused inference path
             vfeats, geom = backbone_output
-            bb, logits, offsets = self._plan.run(vfeats, geom, want_backbone=self.return_backbone_feats)
+            bb, logits, offsets = self._plan.run(vfeats, geom, want_backbone=self.return_backbone_feats,
+                                                 all_ones=not (self.use_coords or self.use_feats))
             output['backbone_feats'] = bb
             output['semantic_prediction_logits'] = logits
             output['offset_predictions'] = offsets
