@@ -279,6 +279,11 @@ int tl_bn_train_bwd_from_parts(const void* x, int64_t ld, int x_dtype, const voi
                                const float* rstd, const float* scale, const float* shift, const double* part, int64_t nparts, float* dgamma, float* dbeta,
                                void* dx, int64_t xld, const void* dx_add, int64_t dx_add_ld, tl_stream_t stream);
 
+/* out f32[n, Cout] = x[n, Cin] . W^T for Cout <= 8 (the output Linears of the two heads in training, blocks.py:8-26 `MLP`): x and W
+ * [Cout][Cin] in `dtype`, fp32 accumulation AND fp32 result -- under mixed precision the logits / offsets keep fp32 resolution. */
+int tl_linear_small_f32(const void* x, int64_t x_ld, int dtype, const void* w, int Cin, int Cout, int64_t n, float* out, int64_t out_ld,
+                        tl_stream_t stream);
+
 /* Voxel -> point feature gather and its gradient (tree_learn.py:98 `output.features[v2p_map]`; tools/training/train.py:40):
  *   tl_gather_rows     : out[p, :] = in[idx[p], :] for p < N (idx < 0 counts from the end like torch indexing; in [n_rows, C]);
  *   tl_scatter_add_rows: gin[v, :] = sum over the points p with idx[p] == v of g[p, :], added in ascending p in fp32; `order` i64[N] =

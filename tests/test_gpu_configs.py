@@ -283,6 +283,9 @@ def _batch_from(g, prefix="in_"):
     return b
 
 
+GRAD_TOL = 2e-4        # (measured 3.4e-5) every gradient tensor of the 7-level training step vs kink-pinned float64 autograd, max-norm relative (fp32 path)
+
+
 def test_config3_default_architecture_training_step_vs_reference(golden_dir):
     """The reference's default architecture (7 levels, 32 channels) in training mode on a batch of two crops: loss, BatchNorm
     statistics and gradients against the reference module tree (golden g12, tests/golden/make_golden.py:g12_train7).  The
@@ -302,37 +305,39 @@ def test_config3_default_architecture_training_step_vs_reference(golden_dir):
     assert float(loss) == pytest.approx(float(g["eval_loss"]), rel=REL_TOL)
     for k in ("semantic_prediction_logits", "offset_predictions"):
         assert rel_err(o[k].cpu().numpy(), g[f"eval_{k}"]) < REL_TOL, k
+    from treelearn_amd import autograd as ag
     model.train(); model.zero_grad()
-    loss, ld = model(batch, return_loss=True)
+    ag.RELU_MASK_SINK = {}
+    try:
+        loss, ld = model(batch, return_loss=True)
+        sink = ag.RELU_MASK_SINK
+    finally:
+        ag.RELU_MASK_SINK = None
     loss.backward()
     assert float(loss.detach()) == pytest.approx(float(g["train_loss"]), rel=REL_TOL)
     assert float(ld["offset_loss"].detach()) == pytest.approx(float(g["train_offset_loss"]), rel=REL_TOL)
     P = dict(model.named_parameters()); Bf = dict(model.named_buffers())
     names = [str(s) for s in g["grad_names"]]
     ours = np.array([float(P[n].grad.norm()) for n in names]); ref = g["grad_norms"]
-    # (1) against float64 autograd through the oracle (round-off-free second opinion): EVERY gradient tensor in full, per output
-    # channel.  A ReLU whose pre-activation lies within fp32 rounding of zero takes the other branch in float64 (about one
-    # activation in 10^6-10^7); at a level with 4-557 voxels that single row is a visible share of its channel's gradient
-    # (measured: channel 74 of a level-5 conv, 117 voxels, 11 % of the tensor's maximum), so up to two channels per tensor may
-    # deviate by more than 2e-2 of the tensor's maximum; such a flip at the 4-voxel level also perturbs everything upstream of it in
-    # the backward pass a little (measured medians up to 2.7e-3 on encoder gradients, whose path crosses levels 5-7), hence the 6e-3
-    # median bound there -- and the tight 1e-3 bound on the gradients that are NOT upstream of the deep levels (level-1 decoder, heads).
+    # (1) against float64 autograd through the oracle (round-off-free second opinion), KINK-PINNED: the HIP forward exports the
+    # branch every ReLU took (autograd.RELU_MASK_SINK) and the oracle multiplies by those masks instead of re-deciding the sign in
+    # float64 (oracle.model.train_step_grads(relu_masks=...)), so both differentiate the same piecewise-linear function -- a
+    # pre-activation within fp32 rounding of zero no longer flips (one row of the 117-voxel level is 11 % of a channel's gradient).
+    # EVERY one of the gradient tensors then agrees in max-norm.
+    mod_name = {m: n for n, m in model.named_modules()}
+    masks = {mod_name[m]: v.cpu() for m, v in sink.items()}
+    assert len(masks) == sum(isinstance(m, torch.nn.BatchNorm1d) for m in model.modules())        # every BatchNorm + ReLU ran on the HIP kernels
     _, g64 = om.train_step_grads(random_state_dict(cfg["seed"], **cfg["cfg"]), {k: batch[k] for k in batch}, cfg["voxel_size"],
-                                 cfg["cfg"]["num_blocks"], cfg["spatial_shape"])
-    flips = 0
+                                 cfg["cfg"]["num_blocks"], cfg["spatial_shape"], relu_masks=masks)
+    worst = (0.0, None)
     for n in names:
         b = g64[n].numpy().astype(np.float64)
         if np.abs(b).max() <= 1e-9 * ref.max():
             continue                                             # e.g. Linear biases in front of a BatchNorm: zero gradient
-        a = P[n].grad.cpu().numpy().astype(np.float64)
-        per_ch = np.abs(a - b).reshape(a.shape[0], -1).max(1) / np.abs(b).max()
-        bad = int((per_ch > 2e-2).sum())
-        assert bad <= 2 and np.median(per_ch) < 6e-3 and per_ch.max() < 0.5, (n, bad, float(np.median(per_ch)), float(per_ch.max()))
-        flips += bad
-    assert flips <= 12, flips
-    for n in names:
-        if n.startswith(("unet.blocks_tail.block1", "output_layer", "semantic_linear.3", "offset_linear.3", "semantic_linear.1", "offset_linear.1")):
-            assert rel_err(P[n].grad.cpu().numpy(), g64[n].numpy()) < 1e-3, n
+        e = rel_err(P[n].grad.cpu().numpy(), b)
+        worst = max(worst, (e, n))
+        assert e < GRAD_TOL, (n, e)
+    print("kink-pinned float64 check: worst tensor", worst)
     # (2) against the reference-generated golden.  Its deep-level gradients sit a systematic 1-2 % (max-norm) away from float64
     # autograd of the same function (tests/test_oracle_golden.py::test_g12_gradients_float64_second_opinion: the dense stand-in's
     # conv3d backward on the CPU), so the bound here is 2.5e-2; loss, statistics and shallow gradients agree far tighter
@@ -354,6 +359,57 @@ def test_config3_default_architecture_training_step_vs_reference(golden_dir):
     assert rel_err(checks["grad_sem3"].cpu().numpy(), g["grad_sem3"]) < 1e-4 and rel_err(checks["grad_input_conv"].cpu().numpy(), g["grad_input_conv"]) < 5e-3
     np.testing.assert_allclose(model.output_layer[0].running_mean.cpu().numpy(), g["bn_out_running_mean_after"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(Bf["unet.u.u.u.u.blocks.block1.conv_branch.3.running_var"].cpu().numpy(), g["bn_l5_running_var_after"], rtol=1e-3, atol=1e-6)
+
+
+def test_config3_default_architecture_training_step_bf16_vs_float64(golden_dir):
+    """The mode the config-3 figure is quoted in (bf16 mixed precision = the reference's autocast regime, tools/training/train.py:32-40)
+    on the 7-level golden batch g12: loss against the reference's, and EVERY gradient tensor against kink-pinned float64 autograd (the
+    oracle takes the ReLU branches of this bf16 run): per-tensor cosine and norm ratio."""
+    from treelearn_amd import autograd as ag
+    from treelearn_amd.model import TreeLearn
+    g = np.load(os.path.join(golden_dir, "g12_train7.npz"))
+    cfg = json.loads(str(g["cfg"]))
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=cfg["spatial_shape"], voxel_size=cfg["voxel_size"], compute_dtype=torch.bfloat16, **cfg["cfg"])
+    model.load_state_dict(random_state_dict(cfg["seed"], **cfg["cfg"]), strict=True)
+    model = model.cuda().train()
+    batch = _batch_from(g)
+    ag.RELU_MASK_SINK = {}
+    try:
+        loss, _ = model(batch, return_loss=True)
+        sink = ag.RELU_MASK_SINK
+    finally:
+        ag.RELU_MASK_SINK = None
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["train_loss"]), rel=3e-2)
+    mod_name = {m: n for n, m in model.named_modules()}
+    masks = {mod_name[m]: v.cpu() for m, v in sink.items()}
+    _, g64 = om.train_step_grads(random_state_dict(cfg["seed"], **cfg["cfg"]), {k: batch[k] for k in batch}, cfg["voxel_size"],
+                                 cfg["cfg"]["num_blocks"], cfg["spatial_shape"], relu_masks=masks)
+    P = dict(model.named_parameters())
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    rows = []
+    for n in [str(s_) for s_ in g["grad_names"]]:
+        b = g64[n].numpy().astype(np.float64).ravel()
+        if np.abs(b).max() <= 1e-9 * gmax:
+            continue                                             # Linear biases in front of a BatchNorm: zero gradient
+        a = P[n].grad.cpu().numpy().astype(np.float64).ravel()
+        assert np.isfinite(a).all(), n
+        rows.append((float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))), float(np.linalg.norm(a) / np.linalg.norm(b)), n))
+    rows.sort()
+    depth = lambda n: 1 + sum(part == "u" for part in n.split("."))                           # noqa: E731  U-Net level of the parameter
+    per = {}
+    for cos, ratio, n in rows:
+        d = per.setdefault(depth(n), [1.0, 0.0]); d[0] = min(d[0], cos); d[1] = max(d[1], abs(ratio - 1))
+    print("bf16 vs kink-pinned float64 per level (min cosine, max |norm ratio - 1|):", {k: (round(v[0], 4), round(v[1], 4)) for k, v in sorted(per.items())})
+    for cos, ratio, n in rows:
+        lim = BF16_BOUNDS[min(depth(n), 7)]
+        assert cos >= lim[0] and abs(ratio - 1) <= lim[1], (n, cos, ratio)
+
+
+# per-tensor (min cosine, max |norm ratio - 1|) of the bf16 training step vs kink-pinned float64, by U-Net level of the parameter; the deep
+# levels hold 4-600 voxels, where a bf16 ulp of an activation is per cents of a channel's normalised value (measured values in DESIGN.md)
+# measured (min cosine, max |ratio - 1|): level 1 0.9998 / 0.4 %, 2 0.998 / 1.3 %, 3 0.995 / 1.9 %, 4 0.992 / 2.2 %, 5 0.978 / 5.4 %, 6 0.956 / 9.1 %, 7 0.936 / 10.5 %
+BF16_BOUNDS = {1: (0.99, 0.03), 2: (0.99, 0.03), 3: (0.99, 0.03), 4: (0.985, 0.04), 5: (0.96, 0.08), 6: (0.93, 0.12), 7: (0.90, 0.14)}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

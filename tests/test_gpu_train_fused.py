@@ -155,3 +155,48 @@ def test_gather_rows_and_scatter_add_vs_torch(dtype):
     ref = torch.zeros(n, C, dtype=torch.float64, device=d).index_add_(0, torch.where(idx < 0, idx + n, idx), w.double())
     err = float((g1.double() - ref).abs().max() / ref.abs().max())
     assert err < (1e-2 if dtype == torch.bfloat16 else 1e-6)
+
+
+def test_reference_training_step_body_under_autocast():
+    """The literal step body of reference tools/training/train.py:30-44 -- zero_grad, `torch.cuda.amp.autocast(enabled=config.fp16)`
+    around the forward, the loss `.item()` reads, `scaler.scale(loss).backward()`, clip_grad_norm_, `scaler.step`, `scaler.update` --
+    around an unmodified TreeLearn (compute_dtype left at its fp32 default): the autocast region selects the 16-bit kernels, the
+    GradScaler scales and unscales without finding an inf, the optimizer steps."""
+    from collections import defaultdict
+    from treelearn_amd import spconv_compat
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    cfg = dict(channels=32, num_blocks=4)
+    batch = make_batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=s) for s in (1, 2)])
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, **cfg)
+    model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+    model = model.cuda()
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3)
+    scaler = torch.cuda.amp.GradScaler(enabled=True)
+    seen = []
+    hook = model.output_layer.register_forward_hook(lambda m, i, o: seen.append(o.features.dtype))       # the backbone's last activations
+    before = model.unet.blocks[0].conv_branch[2].weight.detach().clone()
+    losses_dict = defaultdict(list)
+    model.train()
+    for _ in range(2):
+        optimizer.zero_grad()
+        with torch.cuda.amp.autocast(enabled=True):
+            loss, loss_dict = model(batch, return_loss=True)
+            for key, value in loss_dict.items():
+                losses_dict[key].append(value.detach().cpu().item())
+        scaler.scale(loss).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0, norm_type=2)
+        scaler.step(optimizer)
+        scaler.update()
+    hook.remove()
+    assert seen and all(d == torch.bfloat16 for d in seen), seen                   # the autocast region ran the 16-bit kernels
+    assert spconv_compat.SparseConvolution.amp_dtype is None                        # and left no state behind
+    assert all(np.isfinite(v).all() for v in losses_dict.values())
+    assert scaler.get_scale() == 65536.0                                            # no inf / nan step was skipped
+    assert not torch.equal(before, model.unet.blocks[0].conv_branch[2].weight.detach())
+    # the same step without autocast runs fp32 and lands near the same loss
+    model2 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, **cfg)
+    model2.load_state_dict(random_state_dict(5, **cfg), strict=True)
+    model2 = model2.cuda().train()
+    l32, _ = model2(batch, return_loss=True)
+    assert losses_dict["semantic_loss"][0] + losses_dict["offset_loss"][0] == pytest.approx(float(l32.detach()), rel=3e-2)

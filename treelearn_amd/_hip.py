@@ -87,6 +87,7 @@ PROTOTYPES = {
     "tl_bn_ws_doubles": (_i64, [_i64, _i32]),
     "tl_bn_train_stats": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_bn_train_bwd": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "tl_linear_small_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _i64, _vp, _i64, _vp]),
     "tl_gather_rows": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tl_scatter_add_rows": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "tl_compact_ws_words": (_i64, [_i64]),

@@ -31,6 +31,9 @@ def _packed(weight, dtype):
 
 
 FUSE_BN = os.environ.get("TL_TRAIN_FUSE", "1") != "0"      # conv-epilogue BatchNorm reductions in training (0: the separate passes, for A/B)
+# test hook: when set to a dict, every training-mode BatchNorm + ReLU served by the HIP kernels stores its ReLU decisions there
+# ({BatchNorm module: bool [rows, C] = output > 0}), so that a float64 reference can differentiate the same piecewise-linear function
+RELU_MASK_SINK = None
 
 
 def _conv_with_stats(x, w_packed, ref, residual, holder):
@@ -102,6 +105,8 @@ class _BNReLUConvFn(torch.autograd.Function):
         x = x.contiguous()
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
         a = ops.affine_relu(x, st[2], st[3], relu)
+        if RELU_MASK_SINK is not None and relu:
+            RELU_MASK_SINK[bn] = a > 0
         y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder)
         ctx.save_for_backward(x, a, st, weight)
         ctx.ref, ctx.relu = ref, relu
@@ -151,6 +156,8 @@ class _BNReLUTrainFn(torch.autograd.Function):
         x = x.contiguous()
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
         y = ops.affine_relu(x, st[2], st[3], relu)
+        if RELU_MASK_SINK is not None and relu:
+            RELU_MASK_SINK[bn] = y > 0
         ctx.save_for_backward(x, st)
         ctx.relu = relu
         if skip:
@@ -250,3 +257,31 @@ def gather_rows(feats, idx, cache=None):
             and (feats.shape[1] * feats.element_size()) % 16 == 0 and feats.shape[0] > 0 and idx.numel() > 0:
         return _GatherRowsFn.apply(feats, idx, cache)
     return feats[idx]
+
+
+class _LinearSmallFn(torch.autograd.Function):
+    """The output Linear of a head (32 -> 2 / 3) with an fp32 RESULT from 16-bit inputs (ops.linear_small_f32): under mixed precision the
+    offsets keep fp32 resolution (bf16 would quantise 8-16 m to 3-6 cm).  Backward: the incoming fp32 gradient is rounded to x's dtype
+    once and takes the same kernels as any 1x1 conv."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        out = ops.linear_small_f32(x, _packed(weight, x.dtype))
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import backward as bw
+        x, weight = ctx.saved_tensors
+        n = x.shape[0]
+        gx, gw = bw.conv_backward(x, weight, bw.TableRef(None, n, None, n, False), g.to(x.dtype).contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw
+
+
+def linear_small_f32(x, weight5):
+    """x . W^T -> fp32 for a [Cout <= 8, 1, 1, 1, Cin] weight view, or None when the shape is not served (caller falls back)."""
+    if x.is_cuda and x.dim() == 2 and x.shape[1] % 8 == 0 and weight5.shape[0] <= 8 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] > 0:
+        return _LinearSmallFn.apply(x, weight5)
+    return None

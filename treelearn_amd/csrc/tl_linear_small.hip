@@ -27,7 +27,9 @@ static __device__ __forceinline__ void load8(const void* base, int64_t elem, flo
   }
 }
 
-template <bool BF16, int CO>
+// OF32: the result is stored as fp32 whatever the input dtype (tl_linear_small_f32: the heads' outputs keep fp32 resolution under
+// mixed precision -- a bf16 offset of 8-16 m would be quantised to 3-6 cm)
+template <bool BF16, int CO, bool OF32 = false>
 __global__ void __launch_bounds__(256) k_conv_tinycout(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float wsh[];        // [CO][Cin]
   for (int e = threadIdx.x; e < CO * p.Cin; e += 256)
@@ -49,7 +51,7 @@ __global__ void __launch_bounds__(256) k_conv_tinycout(ConvP p) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < CO; ++j) epi_store1<BF16>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, o, j, acc[j]);
+    for (int j = 0; j < CO; ++j) epi_store1<BF16 && !OF32>(p.out, p.out_ld, p.out_scale, p.out_shift, p.out_relu, o, j, acc[j]);
   }
 }
 
@@ -133,4 +135,23 @@ int tl_launch_wgrad_tinycout(const void* x, int64_t x_ld, const void* g, int64_t
 #undef TL_TW
   if (hipGetLastError() != hipSuccess) return TL_ERR_LAUNCH;
   return tl_launch_wgrad_reduce(ws, used, (int64_t)Cout * Cin, gw, s);
+}
+
+extern "C" int tl_linear_small_f32(const void* x, int64_t x_ld, int dtype, const void* w, int Cin, int Cout, int64_t n, float* out, int64_t out_ld,
+                                   tl_stream_t stream) {
+  if (!x || !w || !out || n <= 0 || Cin <= 0 || Cout < 1 || Cout > 8 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  if (Cin % 8 || Cin > 1024 || x_ld % 8 || ((uintptr_t)x) % 16) return TL_ERR_UNSUPPORTED;
+  ConvP p{};
+  p.in = x; p.in_ld = x_ld; p.w = w; p.n_out = n; p.n_in = n; p.K = 1; p.Cin = Cin; p.Cout = Cout; p.out = out; p.out_ld = out_ld;
+  const unsigned g = tl_grid(n, 256);
+  const size_t lds = (size_t)Cout * Cin * 4;
+  hipStream_t s = tl_s(stream);
+#define TL_TF(CO_)                                                                             \
+  case CO_:                                                                                    \
+    if (dtype == TL_BF16) k_conv_tinycout<true, CO_, true><<<g, 256, lds, s>>>(p);             \
+    else k_conv_tinycout<false, CO_, true><<<g, 256, lds, s>>>(p);                             \
+    break;
+  switch (Cout) { TL_TF(1) TL_TF(2) TL_TF(3) TL_TF(4) TL_TF(5) TL_TF(6) TL_TF(7) TL_TF(8) }
+#undef TL_TF
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }

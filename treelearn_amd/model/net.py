@@ -64,8 +64,8 @@ class TreeLearn(nn.Module):
         """Build the fused inference plan (folded BatchNorms, packed weights) now, on the current stream.  Callers that spread
         forwards over several streams do this first: the plan is otherwise built by the first forward, on that forward's stream,
         and a forward on another stream could read weights that are still being packed."""
-        if not self.training and (self._plan is None or self._plan.dtype != self.compute_dtype):
-            self._plan = InferencePlan(self, self.compute_dtype)
+        if not self.training and (self._plan is None or self._plan.dtype != self.active_dtype()):
+            self._plan = InferencePlan(self, self.active_dtype())
         return self
 
     def invalidate_plan(self):
@@ -116,22 +116,34 @@ class TreeLearn(nn.Module):
             vfeats = torch.ones((M, C), dtype=torch.float32, device=coords.device)
         return vfeats, geom
 
+    def active_dtype(self):
+        """The dtype the sparse convs run in for this call.  Inside `torch.cuda.amp.autocast` / `torch.autocast("cuda")` -- how the
+        reference selects mixed precision (tools/training/train.py:32 `autocast(enabled=config.fp16)`) -- it is the autocast dtype,
+        whatever `compute_dtype` says; the library has bf16 and fp32 kernels, so a float16 autocast region runs the bf16 kernels (same
+        storage width and matrix-core rate, fp32's exponent range: a GradScaler around the step stays finite and simply scales and
+        unscales).  Outside autocast: `compute_dtype`."""
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+            return torch.bfloat16 if dt in (torch.float16, torch.bfloat16) else torch.float32
+        return self.compute_dtype
+
     @cuda_cast
     def forward_backbone(self, coords, input_feats, batch_ids, batch_size, **kwargs):
         vfeats, geom = self._voxelize(coords.float(), input_feats.float(), batch_ids.long(), batch_size)
+        dtype = self.active_dtype()
         if self.training or torch.is_grad_enabled():
             # module-by-module path (batch-statistics BatchNorm, autograd through the HIP convs)
             lv = geom.levels[0]
             x = spconv.SparseConvTensor(vfeats, lv.coords, list(lv.shape), batch_size, geometry=geom, level=0)
             prev = spconv.SparseConvolution.amp_dtype
-            spconv.SparseConvolution.amp_dtype = None if self.compute_dtype == torch.float32 else self.compute_dtype
-            try:                                                       # compute_dtype = bf16: autocast-like mixed precision
+            spconv.SparseConvolution.amp_dtype = None if dtype == torch.float32 else dtype
+            try:                                                       # 16-bit: mixed precision as under the reference's autocast
                 x = self.output_layer(self.unet(self.input_conv(x)))
             finally:
                 spconv.SparseConvolution.amp_dtype = prev
             return x, geom.v2p
-        if self._plan is None or self._plan.dtype != self.compute_dtype:
-            self._plan = InferencePlan(self, self.compute_dtype)
+        if self._plan is None or self._plan.dtype != dtype:
+            self._plan = InferencePlan(self, dtype)
         return (vfeats, geom), geom.v2p
 
     # ------------------------------------------------------------------ two-phase inference (software-pipelined tile loop)
@@ -140,8 +152,8 @@ class TreeLearn(nn.Module):
         Returns a handle for `infer`.  Calling `prepare(next_tile)` right after `infer(this_tile)` lets the next tile's
         geometry (small latency-bound kernels + two host syncs) run while this tile's convs occupy the main stream."""
         assert not self.training, "prepare/infer is the eval-mode fused path"
-        if self._plan is None or self._plan.dtype != self.compute_dtype:
-            self._plan = InferencePlan(self, self.compute_dtype)
+        if self._plan is None or self._plan.dtype != self.active_dtype():
+            self._plan = InferencePlan(self, self.active_dtype())
         if self._geom_stream is None:
             self._geom_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()

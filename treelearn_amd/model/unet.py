@@ -28,7 +28,7 @@ class MLP(nn.Sequential):
         super().__init__(*modules)
 
     def forward(self, x):
-        from ..autograd import bias_add, bn_relu_train, fusable_bn, sparse_conv
+        from ..autograd import bias_add, bn_relu_train, fusable_bn, linear_small_f32, sparse_conv
         from ..backward import TableRef
         mods = list(self._modules.values())
         i = 0
@@ -44,7 +44,12 @@ class MLP(nn.Sequential):
                 # (the library GEMMs picked for [3.7 M, 32] x [32, 32] and [3.7 M, 32] x [32, 2] ran 25x below their memory bound:
                 # 5.6 ms per call)
                 n = x.shape[0]
-                x = sparse_conv(x, m.weight.view(m.out_features, 1, 1, 1, m.in_features), TableRef(None, n, None, n, False))
+                w5 = m.weight.view(m.out_features, 1, 1, 1, m.in_features)
+                y = linear_small_f32(x, w5) if (i == len(mods) - 1 and m.out_features <= 8 and x.dtype != torch.float32) else None
+                if y is not None:                              # a head's OUTPUT layer: fp32 result (and fp32 bias add) from 16-bit inputs
+                    x = y
+                else:
+                    x = sparse_conv(x, w5, TableRef(None, n, None, n, False))
                 if m.bias is not None:
                     x = bias_add(x, m.bias)
             else:

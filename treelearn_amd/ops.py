@@ -306,3 +306,17 @@ def scatter_add_rows(g, order, sorted_idx, n_rows):
     _hip.check(L.tl_scatter_add_rows(_hip.ptr(g), g.stride(0), _hip.dtype_code(g.dtype), g.shape[1], _hip.ptr(order), _hip.ptr(sorted_idx), g.shape[0], n_rows,
                                      _hip.ptr(out), out.stride(0), _hip.stream()), "tl_scatter_add_rows")
     return out
+
+
+def linear_small_f32(x, w_packed):
+    """x [n, Cin] (f32 / bf16) . W^T with W = w_packed[0] ([1, Cout <= 8, Cin], x's dtype) -> f32 [n, Cout] (tl_linear_small_f32); None if
+    the shape is not served."""
+    L = _hip.lib()
+    n, ci = x.shape
+    co = w_packed.shape[1]
+    out = torch.empty((n, co), dtype=torch.float32, device=x.device)
+    rc = L.tl_linear_small_f32(_hip.ptr(x), x.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(w_packed), ci, co, n, _hip.ptr(out), out.stride(0), _hip.stream())
+    if rc == _hip.TL_ERR_UNSUPPORTED:
+        return None
+    _hip.check(rc, "tl_linear_small_f32")
+    return out
