@@ -382,7 +382,9 @@ int tl_hdbscan_labels_host(const int32_t* e_src, const int32_t* e_dst, const dou
  * tl_hdbscan_prim_order_host before tl_hdbscan_labels_host).
  *   tl_hdbscan_grid_plan: picks the grid (bounding box; leaf level such that an occupied cell holds about eight points); ws of
  *     tl_hdbscan_grid_plan_ws_bytes(); SYNCHRONISES the stream (two small read-backs).
- *   tl_hdbscan_mst_grid: ws of tl_hdbscan_grid_ws_bytes(n, grid); SYNCHRONISES the stream once per Boruvka round (<= ~20). */
+ *   tl_hdbscan_mst_grid: ws of tl_hdbscan_grid_ws_bytes(n, grid); SYNCHRONISES the stream once per Boruvka round (<= ~20).
+ *     min_samples up to 4096 (reference util/pipeline.py:184-191 passes any tau_min): beyond 128 the k-best lists are heaps in the
+ *     workspace -- size it with tl_hdbscan_grid_ws_bytes_k(n, grid, min_samples). */
 typedef struct TlHdbGrid {
   double lo[2];     /* lower corner of the bounding box */
   double h;         /* leaf cell edge */
@@ -392,6 +394,7 @@ typedef struct TlHdbGrid {
 int64_t tl_hdbscan_grid_plan_ws_bytes(void);
 int tl_hdbscan_grid_plan(const float* xy, int64_t n, TlHdbGrid* grid, void* ws, tl_stream_t stream);
 int64_t tl_hdbscan_grid_ws_bytes(int64_t n, const TlHdbGrid* grid);
+int64_t tl_hdbscan_grid_ws_bytes_k(int64_t n, const TlHdbGrid* grid, int min_samples);
 int tl_hdbscan_mst_grid(const float* xy, int64_t n, int min_samples, const TlHdbGrid* grid, int32_t* e_src, int32_t* e_dst,
                         double* e_w, double* core, void* ws, tl_stream_t stream);
 /* HOST stage: spanning-tree edges in any order / orientation -> the order and orientation Prim's algorithm started at point 0

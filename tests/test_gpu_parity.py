@@ -466,8 +466,37 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
             vals, cnts = np.unique(ref[m], return_counts=True)
             agree += cnts.max() if c != -1 else int((ref[m] == -1).sum())
         assert agree / len(ours) >= 0.99, (n, k, agree / len(ours))
-    with pytest.raises(ValueError, match="exceeds the 128"):
-        hdbscan(xy, 200)
+    # min_cluster_size beyond the 128 neighbours the register kernels keep (reference util/pipeline.py:184-191 accepts any tau_min):
+    # heaps in the workspace; same clusters as sklearn, MST weight multiset bit-equal
+    for k in (200, 513):
+        skl = HDBSCAN(min_cluster_size=k).fit(xy)
+        ours, (_, _, ew) = hdbscan(xy, k, return_mst=True)
+        np.testing.assert_array_equal(np.sort(ew), np.sort(skl._single_linkage_tree_["value"]))
+        assert len(set(ours[ours >= 0])) == len(set(skl.labels_[skl.labels_ >= 0])) and (ours == skl.labels_).mean() >= 0.99, k
+    with pytest.raises(ValueError, match="exceeds the 4096"):
+        hdbscan(np.zeros((5000, 2), np.float32), 4097)
+    with pytest.raises(ValueError, match="Prim form"):
+        hdbscan(xy, 200, algorithm="prim")
+
+
+def test_hdbscan_auto_takes_prim_order_on_tie_heavy_input():
+    """algorithm="auto" above the grid threshold: where more than 1 % of the MST weights are exact ties (quantised coordinates) the
+    tree is re-built in Prim's order, so the default equals the Prim form (= sklearn's labels) there; on tie-poor data it keeps the
+    fast grid form."""
+    from treelearn_amd import cluster
+    from treelearn_amd.cluster import hdbscan
+    rng = np.random.default_rng(11)
+    xy = (np.round(rng.uniform(0, 30, size=(9000, 2)) * 4) / 4).astype(np.float32)            # 0.25 m lattice with duplicates: ties everywhere
+    calls = []
+    orig = cluster.hdbscan
+    cluster.hdbscan = lambda *a, **k: (calls.append(k.get("algorithm")), orig(*a, **k))[1]
+    try:
+        auto = hdbscan(xy, 5)
+    finally:
+        cluster.hdbscan = orig
+    np.testing.assert_array_equal(auto, hdbscan(xy, 5, algorithm="prim"))
+    c = rng.uniform(0, 60, (12, 2)); smooth = (c[rng.integers(0, 12, 9000)] + rng.normal(0, 0.7, (9000, 2))).astype(np.float32)
+    np.testing.assert_array_equal(hdbscan(smooth, 50), hdbscan(smooth, 50, algorithm="grid"))
 
 
 def _hdb_device_stage(xy, k, grid):

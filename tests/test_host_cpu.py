@@ -124,8 +124,14 @@ calls = []
 for name in ("all_gather_into_tensor", "all_gather", "broadcast", "all_reduce"):
     orig = getattr(dist, name)
     setattr(dist, name, (lambda o, n: (lambda *a, **k: (calls.append(n), o(*a, **k))[1]))(orig, name))
-res = get_pointwise_preds_sharded(Fake(), tiles(), dict(voxel_size=0.2), device=torch.device("cpu"))
+res = get_pointwise_preds_sharded(Fake(), tiles(), dict(voxel_size=0.2), device=torch.device("cpu"), return_backbone_feats=True)
 assert calls == ["all_gather_into_tensor"] * 2, calls
+assert get_pointwise_preds_sharded.last_record_width == 1 + 2 + 1 + 3 + 3 + 3 + 1 + 32 + 1          # with the backbone columns: 188 bytes
+lean = get_pointwise_preds_sharded(Fake(), tiles(), dict(voxel_size=0.2), device=torch.device("cpu"))
+assert get_pointwise_preds_sharded.last_record_width == 15 and lean[6].shape == (len(lean[0]), 0)    # default: the 60-byte record
+for i in (0, 1, 2, 3, 4, 5, 7):
+    np.testing.assert_array_equal(lean[i], res[i])
+calls.clear()
 for i, r in enumerate(res):
     np.testing.assert_allclose(r, g[f"out{i}"], rtol=1e-6, atol=1e-6)
     assert r.dtype == g[f"out{i}"].dtype, (i, r.dtype, g[f"out{i}"].dtype)
@@ -134,7 +140,7 @@ from treelearn_amd.util.sharding import TileList, assign_tiles, segment_plot_sha
 made = []
 tl = tiles()
 src = TileList([t["coords"].shape[0] for t in tl], lambda i: (made.append(i), tl[i])[1])
-res2 = get_pointwise_preds_sharded(Fake(), src, dict(voxel_size=0.2), device=torch.device("cpu"))
+res2 = get_pointwise_preds_sharded(Fake(), src, dict(voxel_size=0.2), device=torch.device("cpu"), return_backbone_feats=True)
 assert sorted(made) == assign_tiles(src.n_points, dist.get_world_size())[dist.get_rank()], made
 for a, b in zip(res, res2):
     np.testing.assert_array_equal(a, b)
@@ -155,15 +161,25 @@ dist.destroy_process_group()
 '''
 
 
-def test_sharded_tile_loop_gloo_world2(tmp_path):
-    """world_size-2 gloo run of the sharded tile loop reproduces the single-process golden (incl. the skipped tile)."""
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tile_loop_gloo(tmp_path, world):
+    """world_size 2 and 3 gloo runs of the sharded tile loop reproduce the single-process golden: three tiles of unequal size, one of
+    them skipped by the "reach zero" error -- at world 3 the rank that owns it has NO rows (an empty rank in both collectives); two
+    collectives (+ one broadcast for the plot), the 60-byte record by default."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, TL_REPO=REPO, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def test_tile_grid_and_offset_labels_host_logic(golden_dir):

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "tl_hdbscan_grid_plan_ws_bytes": (_i64, []),
     "tl_hdbscan_grid_plan": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "tl_hdbscan_grid_ws_bytes": (_i64, [_i64, _vp]),
+    "tl_hdbscan_grid_ws_bytes_k": (_i64, [_i64, _vp, _i32]),
     "tl_hdbscan_mst_grid": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_knn_vote": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "tl_knn_vote_grid": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _c.c_float * 3, _f32, _I3, _vp, _i64, _i32, _vp, _vp]),

@@ -23,7 +23,9 @@ def dbscan_min2(xy, eps, device="cuda"):
     return labels.cpu().numpy().astype(np.int64)
 
 
-MAX_MIN_SAMPLES = 128          # kMaxK of csrc/tl_hdbscan.hip: the k-best list of the core-distance pass lives in registers / scratch
+MAX_MIN_SAMPLES = 4096         # grid form: beyond 128 neighbours the k-best lists are heaps in the workspace (csrc/tl_hdbscan_grid.hip k_core_big)
+PRIM_MAX_MIN_SAMPLES = 128     # kMaxK of csrc/tl_hdbscan.hip: the Prim form keeps the k-best list in registers / scratch
+TIE_FRACTION = 0.01            # "auto": above this share of exactly tied MST weights the grid form's tree is re-built in Prim's order
 
 
 GRID_MIN_POINTS = 8192          # from here on the quadtree / Boruvka device stage replaces the two O(n^2) passes
@@ -42,24 +44,34 @@ def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False, algorithm="au
     if n < m:
         raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {m}, n_samples_fit = {n}")   # as sklearn
     if m > MAX_MIN_SAMPLES:
-        raise ValueError(f"min_cluster_size = {m} exceeds the {MAX_MIN_SAMPLES} neighbours the HIP core-distance kernel keeps per point "
-                         f"(tau_min of the reference's grouping config is 50); use a smaller tau_min or DBSCAN grouping")
+        raise ValueError(f"min_cluster_size = {m} exceeds the {MAX_MIN_SAMPLES} neighbours the HIP core-distance kernels keep per point "
+                         f"(tau_min of the reference's grouping config is 50)")
     if algorithm not in ("auto", "prim", "grid"):
         raise ValueError(f"unknown HDBSCAN algorithm {algorithm!r}")
+    if algorithm == "prim" and m > PRIM_MAX_MIN_SAMPLES:
+        raise ValueError(f"the Prim form keeps at most {PRIM_MAX_MIN_SAMPLES} neighbours per point; use algorithm='grid' / 'auto' for min_cluster_size = {m}")
     t = t.to(device)
     e_src = torch.empty(n - 1, dtype=torch.int32, device=t.device)
     e_dst = torch.empty(n - 1, dtype=torch.int32, device=t.device)
     e_w = torch.empty(n - 1, dtype=torch.float64, device=t.device)
-    if algorithm == "grid" or (algorithm == "auto" and n >= GRID_MIN_POINTS):
+    use_grid = algorithm == "grid" or (algorithm == "auto" and (n >= GRID_MIN_POINTS or m > PRIM_MAX_MIN_SAMPLES))
+    if use_grid:
         if not bool(torch.isfinite(t).all()):
             raise ValueError("hdbscan: non-finite coordinates")
         grid = _hip.HdbGrid()
         pws = torch.empty(int(L.tl_hdbscan_grid_plan_ws_bytes()), dtype=torch.uint8, device=t.device)
         _hip.check(L.tl_hdbscan_grid_plan(_hip.ptr(t), n, _c.addressof(grid), _hip.ptr(pws), _hip.stream()), "tl_hdbscan_grid_plan")
-        ws = torch.empty(int(L.tl_hdbscan_grid_ws_bytes(n, _c.addressof(grid))), dtype=torch.uint8, device=t.device)
+        ws = torch.empty(int(L.tl_hdbscan_grid_ws_bytes_k(n, _c.addressof(grid), m)), dtype=torch.uint8, device=t.device)
         _hip.check(L.tl_hdbscan_mst_grid(_hip.ptr(t), n, m, _c.addressof(grid), _hip.ptr(e_src), _hip.ptr(e_dst), _hip.ptr(e_w), None, _hip.ptr(ws),
                                          _hip.stream()), "tl_hdbscan_mst_grid")
         gs, gd, gw = e_src.cpu().numpy(), e_dst.cpu().numpy(), e_w.cpu().numpy()
+        if algorithm == "auto" and m <= PRIM_MAX_MIN_SAMPLES:
+            # Among equal-weight edges the grid form picks by (weight, indices), Prim / sklearn by insertion order: any of those trees is
+            # minimal, but the condensed hierarchy may split a tied level differently.  Where ties are common (quantised or duplicated
+            # coordinates, tiny min_samples) the default therefore re-builds the tree in Prim's own order -- slower, sklearn's labels.
+            ws_ = np.sort(gw)
+            if (ws_[1:] == ws_[:-1]).sum() > TIE_FRACTION * max(len(gw), 1):
+                return hdbscan(xy, min_cluster_size, device=device, return_mst=return_mst, algorithm="prim")
         hs, hd, hw = np.empty_like(gs), np.empty_like(gd), np.empty_like(gw)       # the tree in Prim's order / orientation (host)
         _hip.check(L.tl_hdbscan_prim_order_host(gs.ctypes.data, gd.ctypes.data, gw.ctypes.data, n, hs.ctypes.data, hd.ctypes.data, hw.ctypes.data),
                    "tl_hdbscan_prim_order_host")

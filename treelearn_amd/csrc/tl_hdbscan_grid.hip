@@ -232,6 +232,57 @@ __global__ void __launch_bounds__(kBlock) k_core(const double* __restrict__ sx, 
   core[p] = sqrt(cnt >= k ? worst : std::numeric_limits<double>::infinity());
 }
 
+// The same for k > kMaxK (reference util/pipeline.py:184-191 hands any tau_min to HDBSCAN(min_cluster_size)): the k smallest squared
+// distances of a point live in a binary MAX-heap in the workspace (heap[q * T + t] for thread t of T = kBigThreads: coalesced), so a
+// replacement costs log k instead of a rescan; a thread walks points t, t + T, ...  The value returned (the k-th smallest distance) is
+// that of k_core bit for bit: only the bookkeeping differs.
+constexpr int kBigThreads = 256 * 64;
+constexpr int kBigMaxK = 4096;
+__global__ void __launch_bounds__(kBlock) k_core_big(const double* __restrict__ sx, const double* __restrict__ sy, int n, int k, Grid g,
+                                                     const int* __restrict__ start, const int* __restrict__ tag, double* __restrict__ core,
+                                                     double* __restrict__ lists) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= kBigThreads) return;
+  double* heap = lists + t;
+  auto H = [&](int q) -> double& { return heap[(int64_t)q * kBigThreads]; };
+  auto sift = [&](int i, int cnt) {
+    const double v = H(i);
+    while (true) {
+      int c = 2 * i + 1;
+      if (c >= cnt) break;
+      if (c + 1 < cnt && H(c + 1) > H(c)) ++c;
+      if (!(H(c) > v)) break;
+      H(i) = H(c); i = c;
+    }
+    H(i) = v;
+  };
+  for (int p = t; p < n; p += kBigThreads) {
+    const double x = sx[p], y = sy[p];
+    int cnt = 0;
+    int stack[kStack]; int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+      const int c = stack[--sp];
+      const int l = c >> 26, nx = c & 8191, ny = (c >> 13) & 8191;
+      const int64_t ni = lvl_off(l) + ((int64_t)ny << l) + nx;
+      if (tag[ni] == kEmptyTag) continue;
+      if (cnt >= k && node_d2(g, l, nx, ny, x, y) > H(0)) continue;
+      if (l < g.L) { push_children(g, l, nx, ny, x, y, stack, sp); continue; }
+      const int64_t cell = ((int64_t)ny << l) + nx;
+      for (int j = start[cell]; j < start[cell + 1]; ++j) {
+        const double d = dist2(x, y, sx[j], sy[j]);
+        if (cnt < k) {
+          H(cnt) = d; ++cnt;
+          if (cnt == k) for (int i = k / 2 - 1; i >= 0; --i) sift(i, k);      // heapify once the list is full
+        } else if (d < H(0)) {
+          H(0) = d; sift(0, k);
+        }
+      }
+    }
+    core[p] = sqrt(cnt >= k ? H(0) : std::numeric_limits<double>::infinity());
+  }
+}
+
 // ---------------------------------------------------------------- Boruvka
 __device__ __forceinline__ int find_root(int* parent, int x) {
   while (true) {
@@ -397,12 +448,19 @@ int64_t tl_hdbscan_grid_ws_bytes(int64_t n, const TlHdbGrid* grid) {
   return carve(nullptr, n, grid->levels).bytes;
 }
 
+// workspace for min_samples beyond the 128 neighbours k_core keeps in registers: + one heap of min_samples doubles per walking thread
+int64_t tl_hdbscan_grid_ws_bytes_k(int64_t n, const TlHdbGrid* grid, int min_samples) {
+  const int64_t base = tl_hdbscan_grid_ws_bytes(n, grid);
+  if (!base || min_samples < 1 || min_samples > kBigMaxK) return 0;
+  return min_samples > kMaxK ? a16(base) + (int64_t)kBigThreads * min_samples * 8 : base;
+}
+
 // xy f32[n,2] (device) -> the n-1 edges of the minimum spanning tree of the mutual-reachability graph (original point indices,
 // e_src < e_dst, in no particular order; sort by (weight, src, dst) for a canonical list), core f64[n] or NULL.
 // SYNCHRONISES the stream once per Boruvka round (<= ~20) to read the edge count back.
 int tl_hdbscan_mst_grid(const float* xy, int64_t n, int min_samples, const TlHdbGrid* grid, int32_t* e_src, int32_t* e_dst, double* e_w,
                         double* core_out, void* ws, tl_stream_t stream) {
-  if (!xy || !e_src || !e_dst || !e_w || !ws || n < 2 || n > 0x7FFFFFF0 || min_samples < 1 || min_samples > kMaxK || !grid_ok(grid)) return TL_ERR_ARG;
+  if (!xy || !e_src || !e_dst || !e_w || !ws || n < 2 || n > 0x7FFFFFF0 || min_samples < 1 || min_samples > kBigMaxK || !grid_ok(grid)) return TL_ERR_ARG;
   hipStream_t s = tl_s(stream);
   const int L = grid->levels, ni = (int)n;
   const Grid g{grid->lo[0], grid->lo[1], grid->h, (std::fabs(grid->lo[0]) + std::fabs(grid->lo[1]) + grid->h * (double)(1 << L)) * 1e-13, L};
@@ -425,7 +483,9 @@ int tl_hdbscan_mst_grid(const float* xy, int64_t n, int min_samples, const TlHdb
   };
   // core distances
   tags(nullptr);
-  k_core<<<gpt, kBlock, 0, s>>>(w.sx, w.sy, ni, min_samples, g, w.start, w.tag, w.core);
+  if (min_samples <= kMaxK) k_core<<<gpt, kBlock, 0, s>>>(w.sx, w.sy, ni, min_samples, g, w.start, w.tag, w.core);
+  else                                                          // the heaps sit behind the regular workspace (tl_hdbscan_grid_ws_bytes_k)
+    k_core_big<<<kBigThreads / kBlock, kBlock, 0, s>>>(w.sx, w.sy, ni, min_samples, g, w.start, w.tag, w.core, (double*)((char*)ws + a16(w.bytes)));
   k_mincore_leaf<<<gc, kBlock, 0, s>>>(w.start, ncell, w.core, w.mincore + lvl_off(L));
   for (int l = L - 1; l >= 0; --l) k_mincore_up<<<tl_grid((int64_t)1 << (2 * l), kBlock), kBlock, 0, s>>>(w.mincore + lvl_off(l + 1), w.mincore + lvl_off(l), l);
   if (core_out) k_unsort<<<gp, kBlock, 0, s>>>(w.core, w.oid, ni, core_out);

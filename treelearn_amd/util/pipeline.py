@@ -89,7 +89,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                 ci = idx.cpu()
             return t.index_select(0, ci)
 
-        bb = output['backbone_feats']
+        bb = output['backbone_feats'] if return_backbone_feats else None        # a model without the switch still returns them: not shipped
         # every device-side result goes home in ONE packed D2H copy (float columns) instead of one copy + sync per array
         cols = [rows(output['semantic_prediction_logits']).float(), rows(output['offset_predictions']).float()]
         if bb is not None:
@@ -125,58 +125,60 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     if hasattr(model, "return_backbone_feats") and not return_backbone_feats:
         restore_bb = model.return_backbone_feats                        # skip the [N, 32] backbone output (never used downstream, reference
         model.return_backbone_feats = False                             # tools/pipeline/pipeline.py only saves it); result 6 is then [n, 0]
-    with torch.no_grad():
-        model.eval()
-        if cstreams and hasattr(model, "ensure_plan"):
-            model.ensure_plan()                                        # on the caller's stream, which every compute stream waits for
-        it = iter(dataloader)
-        nxt = next(it, None)
-        staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
-        pending = []                                                   # tiles whose results are still on the device, oldest first
-        pos = -1
-        while nxt is not None:
-            batch, (gbatch, ev) = nxt, staged
-            pos += 1
-            gbatch['voxel_size'] = vs
+    try:
+        with torch.no_grad():
+            model.eval()
+            if cstreams and hasattr(model, "ensure_plan"):
+                model.ensure_plan()                                        # on the caller's stream, which every compute stream waits for
+            it = iter(dataloader)
             nxt = next(it, None)
             staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
-            cs = cstreams[pos % nf] if cstreams else None
-            if cs is not None:
-                cs.wait_stream(main_stream)                            # inputs produced on the caller's stream are visible
-            try:
-                with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
-                    if cs is not None:                                 # inputs allocated on the copy / tiler / caller's stream, consumed on this one
-                        for v in gbatch.values():
-                            if torch.is_tensor(v) and v.is_cuda:
-                                v.record_stream(cs)
-                    if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
-                    if gbatch.get('_ready_event') is not None:          # device-resident tile produced on another stream (PlotTiler)
-                        torch.cuda.current_stream().wait_event(gbatch['_ready_event'])
-                    output = model(gbatch, return_loss=False)
-                    done = None
-                    if use_gpu:
-                        done = torch.cuda.Event(); done.record()
-            except Exception as e:                                     # noqa: BLE001
-                if "reach zero!!!" not in str(e):
-                    raise
-                if logger:
-                    logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
-                                'If this does not happen too often, the results should not be influenced.')
-                continue
-            if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":           # A/B switch: read every tile back right away
-                read_back(pos, batch, gbatch, output, None)
-                continue
-            pending.append((pos, batch, gbatch, output, done))
-            if len(pending) > nf:
-                read_back(*pending.pop(0))                             # the oldest tile comes home while nf younger ones compute
-        for pnd in pending:
-            read_back(*pnd)
+            pending = []                                                   # tiles whose results are still on the device, oldest first
+            pos = -1
+            while nxt is not None:
+                batch, (gbatch, ev) = nxt, staged
+                pos += 1
+                gbatch['voxel_size'] = vs
+                nxt = next(it, None)
+                staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+                cs = cstreams[pos % nf] if cstreams else None
+                if cs is not None:
+                    cs.wait_stream(main_stream)                            # inputs produced on the caller's stream are visible
+                try:
+                    with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
+                        if cs is not None:                                 # inputs allocated on the copy / tiler / caller's stream, consumed on this one
+                            for v in gbatch.values():
+                                if torch.is_tensor(v) and v.is_cuda:
+                                    v.record_stream(cs)
+                        if ev is not None:
+                            torch.cuda.current_stream().wait_event(ev)
+                        if gbatch.get('_ready_event') is not None:          # device-resident tile produced on another stream (PlotTiler)
+                            torch.cuda.current_stream().wait_event(gbatch['_ready_event'])
+                        output = model(gbatch, return_loss=False)
+                        done = None
+                        if use_gpu:
+                            done = torch.cuda.Event(); done.record()
+                except Exception as e:                                     # noqa: BLE001
+                    if "reach zero!!!" not in str(e):
+                        raise
+                    if logger:
+                        logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
+                                    'If this does not happen too often, the results should not be influenced.')
+                    continue
+                if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":           # A/B switch: read every tile back right away
+                    read_back(pos, batch, gbatch, output, None)
+                    continue
+                pending.append((pos, batch, gbatch, output, done))
+                if len(pending) > nf:
+                    read_back(*pending.pop(0))                             # the oldest tile comes home while nf younger ones compute
+            for pnd in pending:
+                read_back(*pnd)
+    finally:
+        if restore_bb is not None:                                    # also when a tile raised: later callers must not inherit the flag
+            model.return_backbone_feats = restore_bb
     if cstreams:
         for cs in cstreams:
             main_stream.wait_stream(cs)
-    if restore_bb is not None:
-        model.return_backbone_feats = restore_bb
     if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
         res = tuple(np.zeros((0,), np.float32) for _ in outs)
     elif keep_on_device:
@@ -186,6 +188,28 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     else:
         res = tuple(torch.cat(o, 0).numpy() for o in outs)
     return (res, tile_rows) if return_tile_rows else res
+
+
+def get_instances_device(coords, offset, semantic_prediction_logits, grouping_cfg, verticality_feat, tree_class_in_dataset,
+                         non_trees_label_in_grouping, not_assigned_label_in_grouping, start_num_preds):
+    """`get_instances` for DEVICE tensors (the ensemble's outputs left in HBM): the masks, the shifted coordinates and the label
+    assembly stay on the GPU; only the labels of the few hundred thousand grouped points cross PCIe for the size filter.  Same
+    arithmetic as the numpy form (float32 softmax, the reference's threshold tests): identical ids.  Returns an int64 device tensor."""
+    g = (lambda k: grouping_cfg[k]) if isinstance(grouping_cfg, dict) else (lambda k: getattr(grouping_cfg, k))
+    cluster_coords = (coords + offset)[:, :3]
+    probs = semantic_prediction_logits.float().softmax(dim=-1)
+    tree_mask = probs[:, tree_class_in_dataset] >= g('tree_conf_thresh')
+    mask = tree_mask & (verticality_feat > g('tau_vert')) & (offset[:, 2].abs() < g('tau_off'))
+    ind = torch.nonzero(mask).squeeze(1)
+    xy = cluster_coords.index_select(0, ind)[:, :2].contiguous()
+    predictions = torch.full((coords.shape[0],), float(non_trees_label_in_grouping), dtype=torch.float64, device=coords.device)
+    predictions[tree_mask] = not_assigned_label_in_grouping
+    if g('use_hdbscan'):
+        inst = group_hdbscan(xy, g('tau_min'), not_assigned_label_in_grouping, start_num_preds)
+    else:
+        inst = group_dbscan(xy, g('tau_group'), g('tau_min'), not_assigned_label_in_grouping, start_num_preds)
+    predictions[ind] = torch.from_numpy(np.asarray(inst)).to(predictions.device, torch.float64)
+    return predictions.to(torch.int64)
 
 
 def make_labels_consecutive(labels, start_num):

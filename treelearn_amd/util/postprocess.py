@@ -103,6 +103,18 @@ def assign_remaining_points_nearest_neighbor(coords, predictions, remaining_poin
     return predictions.astype(np.int64)
 
 
+def assign_remaining_points_nearest_neighbor_device(coords, predictions, remaining_points_idx, n_neighbors=5):
+    """The same k-NN fill for DEVICE tensors (coords f32 [n, 3], predictions i64 [n]); returns an int64 device tensor."""
+    predictions = predictions.clone()
+    q = predictions == remaining_points_idx
+    qi, ri = torch.nonzero(q).squeeze(1), torch.nonzero(~q).squeeze(1)
+    if qi.numel() == 0:
+        return predictions
+    c = coords.float().contiguous()
+    predictions[qi] = knn_vote(c.index_select(0, ri).contiguous(), predictions.index_select(0, ri).contiguous(), c.index_select(0, qi).contiguous(), n_neighbors)
+    return predictions
+
+
 def propagate_preds(source_coords, source_preds, target_coords, n_neighbors, n_jobs=1, device="cuda"):
     """Every target point takes the most frequent label among its k nearest source points, the smallest label on ties
     (reference util/pipeline.py:300-331: sklearn NearestNeighbors + np.bincount(...).argmax()); exact k-NN on the GPU."""

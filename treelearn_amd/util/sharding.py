@@ -81,9 +81,11 @@ def _as_source(tiles):
     return TileList([t["coords"].shape[0] for t in tiles], lambda i: tiles[i])
 
 
-def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, device=None, return_device=False):
+def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, device=None, return_device=False, return_backbone_feats=False):
     """`get_pointwise_preds` over `tiles` (a sequence of batch dicts or a TileList) sharded across the process group;
-    every rank returns the full 8-array result in the original tile order.  Two collectives per plot."""
+    every rank returns the full 8-array result in the original tile order.  Two collectives per plot.
+    The record of a point is 1 + 2 + 1 + 3 + 3 + 3 + 1 + F f32 lanes = 60 bytes at F = 1; return_backbone_feats=True adds the 32
+    backbone columns (188 bytes), which nothing downstream of the reference pipeline reads (tools/pipeline/pipeline.py only saves them)."""
     from .pipeline import get_pointwise_preds
     src = _as_source(tiles)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -91,7 +93,8 @@ def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, d
     on_gpu = dist.get_backend(group) == "nccl"
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
     # one pipelined pass over this rank's tiles, results left where the model put them (HBM on a GPU rank)
-    res, rows = get_pointwise_preds(model, (src.make(i) for i in mine), config, logger, return_tile_rows=True, keep_on_device=True)
+    res, rows = get_pointwise_preds(model, (src.make(i) for i in mine), config, logger, return_backbone_feats=return_backbone_feats,
+                                    return_tile_rows=True, keep_on_device=True)
     res = tuple(torch.as_tensor(r).to(dev) for r in res)
     n_local = res[0].shape[0]
     tidx = torch.empty(n_local, dtype=torch.int64)
@@ -115,6 +118,7 @@ def get_pointwise_preds_sharded(model, tiles, config, logger=None, group=None, d
     ref = next(m for m in metas if m[0] > 0)
     widths, is1d = ref[1:9], [bool(b) for b in ref[9:17]]
     W = 1 + sum(widths)
+    get_pointwise_preds_sharded.last_record_width = W             # f32 lanes per gathered point (tests assert the 60-byte record)
     m = max(counts)
     pad = torch.zeros((m, W), dtype=torch.float32, device=dev)
     if n_local:
@@ -140,15 +144,33 @@ def segment_plot_sharded(model, tiles, config, grouping_cfg, group=None, device=
     `ensemble_fn` / `instances_fn` / `fill_fn` default to the HIP implementations (util.postprocess / util.pipeline);
     CPU tests inject restatements."""
     from . import postprocess as pp
-    from .pipeline import get_instances
+    from .pipeline import get_instances, get_instances_device
     rank = dist.get_rank(group)
+    src_rank = dist.get_global_rank(group, 0) if group is not None else 0          # broadcast takes GLOBAL ranks; group rank 0 does the grouping
     on_gpu = dist.get_backend(group) == "nccl"
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+    device_chain = on_gpu and ensemble_fn is None and instances_fn is None and fill_fn is None     # the HIP implementations: stay in HBM
     ensemble_fn = ensemble_fn or pp.ensemble
     instances_fn = instances_fn or get_instances
     fill_fn = fill_fn or pp.assign_remaining_points_nearest_neighbor
     sem, seml, off, offl, coords, instl, bb, infeat = get_pointwise_preds_sharded(model, tiles, config, logger, group, dev, return_device=on_gpu)
     # ensemble is replicated (deterministic on identical inputs: every rank knows the ensembled point count without a collective)
+    if device_chain:
+        # gather -> ensemble -> grouping -> k-NN fill -> broadcast without leaving the device: only the grouped points' labels (size
+        # filter) and, at the very end, the results cross PCIe
+        e_coords, e_sem, _, e_off, _, _, _, e_infeat = ensemble_fn(coords, sem, seml, off, offl, instl, bb, infeat, return_device=True)
+        n = e_coords.shape[0]
+        ids = torch.empty(n, dtype=torch.int32, device=dev)
+        if rank == 0:
+            inst = get_instances_device(e_coords, e_off, e_sem, grouping_cfg, e_infeat.reshape(n, -1)[:, -1], tree_class, non_trees_label,
+                                        not_assigned_label, start_num_preds)
+            tree = inst != non_trees_label
+            it = inst[tree]
+            if it.numel() and bool((it != not_assigned_label).any()) and bool((it == not_assigned_label).any()):
+                inst[tree] = pp.assign_remaining_points_nearest_neighbor_device((e_coords + e_off)[tree], it, not_assigned_label)
+            ids.copy_(inst.to(torch.int32))
+        dist.broadcast(ids, src=src_rank, group=group)                                   # collective 3: the instance ids
+        return e_coords.cpu().numpy(), ids.cpu().numpy().astype(np.int64)
     ens = ensemble_fn(coords, sem, seml, off, offl, instl, bb, infeat)
     e_coords, e_sem, _, e_off, _, _, _, e_infeat = (np.asarray(x.cpu()) if torch.is_tensor(x) else x for x in ens)
     n = len(e_coords)
@@ -160,5 +182,5 @@ def segment_plot_sharded(model, tiles, config, grouping_cfg, group=None, device=
         if tree.any() and (inst[tree] != not_assigned_label).any() and (inst[tree] == not_assigned_label).any():
             inst[tree] = fill_fn(e_coords[tree] + e_off[tree], inst[tree], not_assigned_label)
         ids.copy_(torch.from_numpy(inst.astype(np.int32)))
-    dist.broadcast(ids, src=0, group=group)                                          # collective 3: the instance ids
+    dist.broadcast(ids, src=src_rank, group=group)                                       # collective 3: the instance ids
     return e_coords, ids.cpu().numpy().astype(np.int64)
