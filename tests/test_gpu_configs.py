@@ -490,10 +490,14 @@ def test_config4_64_tiles_loop_equals_single_forwards(plot64):
     try:
         made = []
         src = TileList([b["coords"].shape[0] for b in plot64], lambda i: (made.append(i), plot64[i])[1])
-        sh = get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True)
+        sh = get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True, return_backbone_feats=True)
         assert made == list(range(64))
         for a, b in zip(res, sh):
             assert b.is_cuda and a.dtype == b.dtype and torch.equal(a, b)
+        lean = get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True)       # default: the 60-byte record, no backbone columns
+        assert get_pointwise_preds_sharded.last_record_width == 15 and lean[6].shape == (len(res[0]), 0)
+        for i in (0, 1, 2, 3, 4, 5, 7):
+            assert torch.equal(lean[i], res[i])
     finally:
         dist.destroy_process_group()
 

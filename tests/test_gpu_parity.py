@@ -471,7 +471,7 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
     for k in (200, 513):
         skl = HDBSCAN(min_cluster_size=k).fit(xy)
         ours, (_, _, ew) = hdbscan(xy, k, return_mst=True)
-        np.testing.assert_array_equal(np.sort(ew), np.sort(skl._single_linkage_tree_["value"]))
+        np.testing.assert_allclose(np.sort(ew), np.sort(skl._single_linkage_tree_["value"]), rtol=1e-14, atol=0)     # (one weight of 11 999 is an ulp off at k = 200)
         assert len(set(ours[ours >= 0])) == len(set(skl.labels_[skl.labels_ >= 0])) and (ours == skl.labels_).mean() >= 0.99, k
     with pytest.raises(ValueError, match="exceeds the 4096"):
         hdbscan(np.zeros((5000, 2), np.float32), 4097)
@@ -480,7 +480,7 @@ def test_hdbscan_vs_golden_and_sklearn(golden_dir):
 
 
 def test_hdbscan_auto_takes_prim_order_on_tie_heavy_input():
-    """algorithm="auto" above the grid threshold: where more than 1 % of the MST weights are exact ties (quantised coordinates) the
+    """algorithm="auto" above the grid threshold: where more than 10 % of the MST weights are exact ties (quantised coordinates) the
     tree is re-built in Prim's order, so the default equals the Prim form (= sklearn's labels) there; on tie-poor data it keeps the
     fast grid form."""
     from treelearn_amd import cluster
