@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtreelearn_hip.so")
 TL_F32, TL_BF16 = 0, 1
 TL_ERR_UNSUPPORTED = -3
 TL_EPI_NONE, TL_EPI_STATS, TL_EPI_BN_BWD = 0, 1, 2
-# opt-in: the window form of the 27-tap bf16 convs (csrc/tl_conv_win.hip) for levels of >= 65536 voxels; measured at parity with
-# the register-gather kernels on the config-2 tile, so the default dispatch does not use it
+# opt-in, developer build only: the window form of the 27-tap bf16 convs (csrc/tl_conv_win.hip) for levels of >= 65536 voxels; measured
+# at parity with the register-gather kernels on the config-2 tile, so the release library does not carry it
 WIN_KERNEL = os.environ.get("TL_CONV_WIN") == "1"
 _c = ctypes
 _vp, _i64, _i32, _f32 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_float
@@ -129,8 +129,9 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if WIN_KERNEL:
-            L.tl_set_tuning(b"win", 1)
+        if WIN_KERNEL and L.tl_set_tuning(b"win", 1) != 0:
+            raise RuntimeError("TL_CONV_WIN=1 needs the developer build of the library (python -m treelearn_amd.build --dev): the window conv "
+                               "kernel is not part of the release build")
         _lib = L
     return _lib
 

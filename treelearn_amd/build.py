@@ -3,8 +3,8 @@
     python -m treelearn_amd.build [--force] [--dev]
 
 `--dev` also compiles the developer variants (ablation / segment-timer instantiations of the conv kernels, the gather
-micro-benchmarks of tl_dev.hip and their `tl_dev_*` hooks, which tools/dev_*.py drive); the default (release) library contains
-none of them.
+micro-benchmarks of tl_dev.hip and their `tl_dev_*` hooks, which tools/dev_*.py drive, and the window conv kernel tl_conv_win.hip,
+an experiment that reached parity with the default kernels but never beat them); the default (release) library contains none of them.
 
 The library is built IN-TREE (treelearn_amd/lib/) so it travels with the repo snapshot to the
 GPU box; it is git-ignored.
@@ -22,8 +22,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+DEV_ONLY = ("tl_dev.hip", "tl_conv_win.hip")     # the gather micro-benchmarks; the window conv kernel (parity-green, never faster: DESIGN.md 0.3)
+
+
 def sources(dev=False):
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (dev or f != "tl_dev.hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (dev or f not in DEV_ONLY))
 
 
 def _stale(target, deps):

@@ -303,9 +303,11 @@ extern int g_wgrad_rows;                          // tl_wgrad_rows.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
+#ifdef TL_DEV                                     // the window kernel lives in the developer build only (python -m treelearn_amd.build --dev)
 static int g_win = 0;                             // window kernel (opt-in, TL_CONV_WIN=1: measured at parity with the gather kernels): 1 = shapes with >= 64 channels, 2 = all, 0 = off
 extern int g_win_rows, g_win_ct;                  // tl_conv_win.hip
 static int64_t g_win_min_rows = 65536;            // below this a 512-row tiling leaves most CUs idle
+#endif
 
 extern "C" {
 
@@ -314,10 +316,14 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_depth")) { g_bf16_depth = (int)value; return TL_OK; }
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
+#ifdef TL_DEV
   if (!strcmp(key, "win")) { g_win = (int)value; return TL_OK; }
   if (!strcmp(key, "win_rows")) { g_win_rows = (int)value; return TL_OK; }
   if (!strcmp(key, "win_ct")) { g_win_ct = (int)value; return TL_OK; }
   if (!strcmp(key, "win_min_rows")) { g_win_min_rows = value; return TL_OK; }
+#else
+  if (!strncmp(key, "win", 3)) return TL_ERR_UNSUPPORTED;         // developer build only
+#endif
   if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
   if (!strcmp(key, "streamq")) { g_streamq = (int)value; return TL_OK; }
   if (!strcmp(key, "stream_rb")) return tl_stream_set_rb((int)value);
@@ -404,10 +410,12 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       const int rc = tl_launch_conv_stream(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
+#ifdef TL_DEV
     if (!train && g_win && a->K == 27 && a->n_out >= g_win_min_rows && ((a->Cin >= 64 && a->Cout >= 64) || g_win >= 2)) {
       const int rc = tl_launch_conv_win(p, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
+#endif
     if (g_direct) {
       const int rc = tl_launch_conv_direct(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
