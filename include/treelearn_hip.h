@@ -33,7 +33,10 @@ enum {
   TL_ERR_UNSUPPORTED = -3
 };
 
-enum { TL_F32 = 0, TL_BF16 = 1 };
+/* TL_F16 (IEEE half, BASELINE config 5's "fp16"; the reference trains under fp16 autocast, tools/training/train.py:32): served by
+ * tl_conv_fwd, tl_pack_weight*, tl_head_mlp and tl_affine_relu -- the inference path; the training-only entry points (tl_conv_wgrad,
+ * tl_bn_train_*, epilogue modes) take TL_F32 / TL_BF16.  Values beyond 65504 become inf (no saturation), as on any fp16 path. */
+enum { TL_F32 = 0, TL_BF16 = 1, TL_F16 = 2 };
 
 int tl_version(void);
 /* Developer tuning knobs, process-wide ("win" / "direct" / "stream" / "streamq": enable a conv kernel family; "win_rows": window
@@ -158,7 +161,7 @@ typedef struct tl_conv_args {
   const void* weight;                     /* [K][Cout][Cin], same dtype as `in` */
   const int32_t* table;                   /* [K][n_out], or NULL = identity (K must be 1) */
   int64_t n_out;         int64_t n_in;
-  int32_t K;             int32_t Cin;     int32_t Cout;   int32_t dtype;   /* TL_F32 | TL_BF16 */
+  int32_t K;             int32_t Cin;     int32_t Cout;   int32_t dtype;   /* TL_F32 | TL_BF16 | TL_F16 */
   const float* in_scale; const float* in_shift;  int32_t in_relu;  int32_t out_relu;
   const void* residual;  int64_t res_ld;
   const float* out_scale; const float* out_shift;

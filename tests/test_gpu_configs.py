@@ -136,9 +136,12 @@ def test_config2_full_tile_geometry_bit_exact(tile2):
 @pytest.mark.parametrize("level,cin,cout,kind", [
     (0, 32, 32, "subm"), (0, 64, 32, "subm"), (0, 4, 32, "subm"), (0, 32, 64, "down"), (0, 64, 32, "inverse"),
     (1, 64, 64, "subm"), (1, 128, 64, "subm"), (1, 64, 96, "down"), (1, 96, 64, "inverse"),
-    (2, 96, 96, "subm"), (2, 192, 96, "subm"), (3, 128, 128, "subm"), (3, 256, 128, "subm"), (4, 160, 160, "subm")])
+    (2, 96, 96, "subm"), (2, 192, 96, "subm"), (3, 128, 128, "subm"), (3, 256, 128, "subm"), (4, 160, 160, "subm"),
+    # the deep levels (small-level kernel) and the 1x1 i_branch convs of the decoder's first tail blocks (Custom1x1Subm3d, blocks.py:29-39)
+    (5, 192, 192, "subm"), (5, 384, 192, "subm"), (6, 224, 224, "subm"), (5, 192, 224, "down"), (5, 224, 192, "inverse"),
+    (0, 64, 32, "1x1"), (1, 128, 64, "1x1"), (2, 192, 96, "1x1"), (4, 320, 160, "1x1")])
 def test_config2_full_tile_convs_on_real_rulebooks(tile2, level, cin, cout, kind):
-    """Every conv shape of levels 1-5 on the REAL rulebooks of the full tile (the launches the headline number times), bf16 and
+    """Every conv shape of levels 1-7 on the REAL rulebooks of the full tile (the launches the headline number times), bf16 and
     fp32, residual + BatchNorm/ReLU epilogue + second view as the engine uses them, against the oracle's gather-mm form on 4096
     sampled output rows with the same (bf16-rounded) operands."""
     from treelearn_amd import ops
@@ -146,6 +149,8 @@ def test_config2_full_tile_convs_on_real_rulebooks(tile2, level, cin, cout, kind
     lv = g.levels[level]
     if kind == "subm":
         table, n_out, n_in, K = lv.nbr, lv.n, lv.n, 27
+    elif kind == "1x1":
+        table, n_out, n_in, K = None, lv.n, lv.n, 1
     elif kind == "down":
         table, n_out, n_in, K = lv.child, g.levels[level + 1].n, lv.n, 8
     else:
@@ -154,7 +159,7 @@ def test_config2_full_tile_convs_on_real_rulebooks(tile2, level, cin, cout, kind
     k = round(K ** (1 / 3))
     w = torch.randn((cout, k, k, k, cin), device="cuda", generator=gen) / (cin * K) ** 0.5
     rows = torch.randperm(n_out, device="cuda", generator=gen)[:4096].sort().values
-    sub = table[:, rows].T.contiguous().cpu().numpy()
+    sub = table[:, rows].T.contiguous().cpu().numpy() if table is not None else rows.cpu().numpy()[:, None]
     osc = torch.rand(cout, device="cuda", generator=gen) + 0.5; osh = torch.randn(cout, device="cuda", generator=gen) * 0.3
     for dt, tol in ((torch.bfloat16, 1.2e-2), (torch.float32, 2e-5)):
         x = torch.randn((n_in, cin), device="cuda", generator=gen).to(dt)

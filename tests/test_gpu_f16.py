@@ -1,0 +1,126 @@
+"""float16 inference path (TL_F16: BASELINE config 5 says "fp16"; the reference trains / evaluates under fp16 autocast,
+tools/training/train.py:32): the conv kernel families, compiled a second time with IEEE-half conversions (csrc/tl_half.h), against the
+oracle fed the same fp16-rounded operands; the fused engine on the config-5 stress tile with overflow counts."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ops as osp
+from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _f16_round(a):
+    return torch.from_numpy(a).to(torch.float16).float().numpy()
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(np.asarray(b, np.float64)).max(), 1e-30))
+
+
+# direct (weights in LDS), the 4-channel input conv, stream-q, stream, small-level, down / inverse shapes, 1x1
+@pytest.mark.parametrize("cin,cout,K,n_out,one_hot", [
+    (32, 32, 27, 17001, False), (64, 32, 27, 16500, False), (4, 32, 27, 20000, False), (64, 64, 27, 16500, False), (128, 64, 27, 16400, False),
+    (96, 96, 27, 16400, False), (192, 96, 27, 16402, False), (128, 128, 27, 16401, False), (256, 128, 27, 16404, False), (32, 64, 8, 16400, False),
+    (64, 32, 8, 20000, True), (96, 64, 8, 16385, True), (64, 32, 1, 20000, False), (160, 160, 27, 6500, False), (224, 224, 27, 401, False),
+    (320, 160, 27, 3000, False)])
+def test_conv_fwd_f16_vs_oracle(cin, cout, K, n_out, one_hot):
+    """fp16 storage + f16 MFMA, fp32 accumulate, residual + BatchNorm/ReLU second view: against the oracle on the same fp16-rounded
+    operands (one fp16 rounding of the output: 2^-11)."""
+    from treelearn_amd import ops
+    rng = np.random.default_rng(cin * 7 + cout + K)
+    d = torch.device("cuda")
+    n_in = n_out + 77 if K > 1 else n_out
+    x = _f16_round(rng.normal(size=(n_in, cin)).astype(np.float32))
+    k = round(K ** (1 / 3))
+    w = _f16_round((rng.normal(size=(cout, k, k, k, cin)) / np.sqrt(cin * K)).astype(np.float32))
+    if one_hot:
+        table = np.full((n_out, K), -1, np.int32)
+        table[np.arange(n_out), rng.integers(0, K, n_out)] = rng.integers(0, n_in, n_out)
+    else:
+        table = rng.integers(-1, n_in, size=(n_out, K)).astype(np.int32)
+        table[rng.uniform(size=table.shape) < 0.4] = -1
+    if K == 1:
+        table = np.arange(n_in, dtype=np.int32)[:, None]
+    res = _f16_round(rng.normal(size=(n_out, cout)).astype(np.float32))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32); sh = rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = osp.conv_table(torch.from_numpy(x), torch.from_numpy(w), table, n_out).numpy() + res
+    T = lambda a, dt=torch.float16: torch.from_numpy(a).to(d).to(dt)                     # noqa: E731
+    wp = ops.pack_weight(T(w, torch.float32), torch.float16)
+    tab = None if K == 1 else torch.from_numpy(np.ascontiguousarray(table.T)).to(d)
+    act = torch.empty((n_out, cout), dtype=torch.float16, device=d)
+    out = ops.conv_fwd(T(x), wp, tab, n_out, residual=T(res), out2=(act, T(sc, torch.float32), T(sh, torch.float32), True), one_hot=one_hot)
+    assert out.dtype == torch.float16
+    assert rel_err(out.float().cpu().numpy(), ref) < 1.5e-3
+    assert rel_err(act.float().cpu().numpy(), np.maximum(ref * sc + sh, 0)) < 1.5e-3
+    # and the bf16 kernels are untouched by the second compilation: same call in bf16 against its own rounding
+    outb = ops.conv_fwd(T(x, torch.bfloat16), ops.pack_weight(T(w, torch.float32), torch.bfloat16), tab, n_out, residual=T(res, torch.bfloat16), one_hot=one_hot)
+    assert outb.dtype == torch.bfloat16 and rel_err(outb.float().cpu().numpy(), ref) < 2e-2
+
+
+def _trained_like(voxel, sshape, batch, seed=11):
+    """Synthetic weights with BatchNorm statistics re-estimated on the tile (a random-init net with arbitrary running statistics
+    saturates and reaches 1e5 in places; re-estimated ones keep activations O(1) like a trained net's)."""
+    from treelearn_amd.model import TreeLearn
+    m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=sshape, voxel_size=voxel, compute_dtype=torch.bfloat16)
+    m.load_state_dict(random_state_dict(seed, channels=32, num_blocks=7), strict=True)
+    m = m.cuda().train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(batch, return_loss=False)                       # module-by-module path, batch statistics -> the running statistics move
+    return m.eval()
+
+
+def test_config5_stress_tile_forward_fp16():
+    """BASELINE config 5 as worded: the 0.05 m / 16 M-point tile in fp16, on trained-like weights.  Every output finite (overflow count 0),
+    decisions as in bf16 / closer to fp32 than bf16 is; on RANDOM-INIT running statistics the same forward overflows fp16 (counted), which
+    is why bf16 stays the default 16-bit mode."""
+    from treelearn_amd.model import TreeLearn
+    batch = make_batch([make_tile(**CONFIGS["config5"], seed=0)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    mb = _trained_like(0.05, None, gb)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=None, voxel_size=0.05, compute_dtype=dt)
+        m.load_state_dict(mb.state_dict(), strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            o = m(gb, return_loss=False)
+        outs[dt] = {k: o[k].float() for k in ("semantic_prediction_logits", "offset_predictions")}
+        del m
+    o32, ob, oh = outs[torch.float32], outs[torch.bfloat16], outs[torch.float16]
+    bad = sum(int((~torch.isfinite(v)).sum()) for v in oh.values())
+    print(f"config 5 fp16, trained-like weights: {bad} non-finite outputs of {sum(v.numel() for v in oh.values())}")
+    assert bad == 0
+    for k in oh:
+        eh = float((oh[k] - o32[k]).abs().max() / o32[k].abs().max()); eb = float((ob[k] - o32[k]).abs().max() / o32[k].abs().max())
+        print(f"  {k}: max-norm error vs fp32: fp16 {eh:.2e}, bf16 {eb:.2e}")
+        assert eh < 2e-2 and eh <= eb * 1.2
+    flips = float((oh["semantic_prediction_logits"].argmax(1) != o32["semantic_prediction_logits"].argmax(1)).float().mean())
+    assert flips < 0.01, flips
+    # random-init running statistics: the overflow the reference needs its GradScaler / trained BatchNorms for
+    m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=None, voxel_size=0.05, compute_dtype=torch.float16)
+    m.load_state_dict(random_state_dict(11, channels=32, num_blocks=7), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        o = m(gb, return_loss=False)
+    bad_r = sum(int((~torch.isfinite(o[k])).sum()) for k in ("semantic_prediction_logits", "offset_predictions"))
+    print(f"config 5 fp16, random-init running statistics: {bad_r} non-finite outputs")
+
+
+def test_autocast_float16_eval_runs_the_f16_kernels():
+    """Inside `torch.autocast("cuda", dtype=torch.float16)` an eval-mode forward of a default (fp32) model takes the float16 plan."""
+    from treelearn_amd.model import TreeLearn
+    batch = make_batch([make_tile(extent=10.0, voxel=0.1, n_trees=4, fill=0.10, seed=2)])
+    m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, channels=32, num_blocks=4)
+    m.load_state_dict(random_state_dict(3, channels=32, num_blocks=4), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        ref = m(batch, return_loss=False)
+        with torch.autocast("cuda", dtype=torch.float16):
+            o = m(batch, return_loss=False)
+    assert m._plan.dtype == torch.float16
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        assert bool(torch.isfinite(o[k]).all())
+        assert rel_err(o[k].float().cpu().numpy(), ref[k].float().cpu().numpy()) < 3e-2, k

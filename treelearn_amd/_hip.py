@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtreelearn_hip.so")
 
-TL_F32, TL_BF16 = 0, 1
+TL_F32, TL_BF16, TL_F16 = 0, 1, 2
 TL_ERR_UNSUPPORTED = -3
 TL_EPI_NONE, TL_EPI_STATS, TL_EPI_BN_BWD = 0, 1, 2
 # opt-in, developer build only: the window form of the 27-tap bf16 convs (csrc/tl_conv_win.hip) for levels of >= 65536 voxels; measured
@@ -162,6 +162,8 @@ def dtype_code(dt):
         return TL_F32
     if dt == torch.bfloat16:
         return TL_BF16
+    if dt == torch.float16:
+        return TL_F16                # inference path (tl_conv_fwd, tl_pack_weight*, tl_head_mlp, tl_affine_relu)
     raise ValueError(f"unsupported compute dtype {dt}")
 
 

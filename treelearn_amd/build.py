@@ -25,6 +25,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 DEV_ONLY = ("tl_dev.hip", "tl_conv_win.hip")     # the gather micro-benchmarks; the window conv kernel (parity-green, never faster: DESIGN.md 0.3)
 
 
+# units compiled a SECOND time with -DTL_F16_BUILD (csrc/tl_half.h): the same kernels with IEEE-half conversions and the f16 MFMA,
+# launchers suffixed _f16 -- the float16 inference path (TL_F16)
+F16_UNITS = ("tl_conv_direct.hip", "tl_conv_stream.hip", "tl_conv_streamq.hip", "tl_conv_small.hip", "tl_conv_bf16.hip", "tl_head.hip")
+
+
 def sources(dev=False):
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (dev or f not in DEV_ONLY))
 
@@ -48,19 +53,24 @@ def build(force=False, verbose=True, dev=False):
     flavour = "dev" if dev else "release"
     relink = not os.path.exists(stamp) or open(stamp).read() != flavour
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    jobs = [(s, o, []) for s, o in zip(srcs, objs)]
+    for s in srcs:
+        if os.path.basename(s) in F16_UNITS:
+            o = os.path.join(objdir, os.path.basename(s)[:-4] + "_f16.o")
+            objs.append(o); jobs.append((s, o, ["-DTL_F16_BUILD"]))
 
     def compile_one(so):
-        s, o = so
+        s, o, extra = so
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
+            cmd = [HIPCC] + flags + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
             return True
         return False
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        changed = list(ex.map(compile_one, zip(srcs, objs)))
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        changed = list(ex.map(compile_one, jobs))
     if force or relink or any(changed) or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
         if verbose:

@@ -204,6 +204,7 @@ __global__ void k_pack_weight(const float* __restrict__ w, int Cout, int K, int 
     const int c = (int)(t % Cin); const int64_t r = t / Cin; const int j = (int)(r % Cout); const int k = (int)(r / Cout);
     const float v = w[((int64_t)j * K + k) * Cin + c];                 // reference layout [Cout][K][Cin]
     if (dtype == TL_F32) reinterpret_cast<float*>(o)[t] = v;
+    else if (dtype == TL_F16) reinterpret_cast<_Float16*>(o)[t] = (_Float16)v;
     else reinterpret_cast<__hip_bfloat16*>(o)[t] = __float2bfloat16(v);
   }
 }
@@ -215,6 +216,7 @@ __global__ void k_pack_weight_dgrad(const float* __restrict__ w, int Cout, int K
     const int co = (int)(t % Cout); const int64_t r = t / Cout; const int ci = (int)(r % Cin); const int k = (int)(r / Cin);
     const float v = w[((int64_t)co * K + (flip ? K - 1 - k : k)) * Cin + ci];
     if (dtype == TL_F32) reinterpret_cast<float*>(o)[t] = v;
+    else if (dtype == TL_F16) reinterpret_cast<_Float16*>(o)[t] = (_Float16)v;
     else reinterpret_cast<__hip_bfloat16*>(o)[t] = __float2bfloat16(v);
   }
 }
@@ -231,6 +233,7 @@ __global__ void k_pack_weight_frag(const float* __restrict__ w, int Cout, int K,
     for (int e = 0; e < EPV; ++e) {
       const float x = w[((int64_t)col * K + k) * Cin + c0 + e];
       if (dtype == TL_F32) reinterpret_cast<float*>(o)[v * EPV + e] = x;
+      else if (dtype == TL_F16) reinterpret_cast<_Float16*>(o)[v * EPV + e] = (_Float16)x;
       else reinterpret_cast<__hip_bfloat16*>(o)[v * EPV + e] = __float2bfloat16(x);
     }
   }
@@ -342,7 +345,18 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (!a->table && a->K != 1) return TL_ERR_ARG;
   if ((a->in_scale == nullptr) != (a->in_shift == nullptr)) return TL_ERR_ARG;
   if ((a->out_scale == nullptr) != (a->out_shift == nullptr)) return TL_ERR_ARG;
-  if (a->dtype != TL_F32 && a->dtype != TL_BF16) return TL_ERR_ARG;
+  if (a->dtype != TL_F32 && a->dtype != TL_BF16 && a->dtype != TL_F16) return TL_ERR_ARG;
+  // float16: the same kernel sources compiled a second time with IEEE-half conversions (tl_half.h); inside those units -- and in the
+  // dispatch below -- "TL_BF16" stands for "the 16-bit type"
+  const bool f16 = a->dtype == TL_F16;
+  const int dt = f16 ? TL_BF16 : a->dtype;
+  const auto L_direct = f16 ? tl_launch_conv_direct_f16 : tl_launch_conv_direct;
+  const auto L_ones27 = f16 ? tl_launch_conv_ones27_f16 : tl_launch_conv_ones27;
+  const auto L_stream = f16 ? tl_launch_conv_stream_f16 : tl_launch_conv_stream;
+  const auto L_streamq = f16 ? tl_launch_conv_streamq_f16 : tl_launch_conv_streamq;
+  const auto L_small = f16 ? tl_launch_conv_small_f16 : tl_launch_conv_small;
+  const auto L_tinycin = f16 ? tl_launch_conv_tinycin_f16 : tl_launch_conv_tinycin;
+  if (f16 && a->epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;       // the training epilogues take TL_F32 / TL_BF16
   ConvP p;
   p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
   p.K = a->K; p.Cin = a->Cin; p.Cout = a->Cout; p.in_scale = a->in_scale; p.in_shift = a->in_shift;
@@ -370,28 +384,28 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
                        (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));
-  if (a->in_all_ones && !train && a->dtype == TL_BF16 && out_vec && g_direct && ((uintptr_t)a->weight) % 2 == 0 && !a->residual) {
-    const int rc = tl_launch_conv_ones27(p, s);
+  if (a->in_all_ones && !train && dt == TL_BF16 && out_vec && g_direct && ((uintptr_t)a->weight) % 2 == 0 && !a->residual) {
+    const int rc = L_ones27(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
-  if (a->dtype == TL_BF16 && a->Cin == 4 && a->Cout == 32 && g_direct && out_vec && ((uintptr_t)a->in) % 8 == 0 && ((uintptr_t)a->weight) % 16 == 0 &&
+  if (dt == TL_BF16 && a->Cin == 4 && a->Cout == 32 && g_direct && out_vec && ((uintptr_t)a->in) % 8 == 0 && ((uintptr_t)a->weight) % 16 == 0 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0))) {
-    const int rc = tl_launch_conv_direct(p, TL_BF16, s);
+    const int rc = L_direct(p, TL_BF16, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
-  if (!train && a->Cin <= 8 && a->Cout % 8 == 0 && a->Cout <= 64 && !a->in_scale && !a->in_relu && out_vec) return tl_launch_conv_tinycin(p, a->dtype, s);
-  if (!train && vec_ok && a->n_out <= g_small_rows && a->Cin % 32 == 0 && a->Cout % 32 == 0) return tl_launch_conv_small(p, a->dtype, s);
+  if (!train && a->Cin <= 8 && a->Cout % 8 == 0 && a->Cout <= 64 && !a->in_scale && !a->in_relu && out_vec) return L_tinycin(p, dt, s);
+  if (!train && vec_ok && a->n_out <= g_small_rows && a->Cin % 32 == 0 && a->Cout % 32 == 0) return L_small(p, dt, s);
   if (train && a->n_out <= g_small_rows) return TL_ERR_UNSUPPORTED;            // small levels: the separate passes
   const bool aligned = (a->in_ld % 4 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0) &&
                        (!a->in_scale || (((uintptr_t)a->in_scale) % 16 == 0 && ((uintptr_t)a->in_shift) % 16 == 0));
-  if (a->dtype == TL_F32 && aligned && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && !a->in_scale && !a->in_relu &&
+  if (dt == TL_F32 && aligned && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && !a->in_scale && !a->in_relu &&
       (!a->residual || (a->res_ld % 4 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
-    if (g_direct) { const int rc = tl_launch_conv_direct(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
-    if (g_stream) { const int rc = tl_launch_conv_stream(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
+    if (g_direct) { const int rc = L_direct(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
+    if (g_stream) { const int rc = L_stream(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
   }
-  if (train && a->dtype == TL_F32) return TL_ERR_UNSUPPORTED;
-  if (a->dtype == TL_F32 && aligned && a->Cin % KC == 0 && a->Cout % 32 == 0 && a->Cout <= 224) {
+  if (train && dt == TL_F32) return TL_ERR_UNSUPPORTED;
+  if (dt == TL_F32 && aligned && a->Cin % KC == 0 && a->Cout % 32 == 0 && a->Cout <= 224) {
     switch (a->Cout / 32) {
       case 1: return launch_mfma_f32<1>(p, s);
       case 2: return launch_mfma_f32<2>(p, s);
@@ -402,12 +416,12 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       case 7: return launch_mfma_f32<7>(p, s);
     }
   }
-  if (a->dtype == TL_BF16 && aligned && vec_ok && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && a->Cout <= 224 &&
+  if (dt == TL_BF16 && aligned && vec_ok && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && a->Cout <= 224 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
   {
     if (p.one_hot && g_stream && a->K == 8) {                  // inverse convs: the stream kernel's gather-once form
-      const int rc = tl_launch_conv_stream(p, TL_BF16, s);
+      const int rc = L_stream(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
 #ifdef TL_DEV
@@ -417,27 +431,27 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     }
 #endif
     if (g_direct) {
-      const int rc = tl_launch_conv_direct(p, TL_BF16, s);
+      const int rc = L_direct(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (g_stream && g_streamq) {
-      const int rc = tl_launch_conv_streamq(p, s);
+      const int rc = L_streamq(p, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (g_stream) {
-      const int rc = tl_launch_conv_stream(p, TL_BF16, s);
+      const int rc = L_stream(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (train) return TL_ERR_UNSUPPORTED;
-    return tl_launch_conv_bf16(p, g_bf16_depth, g_bf16_units, s);
+    return f16 ? tl_launch_conv_bf16_f16(p, g_bf16_depth, g_bf16_units, s) : tl_launch_conv_bf16(p, g_bf16_depth, g_bf16_units, s);
   }
-  if (train) return TL_ERR_UNSUPPORTED;
+  if (train || f16) return TL_ERR_UNSUPPORTED;             // scalar fallbacks: TL_F32 / TL_BF16 only
   {                                                              // 1x1 with <= 8 output channels (the heads' output Linears in training)
-    const int rc = tl_launch_conv_tinycout(p, a->dtype, s);
+    const int rc = tl_launch_conv_tinycout(p, dt, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   const unsigned g = tl_grid(a->n_out * a->Cout, 256);
-  if (a->dtype == TL_F32) k_conv_generic<float><<<g, 256, 0, s>>>(p);
+  if (dt == TL_F32) k_conv_generic<float><<<g, 256, 0, s>>>(p);
   else k_conv_generic<__hip_bfloat16><<<g, 256, 0, s>>>(p);
   TL_CHECK_LAUNCH();
   return TL_OK;
@@ -450,21 +464,21 @@ int64_t tl_conv_red_parts(int64_t n_out) {
 }
 
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream) {
-  if (!w_ref || !w_packed || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  if (!w_ref || !w_packed || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16 && dtype != TL_F16)) return TL_ERR_ARG;
   k_pack_weight<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_packed, dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
 
 int tl_pack_weight_dgrad(const float* w_ref, int Cout, int K, int Cin, int flip, void* w_t, int dtype, tl_stream_t stream) {
-  if (!w_ref || !w_t || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  if (!w_ref || !w_t || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16 && dtype != TL_F16)) return TL_ERR_ARG;
   k_pack_weight_dgrad<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, flip, w_t, dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
 
 int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_frag, int dtype, tl_stream_t stream) {
-  if (!w_ref || !w_frag || Cout <= 0 || K <= 0 || Cin <= 0 || Cout % 32 || Cin % 32 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
+  if (!w_ref || !w_frag || Cout <= 0 || K <= 0 || Cin <= 0 || Cout % 32 || Cin % 32 || (dtype != TL_F32 && dtype != TL_BF16 && dtype != TL_F16)) return TL_ERR_ARG;
   k_pack_weight_frag<<<tl_grid((int64_t)Cout * K * Cin / 8, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_frag, dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
@@ -486,6 +500,7 @@ int tl_affine_relu(const void* in, int64_t in_ld, void* out, int64_t out_ld, int
   const unsigned g = tl_grid(n * C, 256);
   if (dtype == TL_F32) k_affine_relu<float><<<g, 256, 0, tl_s(stream)>>>((const float*)in, in_ld, (float*)out, out_ld, n, C, scale, shift, relu);
   else if (dtype == TL_BF16) k_affine_relu<__hip_bfloat16><<<g, 256, 0, tl_s(stream)>>>((const __hip_bfloat16*)in, in_ld, (__hip_bfloat16*)out, out_ld, n, C, scale, shift, relu);
+  else if (dtype == TL_F16) k_affine_relu<_Float16><<<g, 256, 0, tl_s(stream)>>>((const _Float16*)in, in_ld, (_Float16*)out, out_ld, n, C, scale, shift, relu);
   else return TL_ERR_ARG;
   TL_CHECK_LAUNCH();
   return TL_OK;

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_conv_bf16(ConvP p) {
 #pragma unroll
       for (int j = 0; j < KCB / 16; ++j) {
         const bf16x8 bf = *reinterpret_cast<const bf16x8*>(b + 32 * j);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf, acc[nb], 0, 0, 0);
+        acc[nb] = h16_mfma(__builtin_bit_cast(u32x4, af[j]), __builtin_bit_cast(u32x4, bf), acc[nb]);
       }
     }
   };

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
       const u32x4 af = {g[2 * s][0], g[2 * s][1], g[2 * s + 1][0], g[2 * s + 1][1]};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfrag[s]), acc, 0, 0, 0);
+      acc = h16_mfma(af, bfrag[s], acc);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[r];

@@ -2,6 +2,19 @@
 #pragma once
 #include "tl_common.h"
 #include <hip/hip_bf16.h>
+#include "tl_half.h"
+
+#ifdef TL_F16_BUILD       // the float16 build of the conv units: same sources, IEEE-half conversions (tl_half.h), launchers with an _f16 suffix
+#define tl_launch_conv_direct tl_launch_conv_direct_f16
+#define tl_launch_conv_ones27 tl_launch_conv_ones27_f16
+#define tl_launch_conv_stream tl_launch_conv_stream_f16
+#define tl_stream_set_rb tl_stream_set_rb_f16
+#define tl_launch_conv_streamq tl_launch_conv_streamq_f16
+#define tl_launch_conv_small tl_launch_conv_small_f16
+#define tl_launch_conv_tinycin tl_launch_conv_tinycin_f16
+#define tl_launch_conv_bf16 tl_launch_conv_bf16_f16
+#define g_small_mode g_small_mode_f16
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -37,9 +50,11 @@ struct ConvP {
 };
 
 static __device__ __forceinline__ float ld_elem(const float* p) { return *p; }
-static __device__ __forceinline__ float ld_elem(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+static __device__ __forceinline__ float ld_elem(const __hip_bfloat16* p) { return h16_lo((uint32_t)*reinterpret_cast<const uint16_t*>(p)); }   // "the 16-bit type" of this build
 static __device__ __forceinline__ void st_elem(float* p, float v) { *p = v; }
-static __device__ __forceinline__ void st_elem(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+static __device__ __forceinline__ float ld_elem(const _Float16* p) { return (float)*p; }
+static __device__ __forceinline__ void st_elem(_Float16* p, float v) { *p = (_Float16)v; }
+static __device__ __forceinline__ void st_elem(__hip_bfloat16* p, float v) { *reinterpret_cast<uint16_t*>(p) = (uint16_t)(h16_pack2(v, 0.f) & 0xFFFFu); }
 
 // XCD-aware tile order: block b runs on XCD b % 8 (observed, speed only); give each XCD a contiguous
 // range of tiles so neighbouring tiles -- which gather overlapping input rows -- share one L2.
@@ -51,14 +66,10 @@ static __device__ __forceinline__ int xcd_tile(int b, int n) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // round-to-nearest-even
-  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-  a += 0x7FFFu + ((a >> 16) & 1u);
-  b += 0x7FFFu + ((b >> 16) & 1u);
-  return (a >> 16) | (b & 0xFFFF0000u);
-}
-static __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
-static __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+// (names kept from the bf16-only days: in the -DTL_F16_BUILD compilation of a unit these pack / unpack IEEE halves)
+static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return h16_pack2(lo, hi); }
+static __device__ __forceinline__ float bf16_lo(uint32_t u) { return h16_lo(u); }
+static __device__ __forceinline__ float bf16_hi(uint32_t u) { return h16_hi(u); }
 
 // ---- epilogue helpers: write y (fp32) through one output view
 template <bool BF16>
@@ -100,7 +111,7 @@ static __device__ __forceinline__ void epi_store8(void* base, int64_t ld, const 
 template <bool BF16>
 static __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& b) {
   if constexpr (BF16) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    acc = h16_mfma(a, b, acc);
   } else {
     const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
@@ -133,7 +144,7 @@ static __device__ __forceinline__ void epi_views8(const ConvP& p, int64_t row, i
 // ---- training-mode epilogue (epi_mode != 0).  The kernels that support it keep the fp32 accumulators of a 32-row block in a wave-private
 // LDS tile for the row-vector stage anyway; the reductions reuse that tile: the row stage writes the quantity to be summed back to
 // its own place, then every lane adds ONE column over 16 rows (lane (fi, fh): column fi, rows 16 fh ..) and the two halves are combined.
-static __device__ __forceinline__ float round_to(float v, bool bf16) { return bf16 ? __uint_as_float(pack_bf16x2(v, 0.f) << 16) : v; }
+static __device__ __forceinline__ float round_to(float v, bool bf16) { return bf16 ? bf16_lo(pack_bf16x2(v, 0.f)) : v; }
 
 // row stage: v = acc of channels c0..c0+7 of `row` -> views written; on return v = the first summand (y, resp. g), q1 = the second
 // (y^2 is formed in the column pass, so q1 is only set for TL_EPI_BN_BWD: g * xhat)
@@ -305,6 +316,17 @@ int tl_launch_conv_win(const ConvP& p, hipStream_t s);                  // bf16,
 // tl_conv_small.hip
 int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s);     // few output rows: split the tap loop over waves
 int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s);   // Cin <= 8 (the 4-channel input conv)
+
+#ifndef TL_F16_BUILD
+// the float16 compilations of the same units (tl_half.h): inside them dtype TL_BF16 means "the 16-bit type"
+int tl_launch_conv_direct_f16(const ConvP& p, int dtype, hipStream_t s);
+int tl_launch_conv_ones27_f16(const ConvP& p, hipStream_t s);
+int tl_launch_conv_stream_f16(const ConvP& p, int dtype, hipStream_t s);
+int tl_launch_conv_streamq_f16(const ConvP& p, hipStream_t s);
+int tl_launch_conv_small_f16(const ConvP& p, int dtype, hipStream_t s);
+int tl_launch_conv_tinycin_f16(const ConvP& p, int dtype, hipStream_t s);
+int tl_launch_conv_bf16_f16(const ConvP& p, int depth, int units, hipStream_t s);
+#endif
 
 // tl_linear_small.hip
 int tl_launch_conv_tinycout(const ConvP& p, int dtype, hipStream_t s);  // K = 1, Cout <= 8 (the heads' output Linears)

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
       for (int w = 1; w < WV; ++w) v += red[w][r][lane];
       if constexpr (BF16) {
-        if (p.res) v += __uint_as_float((uint32_t)((const uint16_t*)p.res)[orow * p.res_ld + j] << 16);
+        if (p.res) v += bf16_lo((uint32_t)((const uint16_t*)p.res)[orow * p.res_ld + j]);
       } else {
         if (p.res) v += ((const float*)p.res)[orow * p.res_ld + j];
       }

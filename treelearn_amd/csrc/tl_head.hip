@@ -5,8 +5,17 @@
 // reference materialises (tree_learn.py:99) is never re-read; writing it back is optional.
 #include "tl_common.h"
 #include <hip/hip_bf16.h>
+#include "tl_half.h"
 
+#ifdef TL_F16_BUILD       // the float16 build of this unit (tl_half.h): tl_head_mlp_f16, reached from tl_head_mlp(dtype = TL_F16)
+#define tl_head_mlp tl_head_mlp_f16
+extern int g_head_mode;
+#else
 int g_head_mode = 0;      // developer A/B (tl_set_tuning "head_mode"): 1 = the scalar-weight kernel also for bf16 C = 32
+extern "C" int tl_head_mlp_f16(const void* feats, int64_t feats_ld, int dtype, int C, const int64_t* v2p, int64_t N, const float* pro_scale,
+                               const float* pro_shift, const float* w1, const float* b1, const float* w2, const float* b2, float* backbone,
+                               float* logits, float* offsets, tl_stream_t stream);
+#endif
 
 namespace {
 
@@ -30,7 +39,7 @@ __global__ void __launch_bounds__(256) k_head(const T* __restrict__ feats, int64
         const uint4 v = src[c];
         const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { f[8 * c + 2 * q] = __uint_as_float(u[q] << 16); f[8 * c + 2 * q + 1] = __uint_as_float(u[q] & 0xFFFF0000u); }
+        for (int q = 0; q < 4; ++q) { f[8 * c + 2 * q] = h16_lo(u[q]); f[8 * c + 2 * q + 1] = h16_hi(u[q]); }
       }
     }
     if (psc) {
@@ -66,16 +75,10 @@ __global__ void __launch_bounds__(256) k_head(const T* __restrict__ feats, int64
 // registers), B = the points' BatchNorm+ReLU'd feature rows (point x channel: lane (n, h) gathers 16-byte pieces h and 2 + h of
 // row v2p[n]) -- so that afterwards lane (n, h) holds 16 hidden units of point n; the output layer is 16 FMAs per output on
 // those, and one cross-half add.  Activations and W1 are rounded to bf16 for the MFMA (the backbone output stays fp32).
-typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
 typedef float hf32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t hu32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t head_pack_bf16x2(float lo, float hi) {      // round-to-nearest-even
-  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-  a += 0x7FFFu + ((a >> 16) & 1u);
-  b += 0x7FFFu + ((b >> 16) & 1u);
-  return (a >> 16) | (b & 0xFFFF0000u);
-}
+__device__ __forceinline__ uint32_t head_pack_bf16x2(float lo, float hi) { return h16_pack2(lo, hi); }      // round-to-nearest-even, this build's 16-bit type
 
 __global__ void __launch_bounds__(256) k_head_mfma32(const __hip_bfloat16* __restrict__ feats, int64_t ld, const int64_t* __restrict__ v2p, int64_t N,
                                                      const float* __restrict__ psc, const float* __restrict__ psh,
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256) k_head_mfma32(const __hip_bfloat16* __res
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
       float f[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(u[q] << 16); f[2 * q + 1] = __uint_as_float(u[q] & 0xFFFF0000u); }
+      for (int q = 0; q < 4; ++q) { f[2 * q] = h16_lo(u[q]); f[2 * q + 1] = h16_hi(u[q]); }
       if (psc) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) f[q] = fmaxf(fmaf(f[q], sc[s][q], sh[s][q]), 0.f);
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(256) k_head_mfma32(const __hip_bfloat16* __res
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, afrag[hh][s]), __builtin_bit_cast(hbf16x8, bfrag[s]), acc, 0, 0, 0);
+        acc = h16_mfma(afrag[hh][s], bfrag[s], acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float4 t = Tb[h][hh][r];
@@ -190,6 +193,7 @@ int launch_head(const void* feats, int64_t ld, int dtype, const int64_t* v2p, in
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
+#ifndef TL_F16_BUILD
 // ---------------------------------------------------------------- stable row compaction
 constexpr int kItems = 8, kTile = 256 * kItems;
 
@@ -234,6 +238,8 @@ __global__ void __launch_bounds__(256) k_mask_scatter(const float* __restrict__ 
   for (int j = 0; j < kItems; ++j) if (keep[j]) { for (int c = 0; c < C; ++c) out[(int64_t)pos * C + c] = in[(base + j) * C + c]; ++pos; }
 }
 
+#endif  // !TL_F16_BUILD
+
 }  // namespace
 
 extern "C" {
@@ -243,6 +249,10 @@ int tl_head_mlp(const void* feats, int64_t feats_ld, int dtype, int C, const int
                 float* logits, float* offsets, tl_stream_t stream) {
   if (!feats || !v2p || !w1 || !b1 || !w2 || !b2 || !logits || !offsets || N <= 0) return TL_ERR_ARG;
   if ((pro_scale == nullptr) != (pro_shift == nullptr)) return TL_ERR_ARG;
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16)      // the float16 compilation of this unit; inside it "TL_BF16" means "the 16-bit type"
+    return tl_head_mlp_f16(feats, feats_ld, TL_BF16, C, v2p, N, pro_scale, pro_shift, w1, b1, w2, b2, backbone, logits, offsets, stream);
+#endif
   if (dtype != TL_F32 && dtype != TL_BF16) return TL_ERR_ARG;
   if (feats_ld % 8 != 0 || ((uintptr_t)feats) % 16 != 0) return TL_ERR_ARG;
   hipStream_t s = tl_s(stream);
@@ -255,6 +265,7 @@ int tl_head_mlp(const void* feats, int64_t feats_ld, int dtype, int C, const int
   return TL_ERR_UNSUPPORTED;
 }
 
+#ifndef TL_F16_BUILD
 int64_t tl_compact_ws_words(int64_t n) { return tl_cdiv(n, kTile) + 1; }
 
 int tl_compact_rows(const float* in, int C, const uint8_t* mask, int64_t n, float* out, int32_t* count, int32_t* ws, tl_stream_t stream) {
@@ -267,5 +278,6 @@ int tl_compact_rows(const float* in, int C, const uint8_t* mask, int64_t n, floa
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
+#endif  // !TL_F16_BUILD
 
 }  // extern "C"

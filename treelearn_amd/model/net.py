@@ -64,8 +64,8 @@ class TreeLearn(nn.Module):
         """Build the fused inference plan (folded BatchNorms, packed weights) now, on the current stream.  Callers that spread
         forwards over several streams do this first: the plan is otherwise built by the first forward, on that forward's stream,
         and a forward on another stream could read weights that are still being packed."""
-        if not self.training and (self._plan is None or self._plan.dtype != self.active_dtype()):
-            self._plan = InferencePlan(self, self.active_dtype())
+        if not self.training and (self._plan is None or self._plan.dtype != self.active_dtype(False)):
+            self._plan = InferencePlan(self, self.active_dtype(False))
         return self
 
     def invalidate_plan(self):
@@ -116,16 +116,22 @@ class TreeLearn(nn.Module):
             vfeats = torch.ones((M, C), dtype=torch.float32, device=coords.device)
         return vfeats, geom
 
-    def active_dtype(self):
+    def active_dtype(self, training=None):
         """The dtype the sparse convs run in for this call.  Inside `torch.cuda.amp.autocast` / `torch.autocast("cuda")` -- how the
         reference selects mixed precision (tools/training/train.py:32 `autocast(enabled=config.fp16)`) -- it is the autocast dtype,
-        whatever `compute_dtype` says; the library has bf16 and fp32 kernels, so a float16 autocast region runs the bf16 kernels (same
-        storage width and matrix-core rate, fp32's exponent range: a GradScaler around the step stays finite and simply scales and
-        unscales).  Outside autocast: `compute_dtype`."""
+        whatever `compute_dtype` says; outside autocast: `compute_dtype`.  float16 exists for the inference path (TL_F16); the
+        training kernels (weight gradient, BatchNorm, epilogue reductions) are bf16 / fp32, so a float16 TRAINING region runs the bf16
+        kernels: same storage width and matrix-core rate, fp32's exponent range -- a GradScaler around the step stays finite and
+        simply scales and unscales."""
+        dt = self.compute_dtype
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
-            return torch.bfloat16 if dt in (torch.float16, torch.bfloat16) else torch.float32
-        return self.compute_dtype
+            if dt not in (torch.float16, torch.bfloat16):
+                dt = torch.float32
+        training = (self.training or torch.is_grad_enabled()) if training is None else training
+        if dt == torch.float16 and training:
+            dt = torch.bfloat16
+        return dt
 
     @cuda_cast
     def forward_backbone(self, coords, input_feats, batch_ids, batch_size, **kwargs):
@@ -152,8 +158,8 @@ class TreeLearn(nn.Module):
         Returns a handle for `infer`.  Calling `prepare(next_tile)` right after `infer(this_tile)` lets the next tile's
         geometry (small latency-bound kernels + two host syncs) run while this tile's convs occupy the main stream."""
         assert not self.training, "prepare/infer is the eval-mode fused path"
-        if self._plan is None or self._plan.dtype != self.active_dtype():
-            self._plan = InferencePlan(self, self.active_dtype())
+        if self._plan is None or self._plan.dtype != self.active_dtype(False):
+            self._plan = InferencePlan(self, self.active_dtype(False))
         if self._geom_stream is None:
             self._geom_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
@@ -196,7 +202,7 @@ class TreeLearn(nn.Module):
             except AttributeError:
                 pass
         backbone_feats = gather_rows(backbone_output.features, v2p_map, cache)
-        if not (self.training and backbone_feats.dtype == torch.bfloat16 and os.environ.get("TL_HEAD_FP32") != "1"):
+        if not (self.training and torch.is_grad_enabled() and backbone_feats.dtype == torch.bfloat16 and os.environ.get("TL_HEAD_FP32") != "1"):
             backbone_feats = backbone_feats.float()
         # mixed-precision TRAINING keeps the heads in bf16 like the backbone (the reference's autocast runs their nn.Linear layers in
         # half precision too; get_loss casts logits / offsets to fp32): half the traffic of the gather, the two MLPs and their backward
