@@ -73,6 +73,14 @@ def main():
         print("  kernel families (ms, dispatches):")
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:45]:
             print(f"    {k:44s} {v[0] / 1e6:8.3f} {v[1]:5d}")
+        ind = collections.defaultdict(lambda: [0, 0, 0])
+        for s_, e_, n_ in seg:
+            if "k_" in n_:
+                k_ = re.sub(r"\(anonymous namespace\)::|void |\(ConvP.*|\(unsigned short const.*|\(void const.*|\(float const.*|\(double const.*", "", n_)[:90]
+                d_ = ind[k_]; d_[0] += e_ - s_; d_[1] += 1; d_[2] = max(d_[2], e_ - s_)
+        print("  individual kernels (total ms, dispatches, mean us, max us):")
+        for k, v in sorted(ind.items(), key=lambda kv: -kv[1][0])[:40]:
+            print(f"    {v[0] / 1e6:8.3f} {v[1]:5d} {v[0] / v[1] / 1e3:8.1f} {v[2] / 1e3:8.1f}  {k}")
         at = collections.defaultdict(lambda: [0, 0])
         for s_, e_, n_ in seg:
             if "at::" in n_ or "rocclr" in n_:
