@@ -214,6 +214,16 @@ int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed,
 /* Weights of the input-gradient ("dgrad") conv of the same layer, for tl_conv_fwd over the transposed rulebook: w_t[k][ci][co] =
  * w_ref[co][flip ? K-1-k : k][ci] (taps flip for SubM convs: nbr[k][o] = i <=> nbr[K-1-k][i] = o), with dtype conversion. */
 int tl_pack_weight_dgrad(const float* w_ref, int Cout, int K, int Cin, int flip, void* w_t, int dtype, tl_stream_t stream);
+/* All three packings for many layers in ONE launch (a training step re-packs every conv weight after the optimizer: ~210 launches per
+ * step otherwise).  descs (DEVICE array): src = the fp32 parameter [Cout][K][Cin], dst = the packed tensor in `dtype`, form 0 = tl_pack_weight,
+ * 1 = tl_pack_weight_frag, 2 / 3 = tl_pack_weight_dgrad without / with flipped taps.  blocks (DEVICE, i32[n_blocks][2]): workgroup b writes
+ * the 4096 output elements of descriptor blocks[b][0] starting at element 4096 * blocks[b][1]. */
+typedef struct tl_pack_desc {
+  const float* src;
+  void* dst;
+  int32_t Cout, K, Cin, form;
+} tl_pack_desc;
+int tl_pack_weights_batch(const tl_pack_desc* descs, const int32_t* blocks, int64_t n_blocks, int dtype, tl_stream_t stream);
 /* Same weights in fragment order (Cout % 32 == 0, Cin % 32 == 0): [K][Cout/32][Cin/32][J][64 lanes][16 B], where lane
  * (fi = lane & 31, fh = lane >> 5) of 16-B piece j holds W[k][32 cb + fi][32 ch + (32 j + 16 fh) / sizeof(elem) ...]:
  * the B operand of one 32x32 MFMA step is one contiguous 1 KB block (J = 2 for bf16, 4 for fp32). */

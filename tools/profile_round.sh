@@ -18,4 +18,8 @@ python bench.py --workload config3 --steps 4 --warmup 2 > $O/bench_config3.json 
 python bench.py --workload config5 $Q > $O/bench_config5.json 2> $O/bench_config5.err
 python bench.py --workload config4 $Q > $O/bench_config4.json 2> $O/bench_config4.err
 mkdir -p $O/c3; rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o p -- python3 bench.py --workload config3 --steps 4 --warmup 2 > $O/bench_config3_profiled.json 2> $O/c3.err
+python tools/trace_gaps.py $O/c3 > $O/config3_timeline.txt 2>&1
+find $O/c3 -name "*kernel_trace.csv" -delete
+python tools/dev_train_host.py > $O/config3_phases.txt 2>&1
+python tools/dev_wgrad_dense.py > $O/wgrad_dense_vs_pair_list.txt 2>&1
 tail -c 400 $O/bench_unprofiled.json; ls $O/*

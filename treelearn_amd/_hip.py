@@ -78,6 +78,7 @@ PROTOTYPES = {
     "tl_bn_train_bwd_from_parts": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "tl_pack_weights_batch": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "tl_pack_weight_dgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_conv_wgrad_ws_floats": (_i64, [_i64, _i32, _i32, _i32]),
     "tl_conv_wgrad": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),

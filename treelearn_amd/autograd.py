@@ -48,6 +48,84 @@ def _conv_with_stats(x, w_packed, ref, residual, holder):
     return ops.conv_fwd(x, w_packed, ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
 
 
+_dgrad_cache = {}           # id(parameter) -> (weakref, (version, dtype, device, data_ptr, flip), [K, Cin, Cout] weights of the input-gradient conv)
+
+
+def _packed_dgrad(weight, dtype, flip):
+    """W[k]^T (taps flipped for SubM) for the layer's input-gradient conv, cached like `_packed`."""
+    key = (weight._version, dtype, weight.device, weight.data_ptr(), bool(flip))
+    hit = _dgrad_cache.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2]
+    w = ops.pack_weight_dgrad(weight, dtype, flip)
+    if hit is None or hit[0]() is not weight:
+        weakref.finalize(weight, _dgrad_cache.pop, id(weight), None)
+    _dgrad_cache[id(weight)] = (weakref.ref(weight), key, w)
+    return w
+
+
+class PackPlan:
+    """Every conv weight of a model packed in ONE launch per optimizer step (tl_pack_weights_batch): the kernel layout, its
+    fragment-order copy and the input-gradient layout, into persistent buffers; the per-parameter caches above are then hits for the
+    whole step.  `convs`: [(weight parameter [Cout,k,k,k,Cin], flip)] with flip = taps flip in the input-gradient conv (SubM)."""
+
+    def __init__(self, convs, dtype):
+        import ctypes
+        from . import _hip
+        self.dtype = dtype
+        self.params = [w for w, _ in convs]
+        self.sig = None
+        dev = self.params[0].device
+        self.out = []                                                   # per conv: (packed, frag or None, dgrad)
+        descs, blocks = [], []
+
+        def add(w, dst, form, co, K, ci):
+            n = co * K * ci
+            descs.append((w.data_ptr(), dst.data_ptr(), co, K, ci, form))
+            blocks.extend((len(descs) - 1, b) for b in range((n + 4095) // 4096))
+        for w, flip in convs:
+            co, ci = w.shape[0], w.shape[-1]
+            K = w.numel() // (co * ci)
+            pk = torch.empty((K, co, ci), dtype=dtype, device=dev)
+            add(w, pk, 0, co, K, ci)
+            fr = None
+            if co % 32 == 0 and ci % 32 == 0 and K > 1:
+                fr = torch.empty(K * co * ci, dtype=dtype, device=dev)
+                add(w, fr, 1, co, K, ci)
+                pk._tl_frag = fr
+            dg = torch.empty((K, ci, co), dtype=dtype, device=dev)
+            add(w, dg, 3 if flip else 2, co, K, ci)
+            self.out.append((pk, fr, dg, bool(flip)))
+
+        class _D(ctypes.Structure):
+            _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("Cin", ctypes.c_int32), ("form", ctypes.c_int32)]
+        arr = (_D * len(descs))(*[_D(*d) for d in descs])
+        self.descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32).to(dev)
+        self.ptrs = tuple(w.data_ptr() for w in self.params)
+
+    def valid_for(self, convs, dtype):
+        return dtype == self.dtype and len(convs) == len(self.params) and all(a is b for (a, _), b in zip(convs, self.params)) \
+            and tuple(w.data_ptr() for w in self.params) == self.ptrs
+
+    def refresh(self):
+        from . import _hip
+        sig = tuple(w._version for w in self.params)
+        if sig == self.sig:
+            return
+        L = _hip.lib()
+        _hip.check(L.tl_pack_weights_batch(_hip.ptr(self.descs), _hip.ptr(self.blocks), self.blocks.shape[0], _hip.dtype_code(self.dtype), _hip.stream()),
+                   "tl_pack_weights_batch")
+        self.sig = sig
+        for w, (pk, fr, dg, flip) in zip(self.params, self.out):
+            for cache, key, val in ((_packed_cache, (w._version, self.dtype, w.device, w.data_ptr()), pk),
+                                    (_dgrad_cache, (w._version, self.dtype, w.device, w.data_ptr(), flip), dg)):
+                hit = cache.get(id(w))
+                if hit is None or hit[0]() is not w:
+                    weakref.finalize(w, cache.pop, id(w), None)
+                cache[id(w)] = (weakref.ref(w), key, val)
+
+
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, ref, residual, holder=None):

@@ -49,7 +49,8 @@ def _wgrad_param(x, grad_out, ref, K, weight):
 
 def _dgrad_weight(weight, ref, dtype):
     """[K]["Cout" = Cin]["Cin" = Cout] weights of the input-gradient conv: W[k]^T, taps flipped for SubM."""
-    return ops.pack_weight_dgrad(weight, dtype, ref.flip)
+    from .autograd import _packed_dgrad
+    return _packed_dgrad(weight, dtype, ref.flip)
 
 
 def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, gskip):

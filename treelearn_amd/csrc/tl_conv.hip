@@ -239,6 +239,38 @@ __global__ void k_pack_weight_frag(const float* __restrict__ w, int Cout, int K,
   }
 }
 
+// Every conv weight of a model in ONE launch (training: the optimizer changes all of them each step; per-layer packing was ~210 launches).
+// Workgroup b serves 4096 consecutive output elements of ONE descriptor (blocks[b] = {descriptor, first element}); forms: 0 = [K][Cout][Cin],
+// 1 = fragment order (k_pack_weight_frag), 2 / 3 = the input-gradient layout [K][Cin][Cout] without / with flipped taps.
+__global__ void __launch_bounds__(256) k_pack_batch(const tl_pack_desc* __restrict__ descs, const int2* __restrict__ blocks, int dtype) {
+  const int2 bd = blocks[blockIdx.x];
+  const tl_pack_desc d = descs[bd.x];
+  const int64_t total = (int64_t)d.Cout * d.K * d.Cin;
+  const int EB = dtype == TL_F32 ? 4 : 2, EPV = 16 / EB;
+  for (int i = 0; i < 16; ++i) {
+    const int64_t t = (int64_t)bd.y * 4096 + i * 256 + threadIdx.x;
+    if (t >= total) break;
+    float v;
+    if (d.form == 0) {
+      const int c = (int)(t % d.Cin); const int64_t r = t / d.Cin; const int j = (int)(r % d.Cout); const int k = (int)(r / d.Cout);
+      v = d.src[((int64_t)j * d.K + k) * d.Cin + c];
+    } else if (d.form == 1) {
+      const int J = 32 * EB / 32, CB = d.Cout / 32, CH = d.Cin / 32;
+      const int64_t vec = t / EPV; const int e = (int)(t % EPV);
+      const int lane = (int)(vec & 63); int64_t r = vec >> 6;
+      const int j = (int)(r % J); r /= J; const int ch = (int)(r % CH); r /= CH; const int cb = (int)(r % CB); const int k = (int)(r / CB);
+      const int col = cb * 32 + (lane & 31), c0 = ch * 32 + (32 * j + 16 * (lane >> 5)) / EB;
+      v = d.src[((int64_t)col * d.K + k) * d.Cin + c0 + e];
+    } else {
+      const int co = (int)(t % d.Cout); const int64_t r = t / d.Cout; const int ci = (int)(r % d.Cin); const int k = (int)(r / d.Cin);
+      v = d.src[((int64_t)co * d.K + (d.form == 3 ? d.K - 1 - k : k)) * d.Cin + ci];
+    }
+    if (dtype == TL_F32) reinterpret_cast<float*>(d.dst)[t] = v;
+    else if (dtype == TL_F16) reinterpret_cast<_Float16*>(d.dst)[t] = (_Float16)v;
+    else reinterpret_cast<__hip_bfloat16*>(d.dst)[t] = __float2bfloat16(v);
+  }
+}
+
 template <typename T>
 __global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld, int64_t n, int C,
                               const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
@@ -473,6 +505,13 @@ int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed,
 int tl_pack_weight_dgrad(const float* w_ref, int Cout, int K, int Cin, int flip, void* w_t, int dtype, tl_stream_t stream) {
   if (!w_ref || !w_t || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16 && dtype != TL_F16)) return TL_ERR_ARG;
   k_pack_weight_dgrad<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, flip, w_t, dtype);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_pack_weights_batch(const tl_pack_desc* descs, const int32_t* blocks, int64_t n_blocks, int dtype, tl_stream_t stream) {
+  if (!descs || !blocks || n_blocks <= 0 || n_blocks > 0x7FFFFFFF || (dtype != TL_F32 && dtype != TL_BF16 && dtype != TL_F16)) return TL_ERR_ARG;
+  k_pack_batch<<<(unsigned)n_blocks, 256, 0, tl_s(stream)>>>(descs, reinterpret_cast<const int2*>(blocks), dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

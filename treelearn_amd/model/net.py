@@ -68,6 +68,18 @@ class TreeLearn(nn.Module):
             self._plan = InferencePlan(self, self.active_dtype(False))
         return self
 
+    def _refresh_packed(self, dtype):
+        """Training: all conv weights -> kernel layouts in ONE launch when any parameter changed (autograd.PackPlan), instead of three small
+        launches per layer and step."""
+        from ..autograd import PackPlan
+        convs = [(m.weight, bool(m.subm) and int(m.kernel_size) == 3) for m in self.modules()
+                 if isinstance(m, spconv.SparseConvolution) and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or not plan.valid_for(convs, dtype):
+            plan = self._pack_plan = PackPlan(convs, dtype) if convs else None
+        if plan is not None:
+            plan.refresh()
+
     def invalidate_plan(self):
         """Drop the folded-BN / packed-weight cache (call after mutating parameters in place)."""
         self._plan = None
@@ -143,6 +155,8 @@ class TreeLearn(nn.Module):
             x = spconv.SparseConvTensor(vfeats, lv.coords, list(lv.shape), batch_size, geometry=geom, level=0)
             prev = spconv.SparseConvolution.amp_dtype
             spconv.SparseConvolution.amp_dtype = None if dtype == torch.float32 else dtype
+            if torch.is_grad_enabled() and os.environ.get("TL_PACK_BATCH", "1") != "0":
+                self._refresh_packed(dtype)                           # every conv weight packed in one launch (once per optimizer step)
             try:                                                       # 16-bit: mixed precision as under the reference's autocast
                 x = self.output_layer(self.unet(self.input_conv(x)))
             finally:
