@@ -889,6 +889,16 @@ def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     e = ops.conv_wgrad(xb.float(), gb.float(), tab, n_out, K)
     assert torch.equal(c, c2)
     assert rel_err(c.cpu().numpy(), e.cpu().numpy()) < 2e-5
+    if K == 27 and n_out >= 60000 and cin >= 32:                                     # dense-over-taps: the register-staged form of the same kernel
+        from treelearn_amd import _hip
+        _hip.lib().tl_set_tuning(b"wgrad_dma", 0)
+        try:
+            c3 = ops.conv_wgrad(xb, gb, tab, n_out, K)
+        finally:
+            _hip.lib().tl_set_tuning(b"wgrad_dma", 1)
+        assert rel_err(c3.cpu().numpy(), c.cpu().numpy()) < 2e-5
+        if (cin, cout) in ((32, 32), (96, 96), (192, 96), (128, 128), (256, 128)):   # same slot count in both forms -> same summation order
+            assert torch.equal(c3, c)
     if cin % 4 == 0:                                                                 # the parameter's own layout [Cout, K, Cin] straight from the reduction
         assert torch.equal(ops.conv_wgrad(xb, gb, tab, n_out, K, ref_layout=True), c.permute(1, 0, 2).contiguous())
         assert torch.equal(ops.conv_wgrad(wide[:, 8:], torch.from_numpy(g).to(d), tab, n_out, K, ref_layout=True), a.permute(1, 0, 2).contiguous())

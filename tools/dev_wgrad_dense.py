@@ -25,9 +25,15 @@ for li, lv in enumerate(geom.levels[:4]):
         x = torch.randn(lv.n, ci, device="cuda").bfloat16(); g = torch.randn(lv.n, co, device="cuda").bfloat16()
         L.tl_set_tuning(b"wgrad_dense", 0)
         ref = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27); t0 = timeit(lambda: ops.conv_wgrad(x, g, lv.nbr, lv.n, 27))
-        L.tl_set_tuning(b"wgrad_dense", 1)
+        L.tl_set_tuning(b"wgrad_dense", 1); L.tl_set_tuning(b"wgrad_dma", 0)
         new = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27); new2 = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27)
         t1 = timeit(lambda: ops.conv_wgrad(x, g, lv.nbr, lv.n, 27))
+        for var, gxo in ((1, 0),):
+            L.tl_set_tuning(b"wgrad_dma", var); L.tl_set_tuning(b"wgrad_dense_gx", gxo)
+            dma = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27)
+            t2 = timeit(lambda: ops.conv_wgrad(x, g, lv.nbr, lv.n, 27))
+            print(f"    LDS-DMA form variant {var} slots {gxo or 'table'}: {t2:7.3f} ms, max |dma - dense| / max |dense| = {float((dma - new).abs().max() / new.abs().max()):.2e}")
+        L.tl_set_tuning(b"wgrad_dma", 1); L.tl_set_tuning(b"wgrad_dense_gx", 0)
         err = float((new - ref).abs().max() / ref.abs().max())
         pairs = int((lv.nbr >= 0).sum())
         print(f"l{li+1} {ci:3d}->{co:3d} rows {lv.n:8d} pairs/row {pairs / lv.n:5.2f}: pair-list {t0:7.3f} ms, dense {t1:7.3f} ms "

@@ -335,6 +335,7 @@ extern int g_head_mode;                           // tl_head.hip
 extern int g_wgrad_dense;                         // tl_wgrad_dense.hip
 extern int64_t g_wgrad_dense_min_rows;
 extern int g_wgrad_rows;                          // tl_wgrad_rows.hip
+extern int g_wgrad_dma, g_wgrad_dense_gx;         // tl_wgrad_dense.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
@@ -368,6 +369,8 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "dbg")) { g_dbg = (int)value; return TL_OK; }
   if (!strcmp(key, "wgrad_dense")) { g_wgrad_dense = (int)value; return TL_OK; }
   if (!strcmp(key, "wgrad_rows")) { g_wgrad_rows = (int)value; return TL_OK; }
+  if (!strcmp(key, "wgrad_dma")) { g_wgrad_dma = (int)value; return TL_OK; }
+  if (!strcmp(key, "wgrad_dense_gx")) { g_wgrad_dense_gx = (int)value; return TL_OK; }
   if (!strcmp(key, "wgrad_dense_min_rows")) { g_wgrad_dense_min_rows = value; return TL_OK; }
   return TL_ERR_ARG;
 }

@@ -209,6 +209,213 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense(const uint16_t* __restr
       }
 }
 
+// The same kernel with the gathers staged by LDS-DMA (`buffer_load ... lds`: global -> LDS without passing through registers).  PMC on the
+// register-staged form (profiles/r3_wgrad/): no LDS bank conflicts, MFMA pipes busy 31 %, waves parked 44 % of their cycles, LDS
+// instructions more than half of what a wave issues -- and 9 waves of 142 VGPRs per CU with 8 KB of gathers in flight each, i.e. the
+// kernel is bound by how many bytes are in flight against the L2 round trip.  Here a wave owns a RING of NR row tiles in LDS: the DMA of
+// step t + NR - 1 is issued at step t into the slot step t - 1 just read (no staging registers: 14 waves of <= 128 VGPRs per CU, and no
+// ds_write instructions), the source-side swizzle (lane L fetches piece (L % PRX) ^ swz(row) so that the contiguous 1 KB a DMA
+// instruction writes IS the swizzled tile), counted `s_waitcnt vmcnt(N)` with N fixed per unrolled step (vmcnt retires in order; the gout /
+// rulebook loads of a block start are part of the count), raw `s_barrier` (a `__syncthreads()` would drain the DMAs).  Absent neighbours:
+// the out-of-range lanes of a DMA write zeros.  Same results bit for bit (same summation order).
+template <int NBO, int NBIW, int KS, int NR, int NW>
+__global__ void __launch_bounds__(NW * 64) k_wgrad_dense_dma(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
+                                                             const int32_t* __restrict__ table, int64_t n_out, int64_t n_in, int K, int Cin, int NS,
+                                                             int nmb, float* __restrict__ ws) {
+  constexpr int NT = NW * 64;
+  constexpr int COUT = NBO * 32, CS = NBIW * 32, PG = COUT * 2, PX = CS * 2, ROWS = 16 * KS, SPM = 4, MBR = ROWS * SPM;
+  constexpr int PRG = COUT / 8, PRX = CS / 8;
+  constexpr int NPT = (MBR * PRG + NT - 1) / NT;
+  constexpr int NL = ROWS * PRX / 64;
+  constexpr int SLOT = ROWS * PX;
+  static_assert(ROWS * PRX % 64 == 0 && SLOT == NL * 1024 && NR >= 2 && NR <= 9, "configuration");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* Gs = smem;                                                 // [2][MBR][PG]
+  char* Xs = smem + 2 * MBR * PG + wv * (NR * SLOT);               // wave-private ring [NR][ROWS][PX]
+
+  const int job = (int)blockIdx.y * NW + wv;
+  const int tap = job / NS, slice = job % NS;
+  const bool active = tap < K;
+  const int bx = (int)blockIdx.x, nslot = (int)gridDim.x >> 3, xcd = bx & 7, slot = bx >> 3;
+  const int m8 = (nmb + 7) >> 3;
+  const int m_lo = xcd * m8 + slot, m_hi = min(nmb, (xcd + 1) * m8);
+  const int niter = m_lo < m_hi ? (m_hi - 1 - m_lo) / nslot + 1 : 0;
+  auto mb_of = [&](int it) { return it < niter ? m_lo + it * nslot : -1; };
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n_in * x_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n_out * g_ld * 2), 0x00020000);
+  const unsigned x_ld_b = (unsigned)(x_ld * 2);
+
+  // DMA pattern: instruction i writes LDS bytes [1024 i + 16 lane, +16) of the slot = tile row q / PRX, piece slot q % PRX (q = lane + 64 i),
+  // which must hold piece (q % PRX) ^ swz(row) of the gathered row
+  int xrow[NL]; unsigned xcol[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int q = lane + 64 * i, r = q / PRX, ps = q % PRX;
+    xrow[i] = r;
+    xcol[i] = (unsigned)((slice * CS + (ps ^ swz<PX>(r)) * 8) * 2);
+  }
+  const int fi = lane & 31, fh = lane >> 5, ti = lane & 15, tg = (lane >> 4) & 1;
+  const int prow = 8 * fh + (ti >> 2);
+  int ga[NBO], xa[NBIW];
+#pragma unroll
+  for (int a = 0; a < NBO; ++a) ga[a] = prow * PG + (((4 * a + 2 * tg + ((ti & 3) >> 1)) ^ swz<PG>(prow)) << 4) + 8 * (ti & 1);
+#pragma unroll
+  for (int b = 0; b < NBIW; ++b) xa[b] = prow * PX + (((4 * b + 2 * tg + ((ti & 3) >> 1)) ^ swz<PX>(prow)) << 4) + 8 * (ti & 1);
+
+  f32x16 acc[NBO][NBIW];
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBIW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  auto idx_load = [&](int it, int (&dst)[KS]) __attribute__((always_inline)) {
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int64_t row = (int64_t)mb * MBR + kk * 64 + lane;
+      dst[kk] = (mb >= 0 && active && row < n_out) ? table[(int64_t)tap * n_out + row] : -1;
+    }
+  };
+  auto g_load = [&](int it, u32x4 (&dst)[NPT]) __attribute__((always_inline)) {
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * NT, r = q / PRG, pc = q % PRG;
+      const int64_t row = (int64_t)mb * MBR + r;
+      const bool ok = mb >= 0 && row < n_out && (NPT * NT == MBR * PRG || q < MBR * PRG);
+      const unsigned off = ok ? (unsigned)(row * g_ld * 2) + (unsigned)(pc * 16) : 0xFFFFFFFFu;
+      dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 0));
+    }
+  };
+  auto g_store = [&](int buf, const u32x4 (&src)[NPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * NT, r = q / PRG, pc = q % PRG;
+      if (NPT * NT == MBR * PRG || q < MBR * PRG) *reinterpret_cast<u32x4*>(Gs + buf * (MBR * PG) + r * PG + ((pc ^ swz<PG>(r)) << 4)) = src[i];
+    }
+  };
+  // DMA of step s (0 .. SPM-1) of a macro block whose rulebook entries are `idx` into ring slot `rs`
+  auto x_dma = [&](int s, const int (&idx)[KS], int rs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int rmb = s * ROWS + xrow[i];
+      const int e = __builtin_amdgcn_ds_bpermute((rmb & 63) << 2, idx[(s * ROWS) >> 6]);
+      const unsigned off = (unsigned)e * x_ld_b + xcol[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(Xs + rs * SLOT + i * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+  // VMEM operations younger than the DMA of the step being consumed, per position s in the macro block: the DMAs of the NR - 1 steps
+  // issued since, plus the (gout, rulebook) loads of every block start among them (issued BEFORE that step's DMA)
+  auto younger = [](int s) constexpr {
+    int c = 0;
+    for (int j = 0; j <= NR - 2; ++j) if (((s - j) % SPM + SPM) % SPM == 0) ++c;
+    return (NR - 1) * NL + c * (NPT + KS);
+  };
+
+  if (niter > 0) {
+  int idx0[KS], idx1[KS], idx2[KS], idx3[KS];
+  idx_load(0, idx0); idx_load(1, idx1); idx_load(2, idx2);
+  {
+    u32x4 g0[NPT];
+    g_load(0, g0);
+    g_store(0, g0);
+  }
+  int head = 0;                                                    // ring slot of the step about to be consumed
+  const unsigned gs_off = (unsigned)(uintptr_t)(lds_ptr)Gs, xs_off = (unsigned)(uintptr_t)(lds_ptr)Xs;
+#pragma unroll
+  for (int d = 0; d < NR - 1; ++d) {                               // steps 0 .. NR-2 of the first blocks
+    if (d / SPM == 0) x_dma(d % SPM, idx0, d);
+    else if (d / SPM == 1) x_dma(d % SPM, idx1, d);
+    else x_dma(d % SPM, idx2, d);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  for (int it = 0; it < niter; ++it) {
+    u32x4 gn[NPT];
+    const unsigned gc_off = gs_off + (unsigned)((it & 1) * (MBR * PG));
+#pragma unroll
+    for (int s = 0; s < SPM; ++s) {
+      if (s == 0) { g_load(it + 1, gn); idx_load(it + 3, idx3); }
+      // the slot read in the previous step is free (its fragments fed MFMAs that were issued already): DMA of step s + NR - 1
+      {
+        constexpr int dummy = 0; (void)dummy;
+        const int sn = s + NR - 1;
+        const int rs = head == 0 ? NR - 1 : head - 1;
+        if (sn / SPM == 0) x_dma(sn % SPM, idx0, rs);
+        else if (sn / SPM == 1) x_dma(sn % SPM, idx1, rs);
+        else x_dma(sn % SPM, idx2, rs);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      switch (s) {                                                 // everything up to this step's DMA has landed
+        case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger(0)) : "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger(1)) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger(2)) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger(3)) : "memory"); break;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the fragment reads are inline assembly: a DS read the compiler can see is preceded by `s_waitcnt vmcnt(0)` while any LDS-DMA
+      // is outstanding (it cannot tell the slots apart), which would serialise the ring
+      const unsigned xb = xs_off + (unsigned)(head * SLOT);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x2 Ah[NBO][2], Bh[NBIW][2];
+#pragma unroll
+        for (int a = 0; a < NBO; ++a) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(Ah[a][0]) : "v"(gc_off + (unsigned)ga[a]), "n"((s * ROWS + 16 * ks) * PG));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(Ah[a][1]) : "v"(gc_off + (unsigned)ga[a]), "n"((s * ROWS + 16 * ks + 4) * PG));
+        }
+#pragma unroll
+        for (int b = 0; b < NBIW; ++b) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(Bh[b][0]) : "v"(xb + (unsigned)xa[b]), "n"((16 * ks) * PX));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(Bh[b][1]) : "v"(xb + (unsigned)xa[b]), "n"((16 * ks + 4) * PX));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 A[NBO], B[NBIW];
+#pragma unroll
+        for (int a = 0; a < NBO; ++a) {
+          asm volatile("" : "+v"(Ah[a][0]), "+v"(Ah[a][1]));       // orders the consumers after the wait
+          A[a][0] = Ah[a][0][0]; A[a][1] = Ah[a][0][1]; A[a][2] = Ah[a][1][0]; A[a][3] = Ah[a][1][1];
+        }
+#pragma unroll
+        for (int b = 0; b < NBIW; ++b) {
+          asm volatile("" : "+v"(Bh[b][0]), "+v"(Bh[b][1]));
+          B[b][0] = Bh[b][0][0]; B[b][1] = Bh[b][0][1]; B[b][2] = Bh[b][1][0]; B[b][3] = Bh[b][1][1];
+        }
+#pragma unroll
+        for (int a = 0; a < NBO; ++a)
+#pragma unroll
+          for (int b = 0; b < NBIW; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      head = head + 1 == NR ? 0 : head + 1;
+    }
+    g_store((it + 1) & 1, gn);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) { idx0[kk] = idx1[kk]; idx1[kk] = idx2[kk]; idx2[kk] = idx3[kk]; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the DMAs issued past the end (all out of range) before the slots' memory is given back
+  }
+
+  if (!active) return;
+  float* wp = ws + (((int64_t)bx * K + tap) * COUT) * (int64_t)Cin + slice * CS;
+#pragma unroll
+  for (int a = 0; a < NBO; ++a)
+#pragma unroll
+    for (int b = 0; b < NBIW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ci = b * 32 + fi;
+        wp[(int64_t)co * Cin + ci] = acc[a][b][r];
+      }
+}
+
 // gw[e] = sum over the partial tile sets.  A workgroup = 16 float4 elements x 16 part lanes: lane pl adds parts pl, pl + 16, ... (up to
 // 8 loads, all in flight together), the sixteen lane sums are added in lane order through LDS: deterministic, and the partials -- just
 // written by the weight-gradient kernel -- stream out of L2 / Infinity Cache with thousands of loads in flight instead of one chain
@@ -261,7 +468,27 @@ int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, con
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
+template <int NBO, int NBIW, int KS, int NR, int NW>
+int launch_dma(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin, int NS,
+               int gx, float* ws, hipStream_t s) {
+  constexpr int MBR = 64 * KS;
+  const size_t lds = 2 * (size_t)MBR * NBO * 64 + (size_t)NW * NR * (16 * KS) * (NBIW * 64);
+  if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_dense_dma<NBO, NBIW, KS, NR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return TL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nmb = (int)tl_cdiv(n_out, MBR);
+  const int gy = (int)tl_cdiv((int64_t)K * NS, NW);
+  k_wgrad_dense_dma<NBO, NBIW, KS, NR, NW><<<dim3((unsigned)gx, (unsigned)gy), NW * 64, lds, s>>>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, NS, nmb, ws);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
 }  // namespace
+
+int g_wgrad_dma = 1;              // tl_set_tuning("wgrad_dma", 0): the register-staged form everywhere
 
 // shared with tl_wgrad.hip: gw = ordered sum of `nparts` partial tile sets of `per` floats (per % 4 == 0, 16-B aligned)
 int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K, int Cout, int Cin, int ref_layout) {
@@ -274,19 +501,34 @@ int g_wgrad_dense = 1;            // tl_set_tuning("wgrad_dense", 0) restores th
 int64_t g_wgrad_dense_min_rows = 60000;
 
 // row slots (= partial tile sets) of the dense form for a shape, 0 if the shape is not served
+int g_wgrad_dense_gx = 0;          // tl_set_tuning("wgrad_dense_gx", n): slot count override (experiments)
+
 int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout) {
   if (!g_wgrad_dense || K != 27 || n_out < g_wgrad_dense_min_rows) return 0;
   const int key = Cin * 1000 + Cout;
-  switch (key) {
-    case 32032: case 64032: return 128;                  // 27 jobs: 2 workgroups of 14 waves per slot
-    case 64064: return 80;                               // 27 jobs: 3 workgroups of 9 waves (170 registers each) per slot
-    case 128064: return 40;                              // 54 jobs: 6 workgroups of 9 waves per slot
-    case 96096: return 40;                               // 81 jobs (27 taps x 3 slices of 32 channels): 6 workgroups per slot
-    case 192096: return 16;                              // 162 jobs: 12 workgroups per slot
-    case 128128: return 32;                              // 108 jobs (27 taps x 4 slices): 8 workgroups per slot
-    case 256128: return 16;                              // 216 jobs: 16 workgroups per slot
+  int gx = 0;
+  if (g_wgrad_dma) {
+    switch (key) {                                         // 14 waves of <= 128 registers per workgroup, one workgroup per CU
+      case 32032: case 64032: case 64064: gx = 128; break; // 27 jobs: 2 workgroups per slot
+      case 128064: gx = 64; break;                         // 54 jobs: 4 workgroups per slot
+      case 96096: gx = 40; break;                          // 81 jobs: 6 per slot
+      case 192096: gx = 64; break;                         // 162 jobs: 12 per slot, 768 workgroups = 3 per CU
+      case 128128: gx = 32; break;
+      case 256128: gx = 16; break;
+    }
+  } else {
+    switch (key) {
+      case 32032: case 64032: gx = 128; break;             // 27 jobs: 2 workgroups of 14 waves per slot
+      case 64064: gx = 80; break;                          // 27 jobs: 3 workgroups of 9 waves (170 registers each) per slot
+      case 128064: gx = 40; break;                         // 54 jobs: 6 workgroups of 9 waves per slot
+      case 96096: gx = 40; break;                          // 81 jobs (27 taps x 3 slices of 32 channels): 6 workgroups per slot
+      case 192096: gx = 64; break;                         // 162 jobs: 12 workgroups per slot (768 = 3 per CU; 16 slots left a quarter of the CUs idle)
+      case 128128: gx = 32; break;                         // 108 jobs (27 taps x 4 slices): 8 workgroups per slot
+      case 256128: gx = 16; break;                         // 216 jobs: 16 workgroups per slot
+    }
   }
-  return 0;
+  if (gx && g_wgrad_dense_gx) gx = g_wgrad_dense_gx & ~7;
+  return gx;
 }
 
 int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
@@ -294,7 +536,18 @@ int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, in
   const int gx = tl_wgrad_dense_slots(n_out, K, Cin, Cout);
   if (!gx || !table) return TL_ERR_UNSUPPORTED;
   int rc = TL_ERR_UNSUPPORTED;
-  switch (Cin * 1000 + Cout) {
+#define TL_DMA(NBO, NBIW, KS, NR, NW, NS) launch_dma<NBO, NBIW, KS, NR, NW>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, NS, gx, ws, s)
+  if (g_wgrad_dma) switch (Cin * 1000 + Cout) {            // 64 -> 32 measured no faster than the register-staged form: not here
+    case 32032: rc = TL_DMA(1, 1, 2, 4, 14, 1); break;
+    case 64064: rc = TL_DMA(2, 2, 1, 4, 14, 1); break;
+    case 128064: rc = TL_DMA(2, 2, 1, 4, 14, 2); break;
+    case 96096: rc = TL_DMA(3, 1, 2, 4, 14, 3); break;
+    case 192096: rc = TL_DMA(3, 1, 2, 4, 14, 6); break;
+    case 128128: rc = TL_DMA(4, 1, 1, 8, 14, 4); break;
+    case 256128: rc = TL_DMA(4, 1, 1, 8, 14, 8); break;
+  }
+#undef TL_DMA
+  if (rc == TL_ERR_UNSUPPORTED) switch (Cin * 1000 + Cout) {
     case 32032: rc = launch<1, 1, 2, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 1, gx, ws, s); break;
     case 64032: rc = launch<1, 2, 1, 4, 14>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 1, gx, ws, s); break;
     case 64064: rc = launch<2, 2, 1, 4, 9>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, 1, gx, ws, s); break;
