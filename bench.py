@@ -30,6 +30,7 @@ sys.path.insert(0, REPO)
 PEAK_MFMA_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = vector rate
 PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense
 PEAK_HBM_GBS = 8000.0
+GATHER_PATH_GBS = 32 * 256 * 2.4          # 32 B/clk/CU (measured, tools/gather_roof.hip) x 256 CUs x 2.4 GHz = 19 661 GB/s
 
 
 def conv_work(meta):
@@ -484,9 +485,10 @@ def main():
         recs = ops.PROFILE; ops.PROFILE = None
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / reps
         per = len(recs) // reps
-        flops = byts = 0.0
+        flops = byts = slots = 0.0
         for _, _, m in recs[:per]:
             f, b, _ = conv_work(m); flops += f; byts += b
+            slots += float(m["K"]) * m["n_out"] * m["Cin"] * m["esize"]          # bytes the gather path is ASKED for: every tap of every row, present or not
         avg_ms = tot_ms / per
         if args.layer_table:
             # per launch: measured time against its own two roofs -- matrix work if every tap of every 32-row block is contracted
@@ -512,6 +514,14 @@ def main():
             ach = byts / (tot_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
                         mfma_tflops=flops / (tot_ms * 1e-3) / 1e12)
+        # Second roof, measured (tools/gather_roof.hip, profiles/r3_roofs/gather_roof.txt): a 16-B-per-lane gather instruction costs a CU 25-34
+        # clocks whatever its lanes fetch -- an absent neighbour (out-of-range lane) as much as a present one -- i.e. 32 B/clk/CU = 19.7 TB/s
+        # at 2.4 GHz is what the vector memory path returns (L2-resident rows, 16.3-19.6 TB/s measured).  Output-stationary sparse convs
+        # issue K * rows * Cin * esize of it.
+        roof["gather_path"] = dict(requested_gb_per_step=slots / 1e9, achieved_gbs=slots / (tot_ms * 1e-3) / 1e9, peak_gbs=GATHER_PATH_GBS,
+                                   frac=slots / (tot_ms * 1e-3) / 1e9 / GATHER_PATH_GBS,
+                                   note="bytes asked of the gather path (all taps, present or not) / conv time; peak = 32 B/clk/CU x 256 CUs x 2.4 GHz, "
+                                        "measured by tools/gather_roof.hip (profiles/r3_roofs/gather_roof.txt)")
         tr = pmc_traffic(args.dtype, args.workload)
         if tr is not None:
             roof["traffic"] = tr[0]["hbm_gb_per_step"]
