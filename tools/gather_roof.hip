@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 
 // One wave gathers `iters` batches of UNR instructions; lane l of an instruction fetches piece l % LPR of row r(instruction, l / LPR).
 // sequential != 0: the rows of a wave are consecutive (a streaming read through the same instruction) -- the control.
-template <int ROWB, int UNR, bool DMA, int LPR = ROWB / 16, bool EXECMASK = false>
+template <int ROWB, int UNR, bool DMA, int LPR = ROWB / 16, bool EXECMASK = false, bool SPLIT = false>
 __global__ void __launch_bounds__(1024) k_gather(const uint32_t* __restrict__ base, uint32_t bytes, uint32_t win_rows, uint32_t present_1024, int iters,
                                                  int sequential, uint32_t* __restrict__ sink) {
   constexpr int RPI = 64 / LPR;
@@ -41,11 +41,12 @@ __global__ void __launch_bounds__(1024) k_gather(const uint32_t* __restrict__ ba
     u32x4 v[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const uint32_t h = mix((gw * 9176u + (uint32_t)it) * 64u + (uint32_t)u * 8u + (uint32_t)(lane / LPR));
-      uint32_t row = sequential ? (seq + (uint32_t)(lane / LPR)) % win_rows : h % win_rows;
+      const uint32_t rslot = SPLIT ? (uint32_t)(lane % RPI) : (uint32_t)(lane / LPR), piece = SPLIT ? (uint32_t)(lane / RPI) : (uint32_t)(lane % LPR);
+      const uint32_t h = mix((gw * 9176u + (uint32_t)it) * 64u + (uint32_t)u * 64u + rslot);
+      uint32_t row = sequential ? (seq + rslot) % win_rows : h % win_rows;
       seq += sequential ? RPI : 0;
       const bool here = (mix(h ^ 0x9e3779b9u) & 1023u) < present_1024;
-      const uint32_t off = here ? (w0 + row) * ROWB + (uint32_t)(lane % LPR) * 16u : 0xFFFFFFFFu;
+      const uint32_t off = here ? (w0 + row) * ROWB + piece * 16u : 0xFFFFFFFFu;
       if constexpr (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + (wv * UNR + u) * 1024), 16, (int)off, 0, 0, 0);
       else if constexpr (EXECMASK) { v[u] = u32x4{0, 0, 0, 0}; if (here) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0)); }
       else v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(1024) k_gather(const uint32_t* __restrict__ ba
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;   // keeps the loads alive
 }
 
-template <int ROWB, int UNR, bool DMA, int LPR = ROWB / 16, bool EXECMASK = false>
+template <int ROWB, int UNR, bool DMA, int LPR = ROWB / 16, bool EXECMASK = false, bool SPLIT = false>
 static int run(const uint32_t* buf, size_t bytes, size_t win_bytes, int present_pct, int waves_per_cu, int sequential, uint32_t* sink, double clk_ghz) {
   const int cus = 256, iters = 2000 / UNR * 4;
   const int wpb = waves_per_cu >= 16 ? 16 : waves_per_cu;                 // one workgroup per CU up to 16 waves, two beyond
@@ -73,7 +74,7 @@ static int run(const uint32_t* buf, size_t bytes, size_t win_bytes, int present_
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     if (rep) CK(hipEventRecord(e0));
-    k_gather<ROWB, UNR, DMA, LPR, EXECMASK><<<blocks, wpb * 64, lds>>>(buf, (uint32_t)bytes, win_rows, pres, iters, sequential, sink);
+    k_gather<ROWB, UNR, DMA, LPR, EXECMASK, SPLIT><<<blocks, wpb * 64, lds>>>(buf, (uint32_t)bytes, win_rows, pres, iters, sequential, sink);
     if (rep) CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
   }
@@ -82,7 +83,7 @@ static int run(const uint32_t* buf, size_t bytes, size_t win_bytes, int present_
   const double instr = (double)blocks * wpb * iters * UNR;
   const double req = instr * 1024.0 * present_pct / 100.0;   // 16 B per present lane
   printf("row %3d B x %2d lanes%s  window/XCD %7.1f MB  present %3d %%  %2d waves/CU x %d in flight  %s %s: %7.2f TB/s requested, %5.1f lanes/clk/CU at %.1f GHz (%.3f ms)\n",
-         ROWB, LPR, EXECMASK ? " (absent lanes EXEC-masked)" : "", win_bytes / 1048576.0, present_pct, waves_per_cu, UNR, DMA ? "LDS-DMA  " : "registers", sequential ? "sequential" : "random    ",
+         ROWB, LPR, EXECMASK ? " (absent lanes EXEC-masked)" : SPLIT ? " (a row's lanes 64/LPR apart: MFMA-fragment shape)" : "", win_bytes / 1048576.0, present_pct, waves_per_cu, UNR, DMA ? "LDS-DMA  " : "registers", sequential ? "sequential" : "random    ",
          req / (ms * 1e-3) / 1e12, instr * 64.0 / (ms * 1e-3) / (clk_ghz * 1e9) / cus, clk_ghz, ms);
   return 0;
 }
@@ -124,5 +125,14 @@ int main() {
   run<64, 8, false, 1, true>(buf, bytes, 1 * MB, 20, 16, 0, sink, ghz);
   // 8. control: the same instruction streaming through an L2-resident window
   run<128, 8, false>(buf, bytes, 1 * MB, 100, 16, 1, sink, ghz);
+  // 9. the MFMA-fragment shape (lane l: row l % 32, piece l / 32): what k_conv_direct / k_conv_stream issue
+  run<192, 8, false, 2, false, true>(buf, bytes, 1 * MB, 88, 16, 0, sink, ghz);
+  run<192, 8, false, 2, false, false>(buf, bytes, 1 * MB, 88, 16, 0, sink, ghz);
+  run<192, 8, false, 4, false, false>(buf, bytes, 1 * MB, 88, 16, 0, sink, ghz);
+  run<192, 8, false, 4, false, true>(buf, bytes, 1 * MB, 88, 16, 0, sink, ghz);
+  run<128, 8, false, 2, false, true>(buf, bytes, 1 * MB, 61, 16, 0, sink, ghz);
+  run<128, 8, false, 8, false, false>(buf, bytes, 1 * MB, 61, 16, 0, sink, ghz);
+  run<64, 8, false, 2, false, true>(buf, bytes, 1 * MB, 20, 16, 0, sink, ghz);
+  run<64, 8, false, 2, false, true>(buf, bytes, 1 * MB, 100, 16, 0, sink, ghz);
   return 0;
 }
