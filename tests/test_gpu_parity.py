@@ -888,6 +888,9 @@ def test_conv_wgrad_vs_dense_reference(cin, cout, K, n_out):
     c2 = ops.conv_wgrad(xb, gb, tab, n_out, K)
     e = ops.conv_wgrad(xb.float(), gb.float(), tab, n_out, K)
     assert torch.equal(c, c2)
+    if K == 27 and n_out >= 60000:                                                   # the dense-over-taps kernels wait on COUNTED outstanding loads: a wrong
+        for _ in range(12):                                                          # count shows as an occasional stale tile, not as a wrong mean
+            assert torch.equal(ops.conv_wgrad(xb, gb, tab, n_out, K), c)
     assert rel_err(c.cpu().numpy(), e.cpu().numpy()) < 2e-5
     if K == 27 and n_out >= 60000 and cin >= 32:                                     # dense-over-taps: the register-staged form of the same kernel
         from treelearn_amd import _hip

@@ -130,6 +130,47 @@ def test_fused_training_nodes_equal_separate_passes():
     assert np.isfinite(df).all() and df.mean() < 1.25 * ds.mean() + 1e-3, (df.mean(), ds.mean())
     assert df.max() < 1.5 * ds.max() + 1e-2, (df.max(), ds.max())
 
+def test_side_stream_join_modes_give_identical_gradients(monkeypatch):
+    """The weight gradients run on a side stream.  Default: ONE join at the end of the backward pass (autograd final callback; the
+    tensors the side stream reads are kept alive until then); TL_WGRAD_JOIN=layer: the main stream waits after every layer;
+    TL_WGRAD_STREAM=0: everything on the main stream.  Same kernels, same order of summation: the three must agree BIT FOR BIT, step after
+    step, also when gradients are accumulated into an existing `.grad` (where the deferred join must not be used: AccumulateGrad adds right
+    after the node returns)."""
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    cfg = dict(channels=32, num_blocks=4)
+    batch = make_batch([make_tile(extent=16.0, voxel=0.1, n_trees=10, fill=0.10, seed=s) for s in (5, 6)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def run(mode):
+        monkeypatch.delenv("TL_WGRAD_JOIN", raising=False); monkeypatch.delenv("TL_WGRAD_STREAM", raising=False)
+        if mode == "layer": monkeypatch.setenv("TL_WGRAD_JOIN", "layer")
+        if mode == "serial": monkeypatch.setenv("TL_WGRAD_STREAM", "0")
+        model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, compute_dtype=torch.bfloat16, **cfg)
+        model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+        model = model.cuda().train()
+        opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3)
+        out = []
+        for step in range(3):
+            opt.zero_grad()
+            loss, _ = model(gb, return_loss=True)
+            loss.backward()
+            if step == 1:                                    # accumulate a second backward into the existing .grad
+                loss2, _ = model(gb, return_loss=True)
+                loss2.backward()
+            out.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+        torch.cuda.synchronize()
+        return out
+
+    ref = run("serial")
+    for mode in ("deferred", "layer"):
+        got = run(mode)
+        for step, (a, b) in enumerate(zip(ref, got)):
+            bad = [n for n in a if not torch.equal(a[n], b[n])]
+            assert not bad, (mode, step, bad[:5])
+
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gather_rows_and_scatter_add_vs_torch(dtype):

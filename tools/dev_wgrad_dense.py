@@ -28,7 +28,7 @@ for li, lv in enumerate(geom.levels[:4]):
         L.tl_set_tuning(b"wgrad_dense", 1); L.tl_set_tuning(b"wgrad_dma", 0)
         new = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27); new2 = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27)
         t1 = timeit(lambda: ops.conv_wgrad(x, g, lv.nbr, lv.n, 27))
-        for var, gxo in ((1, 0),):
+        for var, gxo in ((1, 0), (2, 0)):
             L.tl_set_tuning(b"wgrad_dma", var); L.tl_set_tuning(b"wgrad_dense_gx", gxo)
             dma = ops.conv_wgrad(x, g, lv.nbr, lv.n, 27)
             t2 = timeit(lambda: ops.conv_wgrad(x, g, lv.nbr, lv.n, 27))

@@ -133,6 +133,10 @@ def lib():
         if WIN_KERNEL and L.tl_set_tuning(b"win", 1) != 0:
             raise RuntimeError("TL_CONV_WIN=1 needs the developer build of the library (python -m treelearn_amd.build --dev): the window conv "
                                "kernel is not part of the release build")
+        for kv in filter(None, os.environ.get("TL_TUNING", "").split(",")):          # developer: TL_TUNING="key=value,..." -> tl_set_tuning at load
+            k, _, v = kv.partition("=")
+            if L.tl_set_tuning(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError(f"TL_TUNING: unknown key {k!r}")
         _lib = L
     return _lib
 

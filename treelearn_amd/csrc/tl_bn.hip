@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(kFin) k_bn_stats_finish(const double* __restri
                                                         float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         int64_t* __restrict__ num_batches_tracked) {
+  __builtin_amdgcn_s_setprio(3);                              // a short kernel on the critical path, often next to a persistent weight-gradient kernel of the side stream
   __shared__ double red[kFin];
   const int c = blockIdx.x;
   const double s = sum_partials(part, blocks, 2 * (int64_t)C, c, red), ss = sum_partials(part, blocks, 2 * (int64_t)C, C + c, red);
@@ -164,6 +165,7 @@ __global__ void __launch_bounds__(kThreads) k_bn_bwd_reduce(const TX* __restrict
 }
 
 __global__ void __launch_bounds__(kFin) k_bn_bwd_finish(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __builtin_amdgcn_s_setprio(3);                              // a short kernel on the critical path, often next to a persistent weight-gradient kernel of the side stream
   __shared__ double red[kFin];
   const int c = blockIdx.x;
   const double s = sum_partials(part, blocks, 2 * (int64_t)C, c, red), sx = sum_partials(part, blocks, 2 * (int64_t)C, C + c, red);

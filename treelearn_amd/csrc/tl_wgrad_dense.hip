@@ -273,12 +273,53 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense_dma(const uint16_t* __r
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+  // (bounds-checked buffer loads, NOT predicated global loads: a load the compiler may branch around when no lane needs it would make the
+  // number of outstanding memory operations -- which the counted waits below rely on -- depend on the data: at the end of a wave's range
+  // the waits then came too early and the step read a slot its DMA had not filled yet)
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(table + (active ? (int64_t)tap * n_out : 0)), 0,
+                                                                     (int)min((int64_t)0x7FFFFFFF, n_out * 4), 0x00020000);
   auto idx_load = [&](int it, int (&dst)[KS]) __attribute__((always_inline)) {
     const int mb = mb_of(it);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int64_t row = (int64_t)mb * MBR + kk * 64 + lane;
-      dst[kk] = (mb >= 0 && active && row < n_out) ? table[(int64_t)tap * n_out + row] : -1;
+      const bool ok = mb >= 0 && active && row < n_out;
+      const int v = __builtin_amdgcn_raw_buffer_load_b32(rt, ok ? (int)(row * 4) : -1, 0, 0);
+      dst[kk] = ok ? v : -1;
+    }
+  };
+  // the same two loads for the main loop, as inline assembly: their POSITION in the instruction stream is part of the wait arithmetic (hipcc
+  // sank the compiler-visible gout load from the block start to its use behind four steps of DMAs and drained them there); the loaded
+  // registers are handed to the compiler only after the counted wait that covers them.  A row past the end is offset -1 = out of range =
+  // 0 from the hardware, which is a valid row index: validity is re-applied after the wait (idx_fix).
+  auto idx_load_asm = [&](int it, int (&dst)[KS]) __attribute__((always_inline)) {
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int64_t row = (int64_t)mb * MBR + kk * 64 + lane;
+      const bool ok = mb >= 0 && active && row < n_out;
+      const int off = ok ? (int)(row * 4) : -1;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst[kk]) : "v"(off), "s"(rt));
+    }
+  };
+  auto idx_fix = [&](int it, int (&dst)[KS]) __attribute__((always_inline)) {      // after the wait: rows past the end read 0 -> absent
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      asm volatile("" : "+v"(dst[kk]));
+      const int64_t row = (int64_t)mb * MBR + kk * 64 + lane;
+      if (!(mb >= 0 && active && row < n_out)) dst[kk] = -1;
+    }
+  };
+  auto g_load_asm = [&](int it, u32x4 (&dst)[NPT]) __attribute__((always_inline)) {
+    const int mb = mb_of(it);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int q = tid + i * NT, r = q / PRG, pc = q % PRG;
+      const int64_t row = (int64_t)mb * MBR + r;
+      const bool ok = mb >= 0 && row < n_out && (NPT * NT == MBR * PRG || q < MBR * PRG);
+      const unsigned off = ok ? (unsigned)(row * g_ld * 2) + (unsigned)(pc * 16) : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[i]) : "v"(off), "s"(rg));
     }
   };
   auto g_load = [&](int it, u32x4 (&dst)[NPT]) __attribute__((always_inline)) {
@@ -333,14 +374,14 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense_dma(const uint16_t* __r
     else if (d / SPM == 1) x_dma(d % SPM, idx1, d);
     else x_dma(d % SPM, idx2, d);
   }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (one-time drain: from here on every wait is counted)
 
   for (int it = 0; it < niter; ++it) {
     u32x4 gn[NPT];
     const unsigned gc_off = gs_off + (unsigned)((it & 1) * (MBR * PG));
 #pragma unroll
     for (int s = 0; s < SPM; ++s) {
-      if (s == 0) { g_load(it + 1, gn); idx_load(it + 3, idx3); }
+      if (s == 0) { g_load_asm(it + 1, gn); idx_load_asm(it + 3, idx3); }
       // the slot read in the previous step is free (its fragments fed MFMAs that were issued already): DMA of step s + NR - 1
       {
         constexpr int dummy = 0; (void)dummy;
@@ -395,6 +436,11 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense_dma(const uint16_t* __r
       __builtin_amdgcn_sched_barrier(0);
       head = head + 1 == NR ? 0 : head + 1;
     }
+    // the block-start loads are older than the SPM * NL gathers issued since
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPM * NL) : "memory");
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) asm volatile("" : "+v"(gn[i]));
+    idx_fix(it + 3, idx3);
     g_store((it + 1) & 1, gn);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) { idx0[kk] = idx1[kk]; idx1[kk] = idx2[kk]; idx2[kk] = idx3[kk]; }
@@ -509,8 +555,9 @@ int tl_wgrad_dense_slots(int64_t n_out, int K, int Cin, int Cout) {
   int gx = 0;
   if (g_wgrad_dma) {
     switch (key) {                                         // 14 waves of <= 128 registers per workgroup, one workgroup per CU
-      case 32032: case 64032: case 64064: gx = 128; break; // 27 jobs: 2 workgroups per slot
-      case 128064: gx = 64; break;                         // 54 jobs: 4 workgroups per slot
+      case 32032: case 64032: gx = 128; break;             // 27 jobs: 2 workgroups per slot
+      case 64064: gx = g_wgrad_dma == 2 ? 128 : 80; break; // 27 jobs: 3 workgroups of 9 waves per slot
+      case 128064: gx = g_wgrad_dma == 2 ? 64 : 40; break; // 54 jobs: 6 workgroups of 9 waves per slot
       case 96096: gx = 40; break;                          // 81 jobs: 6 per slot
       case 192096: gx = 64; break;                         // 162 jobs: 12 per slot, 768 workgroups = 3 per CU
       case 128128: gx = 32; break;
@@ -539,8 +586,8 @@ int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, in
 #define TL_DMA(NBO, NBIW, KS, NR, NW, NS) launch_dma<NBO, NBIW, KS, NR, NW>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, NS, gx, ws, s)
   if (g_wgrad_dma) switch (Cin * 1000 + Cout) {            // 64 -> 32 measured no faster than the register-staged form: not here
     case 32032: rc = TL_DMA(1, 1, 2, 4, 14, 1); break;
-    case 64064: rc = TL_DMA(2, 2, 1, 4, 14, 1); break;
-    case 128064: rc = TL_DMA(2, 2, 1, 4, 14, 2); break;
+    case 64064: rc = g_wgrad_dma == 2 ? TL_DMA(2, 2, 1, 4, 14, 1) : TL_DMA(2, 2, 1, 7, 9, 1); break;
+    case 128064: rc = g_wgrad_dma == 2 ? TL_DMA(2, 2, 1, 4, 14, 2) : TL_DMA(2, 2, 1, 7, 9, 2); break;
     case 96096: rc = TL_DMA(3, 1, 2, 4, 14, 3); break;
     case 192096: rc = TL_DMA(3, 1, 2, 4, 14, 6); break;
     case 128128: rc = TL_DMA(4, 1, 1, 8, 14, 4); break;
