@@ -57,7 +57,7 @@ def build(force=False, verbose=True, dev=False):
     for s in srcs:
         if os.path.basename(s) in F16_UNITS:
             o = os.path.join(objdir, os.path.basename(s)[:-4] + "_f16.o")
-            objs.append(o); jobs.append((s, o, ["-DTL_F16_BUILD"]))
+            objs.append(o); jobs.append((s, o, ["-DTL_F16_BUILD", "-UTL_DEV"]))        # (the developer hooks exist once, in the bf16 objects)
 
     def compile_one(so):
         s, o, extra = so
