@@ -1,0 +1,324 @@
+// PROTOTYPE (not part of the package; built on the GPU box by tools/proto_blk/run_blk.py): level-1 32 -> 32 SubM conv over a BLOCK-LOCAL row order
+// (DESIGN.md R3.6 "what comes next").  Rows are sorted by 8x8x8 block and cut into units of <= 64 own rows; a WAVE owns a unit end to end:
+//   stage  : own rows (contiguous) + halo rows (gathered once each, present by construction) -> per-wave LDS stage by LDS-DMA, 64 B per row,
+//            16-B pieces swizzled by (staged position >> 2) & 3;
+//   taps   : the unit's local rulebook (one byte per (row, tap): staged position or 255 = absent -> an all-zero stage row) gives every A
+//            fragment's LDS address; all 27 weight matrices are resident in LDS; 16x16x32 MFMAs, fp32 accumulators in registers;
+//   output : accumulators -> stage area -> 16-B stores of the unit's own rows.
+// No workgroup barrier after the weights are staged, no minima, no windows, no gather slot for an absent tap.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+static __device__ __forceinline__ u32x4 lds_r128(unsigned a) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); return v; }
+#define LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+#define KEEP(x) asm volatile("" : "+v"(x))
+static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+  a += 0x7FFFu + ((a >> 16) & 1u); b += 0x7FFFu + ((b >> 16) & 1u);
+  return (a >> 16) | (b & 0xFFFF0000u);
+}
+static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+struct BlkP {
+  const uint16_t* x;        // [n][32] bf16, block-local row order
+  const uint16_t* w;        // [27][32 cout][32 cin] bf16
+  uint16_t* out;            // [n][32] bf16
+  const int32_t* unit;      // [nunits][4] = row0, n_own, halo offset, n_halo (halo list padded to a multiple of 16 with -1)
+  const int32_t* halo;      // new-row indices
+  const uint8_t* lrb;       // [nunits][4 groups][16 rows][32]: byte k = staged position of tap k, 255 = absent
+  int64_t n;
+  int nunits;
+  int dbg;
+};
+
+constexpr int STAGE_B = 256 * 64;          // 256 stage rows of 64 B; row 255 stays zero
+constexpr int WS_B = 27 * 32 * 64;
+
+template <int NG>
+static __device__ __forceinline__ void taps(const unsigned ws_a, const unsigned st_a, const unsigned b_off, const int pc, const u32x4 (&rb)[4][2],
+                                            f32x4 (&acc)[4][2]) {
+  // software pipeline of depth 2 over the taps: the reads of tap k + 1 are issued before the MFMAs of tap k (2 + NG reads per tap)
+  u32x4 A[2][NG], B[2][2];
+  auto issue = [&](int k, int s) __attribute__((always_inline)) {
+    B[s][0] = lds_r128(ws_a + (unsigned)(k * 2048) + b_off);
+    B[s][1] = lds_r128(ws_a + (unsigned)(k * 2048 + 1024) + b_off);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const uint32_t wd = rb[g][k >> 4][(k >> 2) & 3];
+      const unsigned idx = (wd >> ((k & 3) * 8)) & 255u;
+      A[s][g] = lds_r128(st_a + idx * 64u + (unsigned)(((pc ^ ((idx >> 2) & 3)) * 16)));
+    }
+  };
+  issue(0, 0);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int s = k & 1;
+    if (k + 1 < 27) { issue(k + 1, s ^ 1); LGKM(2 + NG); } else LGKM(0);
+    KEEP(B[s][0]); KEEP(B[s][1]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      KEEP(A[s][g]);
+      acc[g][0] = mfma16(A[s][g], B[s][0], acc[g][0]);
+      acc[g][1] = mfma16(A[s][g], B[s][1], acc[g][1]);
+    }
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(W * 64) k_conv_blk(BlkP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ri = lane & 15, pc = lane >> 4;
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
+    for (int v = tid; v < 27 * 128; v += W * 64) {
+      const int s = v & 3, n = (v >> 2) & 31, k = v >> 7;
+      *reinterpret_cast<u32x4*>(smem + (k * 32 + n) * 64 + ((s ^ ((n >> 2) & 3)) * 16)) = wsrc[v];
+    }
+  }
+  char* stage = smem + WS_B + wv * STAGE_B;
+  for (int e = lane; e < STAGE_B / 16; e += 64) *reinterpret_cast<u32x4*>(stage + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem, ws_a = lds0, st_a = lds0 + (unsigned)(WS_B + wv * STAGE_B);
+  const unsigned b_off = (unsigned)(ri * 64 + ((pc ^ ((ri >> 2) & 3)) * 16));
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 64), 0x00020000);
+  const int gw = (int)blockIdx.x * W + wv, nw = (int)gridDim.x * W;
+
+  for (int u = gw; u < p.nunits; u += nw) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1], h0 = p.unit[4 * u + 2], nh = p.unit[4 * u + 3];
+    // 1. local rulebook of the unit: lane (ri, pc) takes the 32-byte records of rows 16 g + ri (the four pc groups load the same bytes)
+    u32x4 rb[4][2];
+    const u32x4* lr = reinterpret_cast<const u32x4*>(p.lrb + (int64_t)u * 2048);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { rb[g][0] = lr[(g * 16 + ri) * 2]; rb[g][1] = lr[(g * 16 + ri) * 2 + 1]; }
+    // 2. stage: own rows, then halo rows
+    if (!(p.dbg & 1)) {
+      for (int c = 0; c * 16 < nown; ++c) {
+        const int pos = c * 16 + (lane >> 2);
+        const unsigned off = (unsigned)(row0 + pos) * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16);
+        if (pos < nown) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + c * 1024), 16, (int)off, 0, 0, 0);   // (inactive lanes write nothing: the halo starts right behind)
+      }
+      for (int c = 0; c * 16 < nh; ++c) {
+        const int hi = p.halo[h0 + c * 16 + (lane >> 2)];
+        const int pos = nown + c * 16 + (lane >> 2);
+        const unsigned off = hi >= 0 ? (unsigned)hi * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + nown * 64 + c * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { KEEP(rb[g][0]); KEEP(rb[g][1]); }
+    // 3. taps
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int ng = (nown + 15) >> 4;
+    if (!(p.dbg & 2)) {
+      if (ng == 1) taps<1>(ws_a, st_a, b_off, pc, rb, acc);
+      else if (ng == 2) taps<2>(ws_a, st_a, b_off, pc, rb, acc);
+      else if (ng == 3) taps<3>(ws_a, st_a, b_off, pc, rb, acc);
+      else taps<4>(ws_a, st_a, b_off, pc, rb, acc);
+    }
+    // 4. output through the stage (the halo part is dead now; rows 0 .. 63 x 36 floats = 9216 B), then the stage's used rows back to zero
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* ew = reinterpret_cast<float*>(stage);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ew[(g * 16 + 4 * pc + r) * 36 + ri] = acc[g][0][r];
+        ew[(g * 16 + 4 * pc + r) * 36 + 16 + ri] = acc[g][1][r];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned ea = st_a + (unsigned)((rr * 36 + cvv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      o[it] = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                    pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+    }
+    // rows 0 .. 255 of the stage minus the zero row: zero what the next unit may read as "absent" -- everything is rewritten by the next DMA
+    // except the tail beyond its own + halo rows, which only matters for position 255 (never written).  The fp32 scratch overwrote rows 0..143:
+    // the next unit's DMA overwrites its first n_own + n_halo rows and never reads beyond them, so nothing needs clearing.
+    if (!(p.dbg & 4)) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+        if (rr < nown) *reinterpret_cast<u32x4*>(p.out + (int64_t)(row0 + rr) * 32 + cvv * 8) = o[it];
+      }
+    }
+  }
+}
+
+
+// ---- variant R: the weights live in REGISTERS (27 taps x 2 cout halves x 16 B per lane = 216 registers; with one wave per SIMD the unified
+// VGPR/AGPR file has 512 per lane and MFMA sources may sit in either half), so the LDS holds only stages: two per wave, and the rulebook +
+// staging DMA of unit t + 1 are issued before the taps of unit t.
+template <int NG>
+static __device__ __forceinline__ void taps_r(const unsigned st_a, const int pc, const u32x4 (&rb)[4][2], const u32x4 (&Bw)[27][2], f32x4 (&acc)[4][2]) {
+  constexpr int D = 4;                                     // taps in flight: with one wave per SIMD the LDS latency is covered by the wave's own MFMAs only
+  u32x4 A[D][NG];
+  auto issue = [&](int k, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const uint32_t wd = rb[g][k >> 4][(k >> 2) & 3];
+      const unsigned idx = (wd >> ((k & 3) * 8)) & 255u;
+      A[s][g] = lds_r128(st_a + idx * 64u + (unsigned)(((pc ^ ((idx >> 2) & 3)) * 16)));
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < D - 1; ++k) issue(k, k);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int s = k % D;
+    if (k + D - 1 < 27) { issue(k + D - 1, (k + D - 1) % D); LGKM((D - 1) * NG); }
+    else if (26 - k == 2) LGKM(2 * NG); else if (26 - k == 1) LGKM(NG); else LGKM(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      KEEP(A[s][g]);
+      acc[g][0] = mfma16(A[s][g], Bw[k][0], acc[g][0]);
+      acc[g][1] = mfma16(A[s][g], Bw[k][1], acc[g][1]);
+    }
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(W * 64) k_conv_blk_r(BlkP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ri = lane & 15, pc = lane >> 4;
+  u32x4 Bw[27][2];
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);            // [27][32 cout][4 pieces]
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { Bw[k][0] = wsrc[(k * 32 + ri) * 4 + pc]; Bw[k][1] = wsrc[(k * 32 + 16 + ri) * 4 + pc]; }
+  }
+  char* stage0 = smem + wv * (2 * STAGE_B);
+  for (int e = lane; e < 2 * STAGE_B / 16; e += 64) *reinterpret_cast<u32x4*>(stage0 + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  const unsigned st0 = (unsigned)(uintptr_t)(lds_ptr)stage0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.n * 64), 0x00020000);
+  const int gw = (int)blockIdx.x * W + wv, nw = (int)gridDim.x * W;
+
+  auto stage_unit = [&](int u, char* stage) __attribute__((always_inline)) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1], h0 = p.unit[4 * u + 2], nh = p.unit[4 * u + 3];
+    for (int c = 0; c * 16 < nown; ++c) {
+      const int pos = c * 16 + (lane >> 2);
+      const unsigned off = (unsigned)(row0 + pos) * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16);
+      if (pos < nown) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + c * 1024), 16, (int)off, 0, 0, 0);
+    }
+    for (int c = 0; c * 16 < nh; ++c) {
+      const int hi = p.halo[h0 + c * 16 + (lane >> 2)];
+      const int pos = nown + c * 16 + (lane >> 2);
+      const unsigned off = hi >= 0 ? (unsigned)hi * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + nown * 64 + c * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+  // (inline assembly: a compiler-visible load behind a run-time number of DMA instructions is waited for with vmcnt(0), which would also wait
+  // for the previous unit's stores)
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.lrb), 0, (int)((int64_t)p.nunits * 2048), 0x00020000);
+  auto load_rb = [&](int u, u32x4 (&rb)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned off = (unsigned)u * 2048u + (unsigned)((g * 16 + ri) * 32);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[g][0]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[g][1]) : "v"(off), "s"(rl));
+    }
+  };
+
+  u32x4 rbc[4][2], rbn[4][2];
+  int buf = 0;
+  if (gw < p.nunits) { load_rb(gw, rbc); if (!(p.dbg & 1)) stage_unit(gw, stage0); }
+  for (int u = gw; u < p.nunits; u += nw) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1];
+    char* stage = stage0 + buf * STAGE_B;
+    const unsigned st_a = st0 + (unsigned)(buf * STAGE_B);
+    // this unit's stage and rulebook have landed (issued one unit ago); the only younger operations are the four stores of the previous unit
+    if (u == gw) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (u != gw) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { KEEP(rbn[g][0]); KEEP(rbn[g][1]); rbc[g][0] = rbn[g][0]; rbc[g][1] = rbn[g][1]; }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { KEEP(rbc[g][0]); KEEP(rbc[g][1]); }
+    }
+    const int un = u + nw;
+    if (un < p.nunits) { load_rb(un, rbn); if (!(p.dbg & 1)) stage_unit(un, stage0 + (buf ^ 1) * STAGE_B); }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int ng = (nown + 15) >> 4;
+    if (!(p.dbg & 2)) {
+      if (ng == 1) taps_r<1>(st_a, pc, rbc, Bw, acc);
+      else if (ng == 2) taps_r<2>(st_a, pc, rbc, Bw, acc);
+      else if (ng == 3) taps_r<3>(st_a, pc, rbc, Bw, acc);
+      else taps_r<4>(st_a, pc, rbc, Bw, acc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* ew = reinterpret_cast<float*>(stage);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ew[(g * 16 + 4 * pc + r) * 36 + ri] = acc[g][0][r];
+        ew[(g * 16 + 4 * pc + r) * 36 + 16 + ri] = acc[g][1][r];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned ea = st_a + (unsigned)((rr * 36 + cvv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      o[it] = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                    pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                                   // always four store instructions (a row past the unit: offset out of range, dropped)
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned off = (rr < nown && !(p.dbg & 4)) ? (unsigned)(row0 + rr) * 64u + (unsigned)(cvv * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o[it]), ro, (int)off, 0, 0);
+    }
+    buf ^= 1;
+  }
+}
+
+extern "C" int conv_blk(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int waves,
+                        int dbg, void* stream) {
+  BlkP p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint8_t*)lrb, n, nunits, dbg};
+  hipStream_t s = (hipStream_t)stream;
+#define GO(W_)                                                                                                                   \
+  {                                                                                                                              \
+    const size_t lds = WS_B + (size_t)W_ * STAGE_B;                                                                              \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; \
+    k_conv_blk<W_><<<256, W_ * 64, lds, s>>>(p);                                                                                 \
+  }
+  if (waves == 6) GO(6) else if (waves == 4) GO(4) else if (waves == 5) GO(5)
+  else if (waves == 104 || waves == 102 || waves == 101) {               // variant R: W = waves - 100 waves per workgroup, weights in registers
+    const int W_ = waves - 100;
+    const size_t lds = (size_t)W_ * 2 * STAGE_B;
+    const int per_cu = 4 / W_;                                           // one wave per SIMD
+#define GOR(WW)                                                                                                                  \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk_r<WW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; \
+    k_conv_blk_r<WW><<<256 * per_cu, WW * 64, lds, s>>>(p);
+    if (W_ == 4) { GOR(4) } else if (W_ == 2) { GOR(2) } else { GOR(1) }
+#undef GOR
+  } else return -2;
+#undef GO
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
