@@ -298,6 +298,189 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk_r(BlkP p) {
   }
 }
 
+
+// ---- variant S: variant R plus (1) 32x32x16 MFMAs on units of exactly 64 consecutive rows of the block-sorted order (two 32-row tiles; units may
+// span blocks), (2) a 16-bit local rulebook that stores the swizzled stage offset (address = stage + (entry ^ 16 * piece)), (3) the halo indices
+// of unit t + 2 requested while unit t is computed, so that the staging DMA of unit t + 1 never waits for its own indices.
+struct BlkS {
+  const uint16_t* x; const uint16_t* w; uint16_t* out;
+  const int32_t* unit;      // [nunits][4] = row0, n_own, halo offset (in entries; lists padded to 160 entries), n_halo
+  const int32_t* halo;
+  const uint16_t* lrb;      // [nunits][64 rows][32]: entry k = stage byte offset of tap k (position * 64 + ((position >> 2) & 3) * 16), absent = 255 * 64
+  int64_t n; int nunits; int dbg;
+};
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int HCH = 10;                     // halo chunks of 16 rows per unit (<= 160 halo rows)
+
+template <int W>
+__global__ void __launch_bounds__(W * 64) k_conv_blk_s(BlkS p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 31, fh = lane >> 5;
+  u32x4 Bw[27][2];
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);            // [27][32 cout][4 pieces]; k-step s, lane half fh: piece 2 s + fh
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { Bw[k][0] = wsrc[(k * 32 + fi) * 4 + fh]; Bw[k][1] = wsrc[(k * 32 + fi) * 4 + 2 + fh]; }
+  }
+  char* stage0 = smem + wv * (2 * STAGE_B);
+  for (int e = lane; e < 2 * STAGE_B / 16; e += 64) *reinterpret_cast<u32x4*>(stage0 + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  const unsigned st0 = (unsigned)(uintptr_t)(lds_ptr)stage0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.n * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.lrb), 0, (int)((int64_t)p.nunits * 4096), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.halo), 0, (int)((int64_t)p.nunits * HCH * 16 * 4), 0x00020000);
+  const int gw = (int)blockIdx.x * W + wv, nw = (int)gridDim.x * W;
+  const unsigned pc16[2] = {(unsigned)(fh * 16), (unsigned)(32 + fh * 16)};          // piece 2 s + fh
+
+  // all loads of the steady state are inline assembly with fixed counts (HCH index loads, 8 rulebook loads per unit)
+  auto load_hidx = [&](int u, int (&h)[HCH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) {
+      const unsigned off = u < p.nunits ? ((unsigned)u * (HCH * 16) + (unsigned)(c * 16 + (lane >> 2))) * 4u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
+    }
+  };
+  auto load_rb = [&](int u, u32x4 (&rb)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned off = u < p.nunits ? (unsigned)u * 4096u + (unsigned)((t * 32 + fi) * 64) : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[t][0]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[t][1]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[t][2]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[t][3]) : "v"(off), "s"(rl));
+    }
+  };
+  // staging DMA of a unit: 4 own chunks + HCH halo chunks, ALWAYS 4 + HCH instructions (rows past the unit / absent halo entries: out of range -> zeros)
+  auto stage_unit = [&](int u, const int (&h)[HCH], char* stage) __attribute__((always_inline)) {
+    const bool ok = u < p.nunits;
+    const int row0 = ok ? p.unit[4 * u] : 0, nown = ok ? p.unit[4 * u + 1] : 0, nh = ok ? p.unit[4 * u + 3] : 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int pos = c * 16 + (lane >> 2);
+      const unsigned off = pos < nown ? (unsigned)(row0 + pos) * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + c * 1024), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) {
+      const int j = c * 16 + (lane >> 2), pos = 64 + j;                             // halo rows are staged from position 64 on
+      const unsigned off = j < nh ? (unsigned)h[c] * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + 4096 + c * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  int hc[HCH], hn[HCH];
+  u32x4 rbc[2][4], rbn[2][4];
+  load_hidx(gw, hc); load_hidx(gw + nw, hn); load_rb(gw, rbc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < HCH; ++c) { KEEP(hc[c]); KEEP(hn[c]); }
+  if (!(p.dbg & 1)) stage_unit(gw, hc, stage0);
+  int buf = 0;
+  bool firstu = true;
+  for (int u = gw; u < p.nunits; u += nw) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1];
+    char* stage = stage0 + buf * STAGE_B;
+    const unsigned st_a = st0 + (unsigned)(buf * STAGE_B);
+    // everything but the previous unit's four stores has landed: this unit's stage and rulebook, the next unit's halo indices
+    if (firstu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!firstu) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { KEEP(rbn[t][q]); rbc[t][q] = rbn[t][q]; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) KEEP(rbc[t][q]);
+    }
+    firstu = false;
+    // requests for the units behind: indices of unit t + 2, rulebook and stage of unit t + 1
+    int hnn[HCH];
+    load_hidx(u + 2 * nw, hnn);
+    load_rb(u + nw, rbn);
+    if (!(p.dbg & 1)) stage_unit(u + nw, hn, stage0 + (buf ^ 1) * STAGE_B);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    if (!(p.dbg & 2)) {
+      constexpr int D = 3;
+      u32x4 A[D][2][2];
+      auto issue = [&](int k, int s_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint32_t wd = rbc[t][k >> 3][(k >> 1) & 3];
+          const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+          const unsigned a0 = st_a + val;
+          A[s_][t][0] = lds_r128(a0 ^ pc16[0]);
+          A[s_][t][1] = lds_r128(a0 ^ pc16[1]);
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < D - 1; ++k) issue(k, k);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int s_ = k % D;
+        if (k + D - 1 < 27) { issue(k + D - 1, (k + D - 1) % D); LGKM((D - 1) * 4); }
+        else if (26 - k == 1) LGKM(4); else LGKM(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          KEEP(A[s_][t][0]); KEEP(A[s_][t][1]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_][t][0]), __builtin_bit_cast(bf16x8, Bw[k][0]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_][t][1]), __builtin_bit_cast(bf16x8, Bw[k][1]), acc[t], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* ew = reinterpret_cast<float*>(stage);                                    // 64 rows x 36 floats over the dead stage
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ew[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fi] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned ea = st_a + (unsigned)((rr * 36 + cvv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      o[it] = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                    pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+    }
+    // the zero row (position 255) lies beyond the scratch; the scratch itself is overwritten by the next unit's DMA into this buffer
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned off = (rr < nown && !(p.dbg & 4)) ? (unsigned)(row0 + rr) * 64u + (unsigned)(cvv * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o[it]), ro, (int)off, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) { hn[c] = hnn[c]; }
+    buf ^= 1;
+  }
+}
+
+extern "C" int conv_blk_s(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int waves,
+                          int dbg, void* stream) {
+  BlkS p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint16_t*)lrb, n, nunits, dbg};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)waves * 2 * STAGE_B;
+  const int per_cu = 4 / waves;
+#define GOS(WW)                                                                                                                  \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk_s<WW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; \
+  k_conv_blk_s<WW><<<256 * per_cu, WW * 64, lds, s>>>(p);
+  if (waves == 4) { GOS(4) } else if (waves == 2) { GOS(2) } else if (waves == 1) { GOS(1) } else return -2;
+#undef GOS
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int conv_blk(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int waves,
                         int dbg, void* stream) {
   BlkP p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint8_t*)lrb, n, nunits, dbg};
