@@ -481,6 +481,504 @@ extern "C" int conv_blk_s(const void* x, const void* w, void* out, const void* u
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+
+// ---- variant T: level 2, 64 -> 64 channels (128-B rows).  A workgroup of four waves (one per SIMD) shares the stage of a unit of <= 64 own rows +
+// <= 192 halo rows; wave w computes output channels 16 w .. 16 w + 15 with 16x16x32 MFMAs and keeps ITS slice of all 27 weight matrices in
+// registers (27 taps x 2 k-steps x 16 B = 216 registers per lane).  One barrier per unit (the stage is filled by all four waves), two stages.
+struct BlkT {
+  const uint16_t* x; const uint16_t* w; uint16_t* out;
+  const int32_t* unit;      // [nunits][4] = row0, n_own, -, n_halo
+  const int32_t* halo;      // [nunits][192]
+  const uint16_t* lrb;      // [nunits][64 rows][32]: entry k = stage byte offset of tap k (position * 128 + ((position >> 1) & 7) * 16), absent = 511 * 128
+  int64_t n; int nunits; int dbg;
+};
+constexpr int T_STAGE = 512 * 128;            // 512 stage rows of 128 B would be 64 KB; we use 320 rows (40 KB) per stage, zero row at position 319
+constexpr int T_ROWS = 320, T_STAGE_B = T_ROWS * 128, T_HALO = 192, T_ZERO = 319;
+
+__global__ void __launch_bounds__(256) k_conv_blk_t(BlkT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ri = lane & 15, kq = lane >> 4;
+  u32x4 Bw[27][2];
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);            // [27][64 cout][8 pieces of 8 cin]
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { Bw[k][0] = wsrc[(k * 64 + 16 * wv + ri) * 8 + kq]; Bw[k][1] = wsrc[(k * 64 + 16 * wv + ri) * 8 + 4 + kq]; }
+  }
+  for (int e = tid; e < 2 * T_STAGE_B / 16; e += 256) *reinterpret_cast<u32x4*>(smem + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  float* escr = reinterpret_cast<float*>(smem + 2 * T_STAGE_B) + wv * (64 * 20);            // per-wave epilogue scratch [64 rows][16 + 4]
+  __syncthreads();
+  const unsigned st0 = (unsigned)(uintptr_t)(lds_ptr)smem;
+  const unsigned es_a = st0 + (unsigned)(2 * T_STAGE_B + wv * (64 * 20 * 4));
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.n * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.lrb), 0, (int)((int64_t)p.nunits * 4096), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.halo), 0, (int)((int64_t)p.nunits * T_HALO * 4), 0x00020000);
+  const int gb = (int)blockIdx.x, nb = (int)gridDim.x;
+  const unsigned pq16[2] = {(unsigned)(kq * 16), (unsigned)(64 + kq * 16)};            // k-step s, lane quarter kq: piece 4 s + kq
+
+  // wave w stages own chunks 2 w, 2 w + 1 (8 rows of 128 B each) and halo chunks 6 w .. 6 w + 5: always 8 DMA instructions, 6 index loads
+  auto load_hidx = [&](int u, int (&h)[6]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const unsigned off = u < p.nunits ? ((unsigned)u * T_HALO + (unsigned)((6 * wv + c) * 8 + (lane >> 3))) * 4u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
+    }
+  };
+  auto load_rb = [&](int u, u32x4 (&rb)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned off = u < p.nunits ? (unsigned)u * 4096u + (unsigned)((g * 16 + ri) * 64) : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[g][0]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[g][1]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[g][2]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[g][3]) : "v"(off), "s"(rl));
+    }
+  };
+  auto stage_unit = [&](int u, const int (&h)[6], char* stage) __attribute__((always_inline)) {
+    const bool ok = u < p.nunits;
+    const int row0 = ok ? p.unit[4 * u] : 0, nown = ok ? p.unit[4 * u + 1] : 0, nh = ok ? p.unit[4 * u + 3] : 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int pos = (2 * wv + c) * 8 + (lane >> 3);
+      const unsigned off = pos < nown ? (unsigned)(row0 + pos) * 128u + (unsigned)((((lane & 7) ^ ((pos >> 1) & 7))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + (2 * wv + c) * 1024), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int j = (6 * wv + c) * 8 + (lane >> 3), pos = 64 + j;
+      const unsigned off = j < nh ? (unsigned)h[c] * 128u + (unsigned)((((lane & 7) ^ ((pos >> 1) & 7))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + 8192 + (6 * wv + c) * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  int hc[6], hn[6];
+  u32x4 rbc[4][4], rbn[4][4];
+  load_hidx(gb, hc); load_hidx(gb + nb, hn); load_rb(gb, rbc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { KEEP(hc[c]); KEEP(hn[c]); }
+  if (!(p.dbg & 1)) stage_unit(gb, hc, smem);
+  int buf = 0;
+  bool firstu = true;
+  for (int u = gb; u < p.nunits; u += nb) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1];
+    const unsigned st_a = st0 + (unsigned)(buf * T_STAGE_B);
+    // this wave's share of the unit's stage, its rulebook and the next unit's indices have landed (the two stores of the previous unit may be
+    // outstanding); the barrier makes the other waves' shares visible and says that everybody is done with the other stage
+    if (firstu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!firstu) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { KEEP(rbn[g][q]); rbc[g][q] = rbn[g][q]; }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) KEEP(rbc[g][q]);
+    }
+    firstu = false;
+    int hnn[6];
+    load_hidx(u + 2 * nb, hnn);
+    load_rb(u + nb, rbn);
+    if (!(p.dbg & 1)) stage_unit(u + nb, hn, smem + (buf ^ 1) * T_STAGE_B);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(p.dbg & 2)) {
+      constexpr int D = 2;                               // (lgkmcnt counts to 15: one tap of 8 reads ahead)
+      u32x4 A[D][4][2];
+      auto issue = [&](int k, int s_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t wd = rbc[g][k >> 3][(k >> 1) & 3];
+          const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+          const unsigned a0 = st_a + val;
+          A[s_][g][0] = lds_r128(a0 ^ pq16[0]);
+          A[s_][g][1] = lds_r128(a0 ^ pq16[1]);
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < D - 1; ++k) issue(k, k);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int s_ = k % D;
+        if (k + D - 1 < 27) { issue(k + D - 1, (k + D - 1) % D); LGKM((D - 1) * 8); }
+        else LGKM(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          KEEP(A[s_][g][0]); KEEP(A[s_][g][1]);
+          acc[g] = mfma16(A[s_][g][0], Bw[k][0], acc[g]);
+          acc[g] = mfma16(A[s_][g][1], Bw[k][1], acc[g]);
+        }
+      }
+    }
+    // epilogue: the wave's [64 rows][16 channels] through its own scratch -> 16-B stores (two per lane)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) escr[(g * 16 + 4 * kq + r) * 20 + ri] = acc[g][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rr = (lane >> 1) + 32 * it, cv = lane & 1;
+      const unsigned ea = es_a + (unsigned)((rr * 20 + cv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      const u32x4 o = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                            pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+      const unsigned off = (rr < nown && !(p.dbg & 4)) ? (unsigned)(row0 + rr) * 128u + (unsigned)(wv * 32 + cv * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ro, (int)off, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) hn[c] = hnn[c];
+    buf ^= 1;
+  }
+}
+
+extern "C" int conv_blk_t(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int dbg,
+                          void* stream) {
+  BlkT p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint16_t*)lrb, n, nunits, dbg};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * T_STAGE_B + 4 * 64 * 20 * 4;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk_t), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+  k_conv_blk_t<<<256, 256, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+
+// ---- variant U: level 2, 64 -> 64, "stream-q with a stage": a workgroup of two waves (two workgroups per CU) owns a unit of <= 64 rows (wave w: rows
+// 32 w .. 32 w + 31), the unit's own + halo rows are staged once in LDS (two stages), the weights are streamed tap by tap through a
+// double-buffered 8-KB LDS tile by LDS-DMA (one barrier per tap, as in tl_conv_streamq.hip), 32x32x16 MFMAs: per tap and wave 4 A fragments
+// from the stage + 8 B fragments from the weight tile feed 8 MFMAs.  The staging DMAs of the next unit are interleaved with the taps (one per
+// tap after that tap's weight DMAs) so that the per-tap counted wait never covers them.
+struct BlkU {
+  const uint16_t* x; const uint16_t* w; uint16_t* out;
+  const int32_t* unit;      // [nunits][4] = row0, n_own, -, n_halo (<= 184)
+  const int32_t* halo;      // [nunits][192]
+  const uint16_t* lrb;      // [nunits][64 rows][32]: stage byte offset (position * 128 + ((position >> 1) & 7) * 16), absent = 255 * 128
+  int64_t n; int nunits; int dbg;
+};
+constexpr int U_STAGE_B = 256 * 128, U_W_B = 64 * 128;
+
+__global__ void __launch_bounds__(128) k_conv_blk_u(BlkU p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // [2 stages][256 rows][128 B] | [2][64 cout][128 B] weights
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 31, fh = lane >> 5;
+  for (int e = tid; e < 2 * U_STAGE_B / 16; e += 128) *reinterpret_cast<u32x4*>(smem + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const unsigned st0 = (unsigned)(uintptr_t)(lds_ptr)smem, wb0 = st0 + 2 * U_STAGE_B;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, 27 * 64 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.n * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.lrb), 0, (int)((int64_t)p.nunits * 4096), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.halo), 0, (int)((int64_t)p.nunits * 192 * 4), 0x00020000);
+  const int gb = (int)blockIdx.x, nb = (int)gridDim.x;
+  // weight DMA: tap k = 8 KB = 8 chunks of 8 cout rows; wave w takes chunks 4 w .. 4 w + 3; lane L: row L >> 3, position L & 7 holds piece (L & 7) ^ (row & 7)
+  const unsigned wdma = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16));
+  auto dma_w = [&](int k, int wbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ch = 4 * wv + c;
+      const unsigned off = k < 27 ? (unsigned)(k * U_W_B + ch * 1024) + wdma : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + 2 * U_STAGE_B + wbuf * U_W_B + ch * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+  // B fragment of (cout block nbk, k-step s): lane (n = fi, half fh): row 32 nbk + fi, piece 2 s + fh at position (2 s + fh) ^ (fi & 7)
+  unsigned boff[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) boff[s_] = (unsigned)(fi * 128 + (((2 * s_ + fh) ^ (fi & 7)) * 16));
+  // staging: 32 chunks of 8 rows per unit (8 own + 24 halo); wave w issues chunks w, w + 2, ... (16 per wave), chunk j of the wave at tap j
+  auto load_hidx = [&](int u, int (&h)[12]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const unsigned off = u < p.nunits ? ((unsigned)u * 192u + (unsigned)((2 * c + wv) * 8 + (lane >> 3))) * 4u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
+    }
+  };
+  auto load_rb = [&](int u, u32x4 (&rb)[4]) __attribute__((always_inline)) {
+    const unsigned off = u < p.nunits ? (unsigned)u * 4096u + (unsigned)((wv * 32 + fi) * 64) : 0xFFFFFFFFu;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[0]) : "v"(off), "s"(rl));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[1]) : "v"(off), "s"(rl));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[2]) : "v"(off), "s"(rl));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[3]) : "v"(off), "s"(rl));
+  };
+  // one staging chunk (j = 0 .. 15 of this wave) of unit u into `stage`
+  auto stage_chunk = [&](int u, int j, const int (&h)[12], char* stage) __attribute__((always_inline)) {
+    const bool ok = u < p.nunits;
+    const int row0 = ok ? p.unit[4 * u] : 0, nown = ok ? p.unit[4 * u + 1] : 0, nh = ok ? p.unit[4 * u + 3] : 0;
+    const int ch = 2 * j + wv;                                                        // chunk 0 .. 31 of the unit
+    const int pos = ch * 8 + (lane >> 3);
+    unsigned off;
+    if (j < 4) off = pos < nown ? (unsigned)(row0 + pos) * 128u + (unsigned)((((lane & 7) ^ ((pos >> 1) & 7))) * 16) : 0xFFFFFFFFu;
+    else {
+      const int hj = pos - 64;
+      off = hj < nh ? (unsigned)h[j - 4] * 128u + (unsigned)((((lane & 7) ^ ((pos >> 1) & 7))) * 16) : 0xFFFFFFFFu;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + ch * 1024), 16, (int)off, 0, 0, 0);
+  };
+
+  int hc[12], hn[12];
+  u32x4 rbc[4], rbn[4];
+  load_hidx(gb, hc); load_hidx(gb + nb, hn); load_rb(gb, rbc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 12; ++c) { KEEP(hc[c]); KEEP(hn[c]); }
+  if (!(p.dbg & 1)) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) stage_chunk(gb, j, hc, smem);
+  }
+  dma_w(0, 0);
+  int buf = 0;
+  bool firstu = true;
+  for (int u = gb; u < p.nunits; u += nb) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1];
+    const unsigned st_a = st0 + (unsigned)(buf * U_STAGE_B);
+    char* nstage = smem + (buf ^ 1) * U_STAGE_B;
+    // entry: outstanding = [this unit's stage chunks (issued during the previous unit's taps), rulebook / indices, weights of tap 0, the
+    // previous unit's stores]: everything but the stores (4 per lane) has landed after this wait
+    if (firstu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!firstu) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { KEEP(rbn[q]); rbc[q] = rbn[q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) KEEP(rbc[q]);
+    }
+    firstu = false;
+    int hnn[12];
+    load_hidx(u + 2 * nb, hnn);
+    load_rb(u + nb, rbn);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      // weights of tap k have landed in this wave (waited for at the end of tap k - 1 / at entry); barrier: in the other wave too, and
+      // both waves are done with weight buffer (k + 1) & 1 (tap k - 1)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      dma_w(k + 1, (k + 1) & 1);                                                     // (tap 27 = tap 0 of the next unit's weights: requested below instead)
+      if (k < 16 && !(p.dbg & 1)) stage_chunk(u + nb, k, hn, nstage);               // one staging chunk of the next unit per tap, younger than the weights
+      if (!(p.dbg & 2)) {
+        const uint32_t wd = rbc[k >> 3][(k >> 1) & 3];
+        const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+        const unsigned a0 = st_a + val;
+        u32x4 A[4], B[2][4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) A[s_] = lds_r128(a0 ^ (unsigned)((2 * s_ + fh) * 16));
+        const unsigned wbb = wb0 + (unsigned)((k & 1) * U_W_B);
+#pragma unroll
+        for (int nbk = 0; nbk < 2; ++nbk)
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) B[nbk][s_] = lds_r128(wbb + (unsigned)(nbk * 32 * 128) + boff[s_]);
+        LGKM(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) { KEEP(A[s_]); KEEP(B[0][s_]); KEEP(B[1][s_]); }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_]), __builtin_bit_cast(bf16x8, B[0][s_]), acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_]), __builtin_bit_cast(bf16x8, B[1][s_]), acc[1], 0, 0, 0);
+        }
+      }
+      // weights of tap k + 1 must have landed before the next barrier; younger than them: at most this tap's staging chunk
+      if (k < 16 && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // (dma_w(27, 1) requested nothing: out-of-range offsets.)  Weights of the next unit's tap 0 into buffer 0: free after the barrier below.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    dma_w(0, 0);
+    // epilogue through the dead stage: wave w rows 32 w .. 32 w + 31, 64 channels (pitch 68 floats)
+    float* ew = reinterpret_cast<float*>(smem + buf * U_STAGE_B) + wv * (32 * 68);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * 68 + t * 32 + fi] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 3) + 8 * it, cv = lane & 7;
+      const unsigned ea = st_a + (unsigned)((wv * 32 * 68 + rr * 68 + cv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      const u32x4 o = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                            pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+      const int lr = wv * 32 + rr;
+      const unsigned off = (lr < nown && !(p.dbg & 4)) ? (unsigned)(row0 + lr) * 128u + (unsigned)(cv * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ro, (int)off, 0, 0);
+    }
+    // both waves must be out of the scratch before the next-but-one unit's staging overwrites it: that staging starts after the NEXT unit's
+    // first barrier, which every wave reaches only after its epilogue
+#pragma unroll
+    for (int c = 0; c < 12; ++c) hn[c] = hnn[c];
+    buf ^= 1;
+  }
+}
+
+extern "C" int conv_blk_u(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int dbg,
+                          void* stream) {
+  BlkU p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint16_t*)lrb, n, nunits, dbg};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * U_STAGE_B + 2 * U_W_B;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk_u), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+  k_conv_blk_u<<<512, 128, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+
+// ---- variant V: level 2, 64 -> 64: tl_conv_streamq.hip's structure (8 waves, weights streamed tap by tap through LDS, one barrier per tap, 32x32x16
+// MFMAs, 4 A + 8 B fragments per 8 MFMAs) with the A fragments read from STAGED units instead of gathered: the workgroup owns four units at a time
+// (wave pair q: unit 4 j + q, own single-buffered stage of 256 rows), a ring of four 8-KB weight tiles filled by LDS-DMA three taps ahead (one
+// 1-KB chunk per wave and tap), the next four units' halo indices / rulebooks requested during the taps, their staging between the quads.
+__global__ void __launch_bounds__(512) k_conv_blk_v(BlkU p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // [4 stages][256 rows][128 B] | [4][64 cout][128 B] weight ring
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 31, fh = lane >> 5, pq = wv >> 1, pw = wv & 1;           // pair, wave in pair
+  for (int e = tid; e < 4 * U_STAGE_B / 16; e += 512) *reinterpret_cast<u32x4*>(smem + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const unsigned st0 = (unsigned)(uintptr_t)(lds_ptr)smem, wb0 = st0 + 4 * U_STAGE_B;
+  char* stage = smem + pq * U_STAGE_B;
+  const unsigned st_a = st0 + (unsigned)(pq * U_STAGE_B);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, 27 * 64 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.n * 128), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.lrb), 0, (int)((int64_t)p.nunits * 4096), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.halo), 0, (int)((int64_t)p.nunits * 192 * 4), 0x00020000);
+  const int gb = (int)blockIdx.x, nb = (int)gridDim.x;
+  const int nquads = (p.nunits + 3) >> 2;
+  // weight DMA: wave w fills chunk w (cout rows 8 w .. 8 w + 7) of tap k's tile
+  const unsigned wdma = (unsigned)(wv * 1024 + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16));
+  auto dma_w = [&](int k) __attribute__((always_inline)) {
+    const unsigned off = k < 27 ? (unsigned)(k * U_W_B) + wdma : 0xFFFFFFFFu;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + 4 * U_STAGE_B + (k & 3) * U_W_B + wv * 1024), 16, (int)off, 0, 0, 0);
+  };
+  unsigned boff[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) boff[s_] = (unsigned)(fi * 128 + (((2 * s_ + fh) ^ (fi & 7)) * 16));
+  auto load_hidx = [&](int u, int (&h)[12]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const unsigned off = u < p.nunits ? ((unsigned)u * 192u + (unsigned)((2 * c + pw) * 8 + (lane >> 3))) * 4u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
+    }
+  };
+  auto load_rb = [&](int u, u32x4 (&rb)[4]) __attribute__((always_inline)) {
+    const unsigned off = u < p.nunits ? (unsigned)u * 4096u + (unsigned)((pw * 32 + fi) * 64) : 0xFFFFFFFFu;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[0]) : "v"(off), "s"(rl));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[1]) : "v"(off), "s"(rl));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[2]) : "v"(off), "s"(rl));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[3]) : "v"(off), "s"(rl));
+  };
+  auto stage_unit = [&](int u, const int (&h)[12]) __attribute__((always_inline)) {       // 16 chunks of 8 rows per wave (the pair: 32)
+    const bool ok = u < p.nunits;
+    const int row0 = ok ? p.unit[4 * u] : 0, nown = ok ? p.unit[4 * u + 1] : 0, nh = ok ? p.unit[4 * u + 3] : 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ch = 2 * j + pw, pos = ch * 8 + (lane >> 3);
+      unsigned off;
+      if (j < 4) off = pos < nown ? (unsigned)(row0 + pos) * 128u + (unsigned)((((lane & 7) ^ ((pos >> 1) & 7))) * 16) : 0xFFFFFFFFu;
+      else { const int hj = pos - 64; off = hj < nh ? (unsigned)h[j - 4] * 128u + (unsigned)((((lane & 7) ^ ((pos >> 1) & 7))) * 16) : 0xFFFFFFFFu; }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + ch * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  int hc[12], hn[12];
+  u32x4 rbc[4], rbn[4];
+  load_hidx(4 * gb + pq, hc); load_rb(4 * gb + pq, rbc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 12; ++c) KEEP(hc[c]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) KEEP(rbc[q]);
+  for (int j = gb; j < nquads; j += nb) {
+    const int u = 4 * j + pq;
+    const bool uok = u < p.nunits;
+    const int row0 = uok ? p.unit[4 * u] : 0, nown = uok ? p.unit[4 * u + 1] : 0;
+    // stage this quad (the stages are free: everybody left the previous quad's epilogue at the barrier below), weights of taps 0 .. 2
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!(p.dbg & 1)) stage_unit(u, hc);
+    dma_w(0); dma_w(1); dma_w(2);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                   // stage + weights(0) landed (stores of the previous quad are older than all of it)
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // weights(k) landed in every wave; ring slot (k + 3) & 3 (tap k - 1) is free
+      dma_w(k + 3);
+      if (k == 5) { load_hidx(4 * (j + nb) + pq, hn); load_rb(4 * (j + nb) + pq, rbn); }
+      if (!(p.dbg & 2)) {
+        const uint32_t wd = rbc[k >> 3][(k >> 1) & 3];
+        const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+        const unsigned a0 = st_a + val;
+        u32x4 A[4], B[2][4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) A[s_] = lds_r128(a0 ^ (unsigned)((2 * s_ + fh) * 16));
+        const unsigned wbb = wb0 + (unsigned)((k & 3) * U_W_B);
+#pragma unroll
+        for (int nbk = 0; nbk < 2; ++nbk)
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) B[nbk][s_] = lds_r128(wbb + (unsigned)(nbk * 32 * 128) + boff[s_]);
+        LGKM(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) { KEEP(A[s_]); KEEP(B[0][s_]); KEEP(B[1][s_]); }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_]), __builtin_bit_cast(bf16x8, B[0][s_]), acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_]), __builtin_bit_cast(bf16x8, B[1][s_]), acc[1], 0, 0, 0);
+        }
+      }
+      // before the next barrier: this wave's chunk of weights(k + 1); younger: weights(k + 2), (k + 3) and, for three taps, the 16 look-ahead loads
+      if (k >= 5 && k <= 7) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every pair is done with its stage
+    float* ew = reinterpret_cast<float*>(stage) + pw * (32 * 68);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * 68 + t * 32 + fi] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 3) + 8 * it, cv = lane & 7;
+      const unsigned ea = st_a + (unsigned)((pw * 32 * 68 + rr * 68 + cv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      const u32x4 o = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                            pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+      const int lr = pw * 32 + rr;
+      const unsigned off = (lr < nown && !(p.dbg & 4)) ? (unsigned)(row0 + lr) * 128u + (unsigned)(cv * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ro, (int)off, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) { KEEP(hn[c]); hc[c] = hn[c]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { KEEP(rbn[q]); rbc[q] = rbn[q]; }
+  }
+}
+
+extern "C" int conv_blk_v(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int dbg,
+                          void* stream) {
+  BlkU p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint16_t*)lrb, n, nunits, dbg};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * U_STAGE_B + 4 * U_W_B;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk_v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+  k_conv_blk_v<<<256, 512, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int conv_blk(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int waves,
                         int dbg, void* stream) {
   BlkP p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint8_t*)lrb, n, nunits, dbg};

@@ -156,3 +156,154 @@ for waves in (4, 2, 1):
           f"equal rows {float((got == ref).all(dim=1).float().mean()) * 100:.2f} %, max diff {float((got.float() - ref.float()).abs().max() / ref.float().abs().max()):.1e}", flush=True)
 for dbg in (1, 2, 4, 3, 7):
     print(f"  variant S ablation {dbg}: {timeit(lambda: run_s(4, dbg)):.3f} ms", flush=True)
+
+
+# ---------------------------------------------------------------- variant T: level 2, 64 -> 64, workgroup of four waves shares a unit's stage
+L.conv_blk_t.restype = ctypes.c_int
+L.conv_blk_t.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+lv2 = geom.levels[1]
+n2 = lv2.n
+c2 = lv2.coords.long()
+key2 = ((c2[:, 0] * 4096 + (c2[:, 1] // 8)) * 4096 + (c2[:, 2] // 8)) * 4096 + (c2[:, 3] // 8)
+perm2 = torch.argsort(key2, stable=True)
+o2n2 = torch.empty_like(perm2); o2n2[perm2] = torch.arange(n2, device=dev)
+nbr2 = lv2.nbr.long()[:, perm2]
+presT = nbr2 >= 0
+nnT = torch.where(presT, o2n2[nbr2.clamp(min=0)], torch.full_like(nbr2, -1))
+bsT = torch.zeros(n2, dtype=torch.bool, device=dev); bsT[::64] = True
+for _ in range(8):
+    uidT = torch.cumsum(bsT.long(), 0) - 1
+    nuT = int(uidT[-1]) + 1
+    row0T = torch.nonzero(bsT).flatten()
+    nownT = torch.bincount(uidT, minlength=nuT)
+    u_rowT = uidT[None, :].expand_as(nnT)
+    insT = presT & (uidT[nnT.clamp(min=0)] == u_rowT)
+    outT = presT & ~insT
+    pkT = (u_rowT[outT] * n2 + nnT[outT])
+    upT = torch.unique(pkT)
+    huT = upT // n2
+    nhT = torch.bincount(huT, minlength=nuT)
+    big = torch.nonzero(nhT > 192).flatten()
+    if big.numel() == 0:
+        break
+    bsT[row0T[big] + nownT[big] // 2] = True
+hstT = torch.cumsum(nhT, 0) - nhT
+print(f"level 2: rows {n2}, units {nuT}, own/unit {float(nownT.float().mean()):.1f}, halo/unit mean {float(nhT.float().mean()):.1f} max {int(nhT.max())}, "
+      f"staged rows per output row {float((nownT + nhT).sum()) / n2:.2f}, 16-row groups padded/own {float(((nownT + 15) // 16 * 16).sum()) / n2:.2f}", flush=True)
+assert int(nhT.max()) <= 192
+posT = torch.full_like(nnT, 319)
+posT[insT] = (nnT - row0T[uidT][None, :])[insT]
+posT[outT] = 64 + torch.searchsorted(upT, pkT) - hstT[u_rowT[outT]]
+valT = posT * 128 + ((posT >> 1) & 7) * 16
+haloT = torch.full((nuT, 192), -1, dtype=torch.int32, device=dev)
+haloT[huT, torch.arange(upT.numel(), device=dev) - hstT[huT]] = (upT % n2).int()
+unitT = torch.stack([row0T, nownT, torch.zeros_like(row0T), nhT], 1).int().contiguous()
+lrbT = torch.full((nuT * 64, 32), 319 * 128, dtype=torch.int32, device=dev)
+lrbT[uidT * 64 + (torch.arange(n2, device=dev) - row0T[uidT]), :27] = valT.t().int()
+lrbT = (lrbT & 0xFFFF).to(torch.int32)
+lrbT = torch.where(lrbT >= 32768, lrbT - 65536, lrbT).to(torch.int16).contiguous()      # 16-bit patterns (values up to 40 959)
+x2 = torch.randn(n2, 64, device=dev).bfloat16()
+w2 = torch.randn(64, 3, 3, 3, 64, device=dev) * 0.05
+wp2 = ops.pack_weight(w2.reshape(64, 27, 64), torch.bfloat16)
+ref2 = ops.conv_fwd(x2, wp2, lv2.nbr, n2)
+xn2 = x2[perm2].contiguous()
+outT_ = torch.zeros(n2, 64, device=dev, dtype=torch.bfloat16)
+
+
+def run_t(dbg=0):
+    rc = L.conv_blk_t(xn2.data_ptr(), wp2.data_ptr(), outT_.data_ptr(), unitT.data_ptr(), haloT.data_ptr(), lrbT.data_ptr(), n2, nuT, dbg, st)
+    assert rc == 0, rc
+
+
+run_t(); torch.cuda.synchronize()
+gotT = torch.empty_like(outT_); gotT[perm2] = outT_
+t_ref2 = timeit(lambda: ops.conv_fwd(x2, wp2, lv2.nbr, n2))
+print(f"level 2 64->64: production kernel (k_conv_streamq) {t_ref2:.3f} ms | variant T {timeit(run_t):.3f} ms, equal rows "
+      f"{float((gotT == ref2).all(dim=1).float().mean()) * 100:.2f} %, max diff {float((gotT.float() - ref2.float()).abs().max() / ref2.float().abs().max()):.1e}", flush=True)
+for dbg in (1, 2, 4, 3, 7):
+    print(f"  variant T ablation {dbg}: {timeit(lambda: run_t(dbg)):.3f} ms", flush=True)
+
+
+# ---------------------------------------------------------------- variant U: level 2, streamed weights + staged unit (halo <= 184, absent = position 255)
+L.conv_blk_u.restype = ctypes.c_int
+L.conv_blk_u.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+bsU = torch.zeros(n2, dtype=torch.bool, device=dev); bsU[::64] = True
+for _ in range(8):
+    uidU = torch.cumsum(bsU.long(), 0) - 1
+    nuU = int(uidU[-1]) + 1
+    row0U = torch.nonzero(bsU).flatten()
+    nownU = torch.bincount(uidU, minlength=nuU)
+    u_rowU = uidU[None, :].expand_as(nnT)
+    insU = presT & (uidU[nnT.clamp(min=0)] == u_rowU)
+    outU = presT & ~insU
+    pkU = (u_rowU[outU] * n2 + nnT[outU])
+    upU = torch.unique(pkU)
+    huU = upU // n2
+    nhU = torch.bincount(huU, minlength=nuU)
+    big = torch.nonzero(nhU > 184).flatten()
+    if big.numel() == 0:
+        break
+    bsU[row0U[big] + nownU[big] // 2] = True
+hstU = torch.cumsum(nhU, 0) - nhU
+print(f"variant U units: {nuU}, own/unit {float(nownU.float().mean()):.1f}, halo/unit mean {float(nhU.float().mean()):.1f} max {int(nhU.max())}, "
+      f"32-row tiles padded/own {float(((nownU + 31) // 32 * 32).sum()) / n2:.2f}", flush=True)
+assert int(nhU.max()) <= 184
+posU = torch.full_like(nnT, 255)
+posU[insU] = (nnT - row0U[uidU][None, :])[insU]
+posU[outU] = 64 + torch.searchsorted(upU, pkU) - hstU[u_rowU[outU]]
+valU = posU * 128 + ((posU >> 1) & 7) * 16
+haloU = torch.full((nuU, 192), -1, dtype=torch.int32, device=dev)
+haloU[huU, torch.arange(upU.numel(), device=dev) - hstU[huU]] = (upU % n2).int()
+unitU = torch.stack([row0U, nownU, torch.zeros_like(row0U), nhU], 1).int().contiguous()
+lrbU = torch.full((nuU * 64, 32), 255 * 128, dtype=torch.int32, device=dev)
+lrbU[uidU * 64 + (torch.arange(n2, device=dev) - row0U[uidU]), :27] = valU.t().int()
+lrbU = torch.where(lrbU >= 32768, lrbU - 65536, lrbU).to(torch.int16).contiguous()
+outU_ = torch.zeros(n2, 64, device=dev, dtype=torch.bfloat16)
+
+
+def run_u(dbg=0):
+    rc = L.conv_blk_u(xn2.data_ptr(), wp2.data_ptr(), outU_.data_ptr(), unitU.data_ptr(), haloU.data_ptr(), lrbU.data_ptr(), n2, nuU, dbg, st)
+    assert rc == 0, rc
+
+
+run_u(); torch.cuda.synchronize()
+gotU = torch.empty_like(outU_); gotU[perm2] = outU_
+print(f"level 2 64->64: production kernel (k_conv_streamq) {t_ref2:.3f} ms | variant U {timeit(run_u):.3f} ms, equal rows "
+      f"{float((gotU == ref2).all(dim=1).float().mean()) * 100:.2f} %, max diff {float((gotU.float() - ref2.float()).abs().max() / ref2.float().abs().max()):.1e}", flush=True)
+for dbg in (1, 2, 4, 3, 7):
+    print(f"  variant U ablation {dbg}: {timeit(lambda: run_u(dbg)):.3f} ms", flush=True)
+
+
+# ---------------------------------------------------------------- variant V: stream-q with staged units (8 waves, four units at a time, weight ring of 4)
+L.conv_blk_v.restype = ctypes.c_int
+L.conv_blk_v.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+outV_ = torch.zeros(n2, 64, device=dev, dtype=torch.bfloat16)
+
+
+def run_v(dbg=0):
+    rc = L.conv_blk_v(xn2.data_ptr(), wp2.data_ptr(), outV_.data_ptr(), unitU.data_ptr(), haloU.data_ptr(), lrbU.data_ptr(), n2, nuU, dbg, st)
+    assert rc == 0, rc
+
+
+run_v(); torch.cuda.synchronize()
+gotV = torch.empty_like(outV_); gotV[perm2] = outV_
+print(f"level 2 64->64: production kernel (k_conv_streamq) {t_ref2:.3f} ms | variant V {timeit(run_v):.3f} ms, equal rows "
+      f"{float((gotV == ref2).all(dim=1).float().mean()) * 100:.2f} %, equal to variant U {bool(torch.equal(outV_, outU_))}, "
+      f"max diff {float((gotV.float() - ref2.float()).abs().max() / ref2.float().abs().max()):.1e}", flush=True)
+for dbg in (1, 2, 4, 3, 7):
+    print(f"  variant V ablation {dbg}: {timeit(lambda: run_v(dbg)):.3f} ms", flush=True)
+
+d_uv = (outV_ != outU_).any(dim=1)
+run_v(); torch.cuda.synchronize(); v2 = outV_.clone(); run_v(); torch.cuda.synchronize()
+run_u(); torch.cuda.synchronize(); u2 = outU_.clone(); run_u(); torch.cuda.synchronize()
+print(f"rows that differ between variants U and V: {int(d_uv.sum())}; V run-to-run differing rows {int((v2 != outV_).any(dim=1).sum())}; U run-to-run {int((u2 != outU_).any(dim=1).sum())}; "
+      f"U vs float-accumulated reference max {float((gotU.float() - ref2.float()).abs().max()):.3e}, V {float((gotV.float() - ref2.float()).abs().max()):.3e}")
+# float64 reference on a sample of rows
+idx = torch.randint(0, n2, (3000,), device=dev)
+tab = lv2.nbr[:, idx].long()
+acc = torch.zeros(3000, 64, dtype=torch.float64, device=dev)
+for k in range(27):
+    m = tab[k] >= 0
+    acc[m] += x2.double()[tab[k][m]] @ wp2.double()[k].T
+for name, g in (("stream-q", ref2), ("variant U", gotU), ("variant V", gotV)):
+    print(f"  {name}: max |y - float64| / max |float64| on 3000 rows = {float((g[idx].double() - acc).abs().max() / acc.abs().max()):.3e}")
