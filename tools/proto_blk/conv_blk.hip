@@ -979,6 +979,189 @@ extern "C" int conv_blk_v(const void* x, const void* w, void* out, const void* u
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+
+// ---- variant W: variant S's tap loop with TWO waves per SIMD: the weights go back to LDS (55 KB), every wave has ONE stage of 192 rows (halo <= 128), the
+// next unit's staging is requested as soon as this unit's results have left the stage (before its stores), rulebook / indices one and two units ahead.
+// While one wave of a SIMD waits for its stage, the other one computes.
+constexpr int W_STAGE_B = 192 * 64, W_HCH = 8, W_ZERO = 191;
+
+template <int W>
+__global__ void __launch_bounds__(W * 64) k_conv_blk_w(BlkS p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 31, fh = lane >> 5;
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
+    for (int v = tid; v < 27 * 128; v += W * 64) {
+      const int s_ = v & 3, n = (v >> 2) & 31, k = v >> 7;
+      *reinterpret_cast<u32x4*>(smem + (k * 32 + n) * 64 + ((s_ ^ ((n >> 2) & 3)) * 16)) = wsrc[v];
+    }
+  }
+  char* stage = smem + WS_B + wv * W_STAGE_B;
+  for (int e = lane; e < W_STAGE_B / 16; e += 64) *reinterpret_cast<u32x4*>(stage + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem, st_a = lds0 + (unsigned)(WS_B + wv * W_STAGE_B);
+  unsigned boff[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) boff[s_] = lds0 + (unsigned)(fi * 64 + (((2 * s_ + fh) ^ ((fi >> 2) & 3)) * 16));
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, (int)(p.n * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.n * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.lrb), 0, (int)((int64_t)p.nunits * 4096), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.halo), 0, (int)((int64_t)p.nunits * W_HCH * 16 * 4), 0x00020000);
+  const int gw = (int)blockIdx.x * W + wv, nw = (int)gridDim.x * W;
+  const unsigned pc16[2] = {(unsigned)(fh * 16), (unsigned)(32 + fh * 16)};
+
+  auto load_hidx = [&](int u, int (&h)[W_HCH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < W_HCH; ++c) {
+      const unsigned off = u < p.nunits ? ((unsigned)u * (W_HCH * 16) + (unsigned)(c * 16 + (lane >> 2))) * 4u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
+    }
+  };
+  auto load_rb = [&](int u, u32x4 (&rb)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned off = u < p.nunits ? (unsigned)u * 4096u + (unsigned)((t * 32 + fi) * 64) : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[t][0]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[t][1]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[t][2]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[t][3]) : "v"(off), "s"(rl));
+    }
+  };
+  // staging: 4 own chunks + as many halo chunks as the unit has (the counted wait below does not depend on their number)
+  auto stage_unit = [&](int u, const int (&h)[W_HCH]) __attribute__((always_inline)) {
+    if (u >= p.nunits) return;
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1], nh = p.unit[4 * u + 3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int pos = c * 16 + (lane >> 2);
+      const unsigned off = pos < nown ? (unsigned)(row0 + pos) * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + c * 1024), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < W_HCH; ++c) {
+      if (c * 16 < nh) {
+        const int j = c * 16 + (lane >> 2), pos = 64 + j;
+        const unsigned off = j < nh ? (unsigned)h[c] * 64u + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + 4096 + c * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  int hn[W_HCH];
+  u32x4 rbc[2][4], rbn[2][4];
+  {
+    int h0[W_HCH];
+    load_hidx(gw, h0); load_hidx(gw + nw, hn); load_rb(gw, rbc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < W_HCH; ++c) { KEEP(h0[c]); KEEP(hn[c]); }
+    if (!(p.dbg & 1)) stage_unit(gw, h0);
+  }
+  bool firstu = true;
+  for (int u = gw; u < p.nunits; u += nw) {
+    const int row0 = p.unit[4 * u], nown = p.unit[4 * u + 1];
+    // this unit's stage has landed (requested before the previous unit's four stores), and so have its rulebook and the next unit's halo indices
+    if (firstu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (!firstu) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { KEEP(rbn[t][q]); rbc[t][q] = rbn[t][q]; }
+#pragma unroll
+      for (int c = 0; c < W_HCH; ++c) KEEP(hn[c]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) KEEP(rbc[t][q]);
+    }
+    firstu = false;
+    int hcur[W_HCH];
+#pragma unroll
+    for (int c = 0; c < W_HCH; ++c) hcur[c] = hn[c];                                  // indices of unit t + 1 (for the staging after the taps)
+    load_hidx(u + 2 * nw, hn);                                                       // unit t + 2
+    load_rb(u + nw, rbn);                                                            // unit t + 1
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    if (!(p.dbg & 2)) {
+      constexpr int D = 2;                                                           // 6 reads per tap: lgkmcnt counts to 15
+      u32x4 A[D][2][2], B[D][2];
+      auto issue = [&](int k, int s_) __attribute__((always_inline)) {
+        B[s_][0] = lds_r128(boff[0] + (unsigned)(k * 2048));
+        B[s_][1] = lds_r128(boff[1] + (unsigned)(k * 2048));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint32_t wd = rbc[t][k >> 3][(k >> 1) & 3];
+          const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+          const unsigned a0 = st_a + val;
+          A[s_][t][0] = lds_r128(a0 ^ pc16[0]);
+          A[s_][t][1] = lds_r128(a0 ^ pc16[1]);
+        }
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int s_ = k & 1;
+        if (k + 1 < 27) { issue(k + 1, s_ ^ 1); LGKM(6); } else LGKM(0);
+        KEEP(B[s_][0]); KEEP(B[s_][1]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          KEEP(A[s_][t][0]); KEEP(A[s_][t][1]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_][t][0]), __builtin_bit_cast(bf16x8, B[s_][0]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s_][t][1]), __builtin_bit_cast(bf16x8, B[s_][1]), acc[t], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* ew = reinterpret_cast<float*>(stage);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ew[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fi] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned ea = st_a + (unsigned)((rr * 36 + cvv * 8) * 4);
+      u32x4 u0 = lds_r128(ea), u1 = lds_r128(ea + 16);
+      LGKM(0);
+      KEEP(u0); KEEP(u1);
+      o[it] = u32x4{pack2(__uint_as_float(u0[0]), __uint_as_float(u0[1])), pack2(__uint_as_float(u0[2]), __uint_as_float(u0[3])),
+                    pack2(__uint_as_float(u1[0]), __uint_as_float(u1[1])), pack2(__uint_as_float(u1[2]), __uint_as_float(u1[3]))};
+    }
+    // the stage is free (the results are in registers): the next unit's staging goes out BEFORE this unit's stores, so that the wait at the
+    // top of the next iteration can leave the stores outstanding
+    if (!(p.dbg & 1)) stage_unit(u + nw, hcur);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = (lane >> 2) + 16 * it, cvv = lane & 3;
+      const unsigned off = (rr < nown && !(p.dbg & 4)) ? (unsigned)(row0 + rr) * 64u + (unsigned)(cvv * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o[it]), ro, (int)off, 0, 0);
+    }
+  }
+}
+
+extern "C" int conv_blk_w(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int waves,
+                          int dbg, void* stream) {
+  BlkS p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint16_t*)lrb, n, nunits, dbg};
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)WS_B + (size_t)waves * W_STAGE_B;
+  if (lds > 160 * 1024) return -4;
+#define GOW(WW)                                                                                                                  \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk_w<WW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; \
+  k_conv_blk_w<WW><<<256, WW * 64, lds, s>>>(p);
+  if (waves == 8) { GOW(8) } else if (waves == 6) { GOW(6) } else if (waves == 4) { GOW(4) } else return -2;
+#undef GOW
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int conv_blk(const void* x, const void* w, void* out, const void* unit, const void* halo, const void* lrb, int64_t n, int nunits, int waves,
                         int dbg, void* stream) {
   BlkP p{(const uint16_t*)x, (const uint16_t*)w, (uint16_t*)out, (const int32_t*)unit, (const int32_t*)halo, (const uint8_t*)lrb, n, nunits, dbg};
