@@ -229,13 +229,14 @@ def test_config2_window_kernel_on_real_rulebooks(tile2, level, cin, cout):
 
 
 @pytest.mark.timeout(1200)
-def test_config2_forward_fp32_vs_oracle_end_to_end():
-    """End-to-end parity at workload scale: the fp32 forward of a 28x28 m tile of the config-2 generator (0.9 M points; all seven
-    levels above the small-level threshold except the last three, i.e. the kernel mix of the 40 m tile) within 1e-3 relative of
-    the CPU oracle's forward.  (The full 1.89 M-point tile is covered layer by layer on its real rulebooks above; its oracle
-    forward takes minutes of host time.)  The oracle runs in a child process with a thread pool sized to the usable cores."""
+@pytest.mark.parametrize("full", [False, True], ids=["28m_0.9Mpoints", "config2_40m_1.89Mpoints"])
+def test_config2_forward_fp32_vs_oracle_end_to_end(full):
+    """End-to-end parity at workload scale: the fp32 forward within 1e-3 relative of the CPU oracle's forward -- of a 28x28 m tile of
+    the config-2 generator (0.9 M points; the kernel mix of the 40 m tile) and of THE config-2 tile itself (40x40 m, 1.89 M points:
+    BASELINE.json configs[1], the workload the headline is quoted on; its layers are also covered one by one on their real rulebooks
+    above).  The oracle runs in a child process with a thread pool sized to the usable cores (about a minute for the full tile)."""
     import subprocess, sys, tempfile
-    batch = make_batch([make_tile(extent=28.0, voxel=0.1, n_trees=31, fill=0.10, seed=0)])
+    batch = make_batch([make_tile(**CONFIGS["config2"], seed=0) if full else make_tile(extent=28.0, voxel=0.1, n_trees=31, fill=0.10, seed=0)])
     model = _model(torch.float32)
     with torch.no_grad():
         out = model(batch, return_loss=False)
