@@ -132,6 +132,10 @@ typedef struct tl_level {
   int32_t* child;
   int32_t* parent;
   int32_t* inv;
+  /* optional (NULL = canonical order): the block-local order of THIS level (tl_blk_build's o2n).  The tables that hold or are indexed
+   * by rows of this level -- child (entries), parent / inv (index) and, on level 1, v2p (entries) -- are then written in that order.
+   * With o2n set, coords / nbr / compact of the level may be NULL (the block-local conv kernel needs none of them). */
+  const int32_t* o2n;
 } tl_level;
 
 /* coords + every rulebook of every level + (v2p != NULL) the point -> voxel map, in one call.  parent / inv arrays that lie
@@ -139,6 +143,34 @@ typedef struct tl_level {
  * one by one). */
 int tl_rulebooks_build(const tl_level* levels, int num_levels, int32_t* minus_one, int64_t minus_one_words,
                        const int32_t* pcoords, int64_t N, int64_t* v2p, tl_stream_t stream);
+
+/* ---- block-local row order + staged rulebook of a level (what the level-1 convs of the inference engine run on; csrc/tl_blk.hip).
+ * The reference's spconv keeps voxels in hash order and gathers every tap of every output row (blocks.py:57-70 -> spconv's
+ * implicit-GEMM gather); the canonical order here (ascending key) pins the bit-exact rulebook tests.  For the matrix-core kernel a
+ * THIRD, internal order is better: voxels sorted by (batch, x >> 3, y >> 3, z >> 3), canonical order inside a block.  Units of <= 64
+ * consecutive rows of that order then reach few rows outside themselves (their "halo"), so a wave can stage own + halo rows once in
+ * LDS and read all 27 taps from there.
+ *   o2n / perm     i32[n]: canonical row -> new row and back;  coords_new i32[n][4] = (b,x,y,z) in the new order
+ *   unit           i32[cap_units][4] = {first new row, rows (1..64), halo rows, 0}.  Chunk c = new rows [64 c, 64 c + 64) is unit c when
+ *                  its halo has <= halo_max rows; otherwise it is halved (recursively) and the pieces after the first are appended
+ *                  behind the ceil(n / 64) regular units in arrival order.  counter[0] (DEVICE) = number of units, counter[1] = error flag
+ *   halo           i32[32 n]: the unit that starts at row r0 lists its DISTINCT outside rows ascending at halo + 32 r0, padded with -1
+ *                  to a multiple of 16
+ *   lrb            u16[n][32]: entry k of a row = byte offset of tap k's input row in the unit's stage: pos * 64 + ((pos >> 2) & 3) * 16
+ *                  with pos = own row index (0..63), 64 + halo rank, or 191 = absent (the stage's zero row); entries 27..31 = absent
+ *   pmask          i32[n]: 27-bit presence mask of the row's taps
+ * n < 2^25.  ws u32[tl_blk_ws_words(dims)].  Deterministic apart from the order of the appended units. */
+#define TL_BLK_HALO_MAX 126
+typedef struct tl_blk {
+  int32_t* o2n; int32_t* perm; int32_t* coords_new;
+  int32_t* unit; int32_t* counter; int32_t* halo; uint16_t* lrb; int32_t* pmask;
+  int64_t cap_units;        /* rows of `unit` (>= ceil(n / 64); n always suffices) */
+  int32_t halo_max;         /* 26 .. TL_BLK_HALO_MAX */
+  int32_t reserved;
+} tl_blk;
+int64_t tl_blk_ws_words(const int32_t dims[4]);
+int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4], int64_t n, const tl_blk* out, uint32_t* ws,
+                 tl_stream_t stream);
 
 /* Column form of a 27-tap SubM rulebook built by tl_rulebook_subm: compact i32[10][n] = the row of the first present
  * dz neighbour of each of the 9 (dx, dy) columns (or -1) followed by a 27-bit presence mask.  Present neighbours of a
@@ -198,6 +230,11 @@ typedef struct tl_conv_args {
   int32_t* red_nparts;
   const void* bn_x;      int64_t bn_x_ld;
   const float* bn_mean;  const float* bn_rstd;  const float* bn_scale;  const float* bn_shift;  int32_t bn_relu;
+  /* Block-local form of a 27-tap SubM rulebook (tl_blk_build; all five NULL when absent).  `in`, `out*`, `residual` are then in the
+   * block-local row order, `table` may be NULL, and K = 27, Cin = Cout = 32, TL_BF16 / TL_F16, no prologue, epi_mode = 0 are served by
+   * the staged-unit kernel (csrc/tl_conv_blk.hip; same summation order as the gather kernels: bit-identical results); with
+   * in_all_ones the presence masks come from blk_pmask.  Other shapes fall through to `table` (TL_ERR_UNSUPPORTED without one). */
+  const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint16_t* blk_lrb; const int32_t* blk_pmask;
 } tl_conv_args;
 
 #define TL_EPI_NONE 0

@@ -1,0 +1,242 @@
+"""GPU tests of the block-local level-1 path (csrc/tl_blk.hip + csrc/tl_conv_blk.hip; include/treelearn_hip.h `tl_blk`, tl_conv_args.blk_*):
+
+geometry  order / units / halo lists / local rulebooks / presence masks bit-exact against the numpy restatement (oracle/blk.py), the staged
+          form decodes to the canonical rulebook (which the oracle pins, tests/test_gpu_configs.py), down / inverse tables and v2p are the
+          canonical ones carried into the new order; forced deep splitting (small halo bound); batches of tiles
+conv      the staged-unit kernel is torch.equal to the gather kernel (tl_conv_direct) on the same rulebook: plain, residual, two / three
+          views with BatchNorm affine + ReLU, column views of wider buffers, float16; on a mid-size tile and on THE config-2 tile
+model     the fused forward with level 1 in block-local order against the canonical-order forward and against the CPU oracle
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import blk as ob
+from oracle import voxel as ov
+from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
+
+
+def _batch(extent, seeds, n_trees=8):
+    return make_batch([make_tile(extent=extent, voxel=0.1, n_trees=n_trees, fill=0.1, seed=s) for s in seeds])
+
+
+def _geoms(batch, vs=0.1, sshape=(500, 500, 1000), ref_table=False, **kw):
+    from treelearn_amd.geometry import build_geometry
+    c, b = batch["coords"].cuda(), batch["batch_ids"].cuda()
+    can = build_geometry(c, b, int(batch["batch_size"]), vs, 7, list(sshape))
+    blk = build_geometry(c, b, int(batch["batch_size"]), vs, 7, list(sshape), blocked=True, ref_table=ref_table, **kw)
+    return can, blk
+
+
+def _check_blocked_geometry(can, blk, halo_max):
+    from treelearn_amd.geometry import BlockedRulebook
+    assert blk.blocked and isinstance(blk.levels[0].nbr, BlockedRulebook)
+    l0, r = can.levels[0], blk.levels[0].nbr
+    n = l0.n
+    coords = l0.coords.cpu().numpy(); nbr = l0.nbr.cpu().numpy()
+    o = ob.build_fast(coords, nbr, halo_max)
+    np.testing.assert_array_equal(r.perm.cpu().numpy(), o["perm"])
+    np.testing.assert_array_equal(r.o2n.cpu().numpy(), o["o2n"])
+    np.testing.assert_array_equal(r.coords_new.cpu().numpy(), o["coords_new"])
+    np.testing.assert_array_equal(r.pmask.cpu().numpy(), o["pmask"])
+    nu = int(r.counter[0]); assert int(r.counter[1]) == 0
+    assert nu == len(o["units"])
+    unit = r.unit[:nu].cpu().numpy()
+    nch = (n + 63) // 64
+    exp = np.array([[u[0], u[1], len(u[2]), 0] for u in o["units"]], np.int32)
+    np.testing.assert_array_equal(unit[:nch], exp[:nch])                                      # regular units: unit c = chunk c
+    key = lambda a: a[np.argsort(a[:, 0], kind="stable")]                                    # appended pieces arrive in any order
+    np.testing.assert_array_equal(key(unit[nch:]), key(exp[nch:]))
+    halo = r.halo.cpu().numpy()
+    for lo, cnt, h in o["units"]:
+        H = len(h); H16 = (H + 15) // 16 * 16
+        got = halo[32 * lo:32 * lo + H16]
+        assert np.array_equal(got[:H], h) and (got[H:] == -1).all(), (lo, cnt)
+    np.testing.assert_array_equal(r.lrb.view(torch.int16).cpu().numpy().view(np.uint16).reshape(n, 32), o["lrb"])
+    # the staged form decodes to the canonical table carried into the new order
+    np.testing.assert_array_equal(r.to_table().cpu().numpy().astype(np.int64), o["nn"])
+    # tables that hold / are indexed by level-1 rows, and v2p
+    o2n = torch.from_numpy(o["o2n"]).cuda(); perm = torch.from_numpy(o["perm"]).cuda()
+    ch = l0.child.long()
+    assert torch.equal(blk.levels[0].child.long(), torch.where(ch >= 0, o2n[ch.clamp(min=0)], ch))
+    assert torch.equal(blk.levels[0].parent, l0.parent[perm])
+    assert torch.equal(blk.levels[0].inv, l0.inv[:, perm])
+    assert torch.equal(blk.v2p, o2n[can.v2p])
+    for a, b in zip(can.levels[1:], blk.levels[1:]):                                          # the other levels are untouched
+        assert torch.equal(a.coords, b.coords) and torch.equal(a.nbr, b.nbr)
+        if a.child is not None:
+            assert torch.equal(a.child, b.child) and torch.equal(a.inv, b.inv) and torch.equal(a.parent, b.parent)
+    return o
+
+
+@pytest.mark.parametrize("halo_max", [126, 40, 26])
+def test_blocked_geometry_vs_oracle(halo_max):
+    """A 14 m tile (150 k voxels): everything bit-exact; halo bounds 40 and 26 force two to five levels of halving."""
+    import treelearn_amd.geometry as G
+    batch = _batch(14.0, [3])
+    old = G.BLK_HALO_MAX
+    G.BLK_HALO_MAX = halo_max
+    try:
+        can, blk = _geoms(batch)
+    finally:
+        G.BLK_HALO_MAX = old
+    o = _check_blocked_geometry(can, blk, halo_max)
+    assert max(len(u[2]) for u in o["units"]) <= halo_max
+    if halo_max < 126:
+        assert len(o["units"]) > (can.levels[0].n + 63) // 64
+
+
+def test_blocked_geometry_batch_of_unequal_tiles_and_ref_table():
+    """Three tiles of different size in one batch (blocks never span batch elements); with ref_table the canonical level-1 table rides along."""
+    batch = make_batch([make_tile(extent=e, voxel=0.1, n_trees=4, fill=0.1, seed=s) for e, s in ((9.0, 1), (13.0, 2), (6.0, 5))])
+    can, blk = _geoms(batch, ref_table=True)
+    _check_blocked_geometry(can, blk, 126)
+    assert torch.equal(blk.levels[0].nbr_ref, can.levels[0].nbr) and torch.equal(blk.levels[0].coords, can.levels[0].coords)
+    b = blk.levels[0].nbr.coords_new[:, 0]
+    assert bool((b[1:] >= b[:-1]).all())
+
+
+def test_blocked_geometry_small_tile_switches_off():
+    batch = _batch(5.0, [1], n_trees=2)
+    can, blk = _geoms(batch)
+    assert not blk.blocked and torch.equal(blk.levels[0].nbr, can.levels[0].nbr) and torch.equal(blk.v2p, can.v2p)
+    can, blk = _geoms(batch, blk_min_rows=1)                  # forced: works at any size
+    _check_blocked_geometry(can, blk, 126)
+
+
+def _conv_pair(can, blk, dtype, residual, views, wide, seed=0):
+    """The same conv on the canonical table (gather kernel) and on the block-local form; returns both results in canonical order."""
+    from treelearn_amd import ops
+    n = can.levels[0].n
+    dev = can.v2p.device
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(n, 32, generator=g) * 0.7).to(dtype).to(dev)
+    res = (torch.randn(n, 32, generator=g)).to(dtype).to(dev) if residual else None
+    w = ops.pack_weight((torch.randn(32, 3, 3, 3, 32, generator=g) * 0.08).to(dev), dtype)
+    aff = [((torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.3).to(dev)) for _ in range(3)]
+    r = blk.levels[0].nbr
+    perm = r.perm.long()
+
+    def run(table, xin, rin):
+        ld = 64 if wide else 32
+        outs = []
+        bufs = [torch.zeros(n, ld, dtype=dtype, device=dev) for _ in range(views)]
+        tgt = [b[:, ld - 32:] for b in bufs]                                   # column views of wider buffers when `wide`
+        xin_ = xin
+        if wide:
+            xb = torch.zeros(n, 64, dtype=dtype, device=dev); xb[:, 32:] = xin; xin_ = xb[:, 32:]
+        kw = {}
+        if views >= 2:
+            kw["out2"] = (tgt[1], aff[1][0], aff[1][1], True)
+        if views >= 3:
+            kw["out3"] = (tgt[2], None, None, True)
+        ops.conv_fwd(xin_, w, table, n, out=tgt[0], residual=rin, out_scale=aff[0][0] if views == 1 else None,
+                     out_shift=aff[0][1] if views == 1 else None, out_relu=views == 1, **kw)
+        return [t.clone() for t in tgt]
+
+    a = run(can.levels[0].nbr, x, res)
+    b = run(r, x[perm].contiguous(), res[perm].contiguous() if residual else None)
+    o2n = r.o2n.long()
+    return a, [t[o2n] for t in b]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("residual,views,wide", [(False, 1, False), (True, 1, False), (True, 2, False), (True, 3, True), (False, 2, True), (False, 3, False)])
+def test_blk_conv_equals_gather_kernel(dtype, residual, views, wide):
+    """Bit-identical to tl_conv_direct on a 14 m tile, every epilogue form of the inference engine."""
+    batch = _batch(14.0, [3])
+    can, blk = _geoms(batch)
+    a, b = _conv_pair(can, blk, dtype, residual, views, wide)
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert torch.equal(p, q), f"view {i}: {int((p != q).any(dim=1).sum())} rows differ, max |diff| {float((p.float() - q.float()).abs().max())}"
+    assert float(a[0].float().abs().max()) > 0.1
+
+
+def test_blk_conv_deep_split_units():
+    """Units of every size (halo bound 26 -> pieces down to a few rows): same results."""
+    import treelearn_amd.geometry as G
+    batch = _batch(10.0, [4])
+    old = G.BLK_HALO_MAX
+    G.BLK_HALO_MAX = 26
+    try:
+        can, blk = _geoms(batch, blk_min_rows=1)
+    finally:
+        G.BLK_HALO_MAX = old
+    a, b = _conv_pair(can, blk, torch.bfloat16, True, 2, False)
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+
+
+@pytest.fixture(scope="module")
+def tile2():
+    return make_batch([make_tile(**CONFIGS["config2"], seed=0)])
+
+
+def test_config2_blocked_geometry_and_conv_on_the_full_tile(tile2):
+    """THE config-2 tile (1.85 M voxels): blocked geometry against the oracle, the level-1 conv torch.equal to the gather kernel."""
+    can, blk = _geoms(tile2)
+    _check_blocked_geometry(can, blk, 126)
+    a, b = _conv_pair(can, blk, torch.bfloat16, True, 2, False)
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+
+
+def _model(dtype, use_feats=False, seed=7):
+    from treelearn_amd.model import TreeLearn
+    m = TreeLearn(use_feats=use_feats, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=dtype)
+    m.load_state_dict(random_state_dict(seed, channels=32, num_blocks=7), strict=True)
+    return m.cuda().eval()
+
+
+def _fwd(m, batch, blocked):
+    old = os.environ.get("TL_BLK")
+    os.environ["TL_BLK"] = "1" if blocked else "0"
+    try:
+        with torch.no_grad():
+            out = m(batch, return_loss=False)
+    finally:
+        if old is None:
+            os.environ.pop("TL_BLK")
+        else:
+            os.environ["TL_BLK"] = old
+    return {k: v.float().cpu() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("use_feats", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_forward_blocked_vs_canonical_order(dtype, use_feats):
+    """Same tile, level 1 in block-local vs canonical order.  Everything but the 64 -> 32 decoder conv (run as two input-channel halves) is
+    bit-identical, so the outputs agree to 16-bit rounding of one layer; rows come back in point order either way."""
+    from treelearn_amd import ops
+    batch = _batch(16.0, [5])
+    m = _model(dtype, use_feats)
+    ops.PROFILE = []
+    a = _fwd(m, batch, True)
+    fam = [type(meta["table"]).__name__ for _, _, meta in ops.PROFILE]
+    ops.PROFILE = None
+    assert fam.count("BlockedRulebook") >= 9                     # the level-1 convs ran on the staged-unit kernel
+    b = _fwd(m, batch, False)
+    for k in a:
+        ref = b[k].abs().max()
+        assert torch.isfinite(a[k]).all()
+        assert float((a[k] - b[k]).abs().max() / ref) < 2e-2, k
+        assert float((a[k] - b[k]).abs().mean() / b[k].abs().mean()) < 2e-3, k
+
+
+def test_forward_blocked_vs_oracle_bf16():
+    """The block-local bf16 forward against the fp32 CPU oracle forward (the bf16 tolerance of the canonical path: 5e-2)."""
+    from oracle import model as om
+    batch = _batch(12.0, [2], n_trees=5)
+    m = _model(torch.bfloat16)
+    a = _fwd(m, batch, True)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    o = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 1, voxel_size=0.1, num_blocks=7,
+                   spatial_shape=[500, 500, 1000])
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        ref = o[k].double().numpy()
+        err = np.abs(a[k].numpy() - ref).max() / np.abs(ref).max()
+        assert err < 5e-2, (k, err)

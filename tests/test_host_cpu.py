@@ -286,3 +286,31 @@ def test_conv_wrapper_rejects_a_rulebook_of_the_wrong_shape():
             ops._check_table(bad, 27, 10, x.device)          # what conv_wgrad calls before its launch
     with pytest.raises(ValueError, match="needs a rulebook"):
         ops.conv_fwd(x, w, None, 10)
+
+
+def test_blk_oracle_decodes_to_the_canonical_rulebook():
+    """oracle/blk.py (block-local order + staged rulebook form of include/treelearn_hip.h `tl_blk`): both builders agree, the staged
+    form decodes to the canonical table carried into the new order, every unit respects the halo bound, also under forced splitting."""
+    from oracle import blk as ob
+    from oracle import voxel as ov
+    from treelearn_amd.synth import make_tile
+    tile = make_tile(extent=7.0, voxel=0.1, n_trees=3, fill=0.1, seed=11)
+    pts = tile["points"].astype(np.float32)
+    _, vc, _, _ = ov.voxelize(pts, tile["feat"], np.zeros(len(pts), np.int64), 1, 0.1)
+    vc = np.asarray(vc, np.int32)
+    nbr = np.ascontiguousarray(ov.rulebook_subm(vc).T)
+    n = len(vc)
+    for hm in (126, 30):
+        a, b = ob.build(vc, nbr, hm), ob.build_fast(vc, nbr, hm)
+        assert len(a["units"]) == len(b["units"]) and np.array_equal(a["lrb"], b["lrb"])
+        for u, w in zip(a["units"], b["units"]):
+            assert u[:2] == w[:2] and np.array_equal(u[2], w[2])
+        assert np.array_equal(ob.decode(a["units"], a["lrb"], n), a["nn"])
+        exp = np.where(nbr[:, a["perm"]] >= 0, a["o2n"][np.clip(nbr[:, a["perm"]], 0, None)], -1)
+        assert np.array_equal(a["nn"], exp)
+        assert max(len(u[2]) for u in a["units"]) <= hm
+        cover = np.zeros(n, np.int64)
+        for lo, cnt, _ in a["units"]:
+            cover[lo:lo + cnt] += 1
+        assert (cover == 1).all()
+        assert np.array_equal(a["nn"][13], np.arange(n))                       # the centre tap is the row itself

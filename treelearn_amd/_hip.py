@@ -34,6 +34,8 @@ class ConvArgs(_c.Structure):
         # training-mode epilogue reductions (include/treelearn_hip.h: TL_EPI_STATS / TL_EPI_BN_BWD)
         ("in_all_ones", _i32), ("epi_mode", _i32), ("red_part", _vp), ("red_nparts", _c.POINTER(_i32)),
         ("bn_x", _vp), ("bn_x_ld", _i64), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_scale", _vp), ("bn_shift", _vp), ("bn_relu", _i32),
+        # block-local form of a 27-tap rulebook (tl_blk_build)
+        ("blk_unit", _vp), ("blk_counter", _vp), ("blk_halo", _vp), ("blk_lrb", _vp), ("blk_pmask", _vp),
     ]
 
 
@@ -43,7 +45,13 @@ class TileBox(_c.Structure):               # tl_tile_box
 
 class Level(_c.Structure):                 # tl_level
     _fields_ = [("dims", _c.c_int32 * 4), ("n", _c.c_int64), ("bitmap", _c.c_void_p), ("prefix", _c.c_void_p), ("coords", _c.c_void_p),
-                ("nbr", _c.c_void_p), ("compact", _c.c_void_p), ("child", _c.c_void_p), ("parent", _c.c_void_p), ("inv", _c.c_void_p)]
+                ("nbr", _c.c_void_p), ("compact", _c.c_void_p), ("child", _c.c_void_p), ("parent", _c.c_void_p), ("inv", _c.c_void_p),
+                ("o2n", _c.c_void_p)]
+
+
+class Blk(_c.Structure):                   # tl_blk
+    _fields_ = [("o2n", _vp), ("perm", _vp), ("coords_new", _vp), ("unit", _vp), ("counter", _vp), ("halo", _vp), ("lrb", _vp), ("pmask", _vp),
+                ("cap_units", _i64), ("halo_max", _i32), ("reserved", _i32)]
 
 
 class HdbGrid(_c.Structure):               # TlHdbGrid
@@ -72,6 +80,8 @@ PROTOTYPES = {
     "tl_pyramid_ws_words": (_i64, [_I4, _i32, _c.POINTER(_i64)]),
     "tl_pyramid_build": (_i32, [_vp, _i64, _I4, _I3, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tl_rulebooks_build": (_i32, [_c.POINTER(Level), _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "tl_blk_ws_words": (_i64, [_I4]),
+    "tl_blk_build": (_i32, [_vp, _vp, _I4, _i64, _c.POINTER(Blk), _vp, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_conv_red_parts": (_i64, [_i64]),
     "tl_bn_train_finish": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -339,6 +339,7 @@ extern int g_wgrad_dma, g_wgrad_dense_gx;         // tl_wgrad_dense.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
+static int g_blk = 1;                             // use the staged-unit kernel when the caller passes the block-local rulebook form
 #ifdef TL_DEV                                     // the window kernel lives in the developer build only (python -m treelearn_amd.build --dev)
 static int g_win = 0;                             // window kernel (opt-in, TL_CONV_WIN=1: measured at parity with the gather kernels): 1 = shapes with >= 64 channels, 2 = all, 0 = off
 extern int g_win_rows, g_win_ct;                  // tl_conv_win.hip
@@ -352,6 +353,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_depth")) { g_bf16_depth = (int)value; return TL_OK; }
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
+  if (!strcmp(key, "blk")) { g_blk = (int)value; return TL_OK; }
 #ifdef TL_DEV
   if (!strcmp(key, "win")) { g_win = (int)value; return TL_OK; }
   if (!strcmp(key, "win_rows")) { g_win_rows = (int)value; return TL_OK; }
@@ -377,7 +379,8 @@ int tl_set_tuning(const char* key, int64_t value) {
 
 int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (!a || !a->in || !a->weight || !a->out || a->n_out <= 0 || a->K <= 0 || a->K > 27 || a->Cin <= 0 || a->Cout <= 0) return TL_ERR_ARG;
-  if (!a->table && a->K != 1) return TL_ERR_ARG;
+  const bool has_blk = a->blk_unit && a->blk_counter && a->blk_halo && a->blk_lrb && a->K == 27;
+  if (!a->table && a->K != 1 && !has_blk && !(a->in_all_ones && a->blk_pmask)) return TL_ERR_ARG;
   if ((a->in_scale == nullptr) != (a->in_shift == nullptr)) return TL_ERR_ARG;
   if ((a->out_scale == nullptr) != (a->out_shift == nullptr)) return TL_ERR_ARG;
   if (a->dtype != TL_F32 && a->dtype != TL_BF16 && a->dtype != TL_F16) return TL_ERR_ARG;
@@ -391,6 +394,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const auto L_streamq = f16 ? tl_launch_conv_streamq_f16 : tl_launch_conv_streamq;
   const auto L_small = f16 ? tl_launch_conv_small_f16 : tl_launch_conv_small;
   const auto L_tinycin = f16 ? tl_launch_conv_tinycin_f16 : tl_launch_conv_tinycin;
+  const auto L_blk = f16 ? tl_launch_conv_blk_f16 : tl_launch_conv_blk;
   if (f16 && a->epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;       // the training epilogues take TL_F32 / TL_BF16
   ConvP p;
   p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
@@ -402,6 +406,8 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if ((a->out2_scale == nullptr) != (a->out2_shift == nullptr) || (a->out3_scale == nullptr) != (a->out3_shift == nullptr)) return TL_ERR_ARG;
   p.nblk = (int)tl_cdiv(a->n_out, TM);
   p.dbg = g_dbg; p.one_hot = a->table_one_hot && a->table != nullptr;
+  p.blk_unit = has_blk ? a->blk_unit : nullptr; p.blk_counter = a->blk_counter; p.blk_halo = a->blk_halo; p.blk_lrb = a->blk_lrb;
+  p.blk_pmask = a->K == 27 ? a->blk_pmask : nullptr;
   p.epi_mode = a->epi_mode; p.red_part = a->red_part; p.red_nparts = a->red_nparts; p.bn_x = a->bn_x; p.bn_x_ld = a->bn_x_ld;
   p.bn_mean = a->bn_mean; p.bn_rstd = a->bn_rstd; p.bn_scale = a->bn_scale; p.bn_shift = a->bn_shift; p.bn_relu = a->bn_relu;
   const bool train = a->epi_mode != TL_EPI_NONE;             // only the direct / stream families carry the training epilogues
@@ -423,6 +429,12 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     const int rc = L_ones27(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
+  if (has_blk && !train && dt == TL_BF16 && g_blk && vec_ok && out_vec && (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
+      (!a->out_scale || (((uintptr_t)a->out_scale) % 4 == 0 && ((uintptr_t)a->out_shift) % 4 == 0))) {
+    const int rc = L_blk(p, s);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
+  if (!a->table && a->K != 1) return TL_ERR_UNSUPPORTED;       // block-local rows without a shape the staged-unit kernel serves
   if (dt == TL_BF16 && a->Cin == 4 && a->Cout == 32 && g_direct && out_vec && ((uintptr_t)a->in) % 8 == 0 && ((uintptr_t)a->weight) % 16 == 0 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0))) {
     const int rc = L_direct(p, TL_BF16, s);

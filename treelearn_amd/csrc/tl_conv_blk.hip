@@ -1,0 +1,325 @@
+// Sparse conv, "block-local" form: the 27-tap 32 -> 32 SubM convs of a level whose rows are in the block-local order of tl_blk.hip
+// (reference layers: every SubMConv3d of level 1 -- tree_learn/model/blocks.py:55-70 inside `unet.blocks` / `unet.blocks_tail`; 16-bit).
+//
+// The gather kernels (tl_conv_direct.hip) issue 27 gather slots per output row and sit AT the 32 B/clk/CU roof of the vector-memory path
+// with 80 % of the slots fetching nothing.  Here a WAVE owns a unit of <= 64 consecutive rows end to end:
+//   stage  : the unit's own rows (contiguous) + its halo rows (tl_blk's list: each distinct outside neighbour ONCE) go global -> LDS by
+//            LDS-DMA, 64 B per row, 16-B pieces XOR-swizzled through the source address: ~1.8 staged rows per output row instead of 27 slots;
+//   taps   : the A fragments of all 27 taps are ds_read_b128s at the offsets the local rulebook stores (absent neighbour = the stage's
+//            all-zero row: no gather slot, no mask), two 32-row tiles per unit share each B fragment; all weights resident in LDS;
+//            32x32x16 MFMAs, fp32 accumulators, taps and k-pieces in the order of the direct kernel -> BIT-IDENTICAL results;
+//   output : accumulators -> the (dead) stage as an fp32 tile -> row vectors -> residual / up to three views (BatchNorm affine + ReLU),
+//            16-B stores.  The NEXT unit's staging is requested as soon as the results have left the stage and BEFORE the stores, so the
+//            counted wait at the top of the next unit leaves only the stores outstanding.
+// Two waves per SIMD (8 per CU: 55 KB of weights + 8 x 12 KB stages): while one waits for its stage the other computes.  No workgroup
+// barrier after the weights are in place.  Rulebook rows and halo indices are requested one and two units ahead with inline-assembly loads
+// (fixed position in the instruction stream: the waits are counted).  Units are dealt XCD-contiguously (block b runs on XCD b % 8): the
+// halo rows of neighbouring units are hits in that XCD's L2.
+#include "tl_conv_internal.h"
+#include <atomic>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+static __device__ __forceinline__ u32x4 lds_r128(unsigned a) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); return v; }
+#define TL_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+#define TL_KEEP(x) asm volatile("" : "+v"(x))
+// unit descriptors travel through the scalar cache: hipcc turns a plain uniform load of them into a vector load + s_waitcnt vmcnt(0) +
+// readfirstlane (the pointer is not provably read-only), which would drain the staging DMAs and stores at the top of every unit
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ i32x4 s_load4(const void* ptr) { i32x4 v; asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(ptr)); return v; }
+#define TL_SWAIT(d) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d) : : "memory")
+
+constexpr int WS_B = 27 * 32 * 64;            // all taps of the weights
+constexpr int AFF_B = 3 * 2 * 32 * 4;         // scale / shift of up to three views
+constexpr int STAGE_B = 192 * 64;             // positions 0..63 own rows, 64..189 halo rows, 191 the zero row
+constexpr int HCH = 8;                        // halo chunks of 16 rows (TL_BLK_HALO_MAX = 126 <= 128)
+
+template <int W, bool RES, int NV>
+__global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 31, fh = lane >> 5;
+  {
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);              // [27][32 cout][4 pieces of 8 cin]
+    for (int v = tid; v < 27 * 128; v += W * 64) {
+      const int s_ = v & 3, n = (v >> 2) & 31, k = v >> 7;
+      *reinterpret_cast<u32x4*>(smem + (k * 32 + n) * 64 + ((s_ ^ ((n >> 2) & 3)) * 16)) = wsrc[v];
+    }
+    float* aff = reinterpret_cast<float*>(smem + WS_B);                   // [view][scale | shift][32]
+    for (int e = tid; e < 3 * 64; e += W * 64) {
+      const int v = e >> 6, c = e & 31, sh = (e >> 5) & 1;
+      const float* src = v == 0 ? (sh ? p.out_shift : p.out_scale) : v == 1 ? (sh ? p.out2_shift : p.out2_scale) : (sh ? p.out3_shift : p.out3_scale);
+      aff[e] = src ? src[c] : (sh ? 0.f : 1.f);
+    }
+  }
+  char* stage = smem + WS_B + AFF_B + wv * STAGE_B;
+  for (int e = lane; e < STAGE_B / 16; e += 64) *reinterpret_cast<u32x4*>(stage + e * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem, st_a = lds0 + (unsigned)(WS_B + AFF_B + wv * STAGE_B);
+  const unsigned aff_a = lds0 + (unsigned)WS_B + (unsigned)((lane & 3) * 32);   // the lane's 8 channels of a row vector
+  unsigned boff[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) boff[s_] = lds0 + (unsigned)(fi * 64 + (((2 * s_ + fh) ^ ((fi >> 2) & 3)) * 16));
+  const unsigned in_ldb = (unsigned)(p.in_ld * 2);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)((p.n_in - 1) * (int64_t)in_ldb + 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.blk_lrb), 0, (int)(p.n_out * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.blk_halo), 0, (int)(p.n_out * 128), 0x00020000);
+  const unsigned o_ldb[3] = {(unsigned)(p.out_ld * 2), (unsigned)(p.out2_ld * 2), (unsigned)(p.out3_ld * 2)};
+  void* const o_ptr[3] = {p.out, p.out2, p.out3};
+  __amdgpu_buffer_rsrc_t ro[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) ro[v] = __builtin_amdgcn_make_buffer_rsrc(o_ptr[v], 0, (int)((p.n_out - 1) * (int64_t)o_ldb[v] + 64), 0x00020000);
+  const unsigned res_ldb = (unsigned)(p.res_ld * 2);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(RES ? p.res : p.in), 0, RES ? (int)((p.n_out - 1) * (int64_t)res_ldb + 64) : 0, 0x00020000);
+  const bool aff_on[3] = {p.out_scale != nullptr, p.out2_scale != nullptr, p.out3_scale != nullptr};
+  const bool relu_on[3] = {p.out_relu != 0, p.out2_relu != 0, p.out3_relu != 0};
+
+  // XCD-contiguous deal: XCD x (= blockIdx % 8) owns units [x * q8, (x + 1) * q8), its waves interleave inside that range
+  const int nunits = p.blk_counter[0];
+  const int q8 = (nunits + 7) >> 3;
+  const int xcd = (int)blockIdx.x & 7, wgx = (int)blockIdx.x >> 3;
+  const int ulo = xcd * q8, uhi = ulo + q8 < nunits ? ulo + q8 : nunits;
+  const int nw = ((int)gridDim.x >> 3) * W;
+  const int u0 = ulo + wgx * W + wv;
+  const i32x4* units = reinterpret_cast<const i32x4*>(p.blk_unit);
+  // (row0, n_own, n_halo, -) of unit u; the load is in flight until TL_SWAIT; a slot past the wave's range reads unit 0 and is voided
+  auto desc_req = [&](int u) __attribute__((always_inline)) { return s_load4(units + (u < uhi ? u : 0)); };
+  auto desc_fin = [&](i32x4 d, int u) __attribute__((always_inline)) { return u < uhi ? make_int4(d[0], d[1], d[2], 0) : make_int4(0, 0, 0, 0); };
+  const unsigned pc16[2] = {(unsigned)(fh * 16), (unsigned)(32 + fh * 16)};
+
+  // d = the unit's descriptor; an exhausted slot (n_own = 0) asks for nothing (out-of-range offsets)
+  auto load_hidx = [&](const int4& d, int (&h)[HCH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) {
+      const unsigned off = d.y > 0 ? ((unsigned)d.x * 32u + (unsigned)(c * 16 + (lane >> 2))) * 4u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
+    }
+  };
+  auto load_rb = [&](const int4& d, u32x4 (&rb)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned off = d.y > 0 ? (unsigned)(d.x + t * 32 + fi) * 64u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[t][0]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[t][1]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[t][2]) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[t][3]) : "v"(off), "s"(rl));
+    }
+  };
+  // staging: 4 own chunks + as many halo chunks as the unit has (the counted wait at the top does not depend on their number)
+  auto stage_unit = [&](const int4& d, const int (&h)[HCH]) __attribute__((always_inline)) {
+    if (d.y <= 0) return;
+    const int row0 = d.x, nown = d.y, nh = d.z;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int pos = c * 16 + (lane >> 2);
+      const unsigned off = pos < nown ? (unsigned)(row0 + pos) * in_ldb + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + c * 1024), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) {
+      if (c * 16 < nh) {
+        const int j = c * 16 + (lane >> 2), pos = 64 + j;
+        const unsigned off = j < nh ? (unsigned)h[c] * in_ldb + (unsigned)((((lane & 3) ^ ((pos >> 2) & 3))) * 16) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(stage + 4096 + c * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  int4 dc, d1, d2;
+  {
+    i32x4 r0 = desc_req(u0), r1 = desc_req(u0 + nw), r2 = desc_req(u0 + 2 * nw);
+    TL_SWAIT(r0); TL_SWAIT(r1); TL_SWAIT(r2);
+    dc = desc_fin(r0, u0); d1 = desc_fin(r1, u0 + nw); d2 = desc_fin(r2, u0 + 2 * nw);
+  }
+  int hn[HCH];
+  u32x4 rbc[2][4], rbn[2][4];
+  {
+    int h0[HCH];
+    load_hidx(dc, h0); load_hidx(d1, hn); load_rb(dc, rbc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) { TL_KEEP(h0[c]); TL_KEEP(hn[c]); }
+    stage_unit(dc, h0);
+  }
+  bool firstu = true;
+  for (int u = u0; u < uhi; u += nw) {
+    const int row0 = dc.x, nown = dc.y;
+    i32x4 d3r = desc_req(u + 3 * nw);                                               // waited for behind the taps, used from the next iteration on
+    // this unit's stage has landed (requested before the previous unit's stores), and so have its rulebook and the next unit's halo indices
+    if (firstu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NV) : "memory");
+    if (!firstu) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { TL_KEEP(rbn[t][q]); rbc[t][q] = rbn[t][q]; }
+#pragma unroll
+      for (int c = 0; c < HCH; ++c) TL_KEEP(hn[c]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) TL_KEEP(rbc[t][q]);
+    }
+    firstu = false;
+    int hcur[HCH];
+#pragma unroll
+    for (int c = 0; c < HCH; ++c) hcur[c] = hn[c];                                  // indices of unit t + 1 (for the staging after the taps)
+    load_hidx(d2, hn);                                                              // unit t + 2
+    load_rb(d1, rbn);                                                               // unit t + 1
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    {
+      u32x4 A[2][2][2], B[2][2];                                                    // 6 reads per tap: lgkmcnt counts to 15
+      auto issue = [&](int k, int s_) __attribute__((always_inline)) {
+        B[s_][0] = lds_r128(boff[0] + (unsigned)(k * 2048));
+        B[s_][1] = lds_r128(boff[1] + (unsigned)(k * 2048));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint32_t wd = rbc[t][k >> 3][(k >> 1) & 3];
+          const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+          const unsigned a0 = st_a + val;
+          A[s_][t][0] = lds_r128(a0 ^ pc16[0]);
+          A[s_][t][1] = lds_r128(a0 ^ pc16[1]);
+        }
+      };
+      issue(0, 0);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int s_ = k & 1;
+        if (k + 1 < 27) { issue(k + 1, s_ ^ 1); TL_LGKM(6); } else TL_LGKM(0);
+        TL_KEEP(B[s_][0]); TL_KEEP(B[s_][1]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          TL_KEEP(A[s_][t][0]); TL_KEEP(A[s_][t][1]);
+          acc[t] = h16_mfma(A[s_][t][0], B[s_][0], acc[t]);
+          acc[t] = h16_mfma(A[s_][t][1], B[s_][1], acc[t]);
+        }
+      }
+    }
+    TL_SWAIT(d3r);
+    // residual row vectors (lane: row (lane >> 2) + 16 it, channels 8 (lane & 3) ..): requested now, used after the LDS transposition
+    [[maybe_unused]] u32x4 rres[4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rr_ = (lane >> 2) + 16 * it;
+        const unsigned off = rr_ < nown ? (unsigned)(row0 + rr_) * res_ldb + (unsigned)((lane & 3) * 16) : 0xFFFFFFFFu;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rres[it]) : "v"(off), "s"(rr));
+      }
+    }
+    float* ew = reinterpret_cast<float*>(stage);                                    // 64 rows x 36 floats over the dead stage
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ew[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fi] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float y[4][8];
+    {
+      u32x4 e0[4], e1[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rr_ = (lane >> 2) + 16 * it;
+        const unsigned ea = st_a + (unsigned)((rr_ * 36 + (lane & 3) * 8) * 4);
+        e0[it] = lds_r128(ea); e1[it] = lds_r128(ea + 16);
+      }
+      TL_LGKM(0);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        TL_KEEP(e0[it]); TL_KEEP(e1[it]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { y[it][q] = __uint_as_float(e0[it][q]); y[it][q + 4] = __uint_as_float(e1[it][q]); }
+      }
+    }
+    if constexpr (RES) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        TL_KEEP(rres[it]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { y[it][2 * q] += bf16_lo(rres[it][q]); y[it][2 * q + 1] += bf16_hi(rres[it][q]); }
+      }
+    }
+    // the stage is free (the results are in registers): the next unit's staging goes out BEFORE this unit's stores
+    stage_unit(d1, hcur);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float sc[8], sh[8];
+      if (aff_on[v]) {
+        const u32x4 s0 = lds_r128(aff_a + (unsigned)(v * 256)), s1 = lds_r128(aff_a + (unsigned)(v * 256 + 16));
+        const u32x4 h0 = lds_r128(aff_a + (unsigned)(v * 256 + 128)), h1 = lds_r128(aff_a + (unsigned)(v * 256 + 144));
+        TL_LGKM(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sc[q] = __uint_as_float(s0[q]); sc[q + 4] = __uint_as_float(s1[q]);
+          sh[q] = __uint_as_float(h0[q]); sh[q + 4] = __uint_as_float(h1[q]);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float z[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q] = y[it][q];
+        if (aff_on[v]) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) z[q] = fmaf(z[q], sc[q], sh[q]);
+        }
+        if (relu_on[v]) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) z[q] = fmaxf(z[q], 0.f);
+        }
+        const u32x4 o = {pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7])};
+        const int rr_ = (lane >> 2) + 16 * it;
+        const unsigned off = rr_ < nown ? (unsigned)(row0 + rr_) * o_ldb[v] + (unsigned)((lane & 3) * 16) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ro[v], (int)off, 0, 0);
+      }
+    }
+    dc = d1; d1 = d2; d2 = desc_fin(d3r, u + 3 * nw);
+  }
+}
+
+template <int W, bool RES, int NV>
+int launch_blk(const ConvP& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)WS_B + AFF_B + (size_t)W * STAGE_B;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return TL_ERR_LAUNCH;
+    attr_set = true;
+  }
+  k_conv_blk<W, RES, NV><<<256, W * 64, lds, s>>>(p);
+  return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// 27 taps, 32 -> 32 channels, 16-bit, rows in the block-local order with the staged rulebook of tl_blk_build; no gather-side prologue, no
+// training epilogue.  Every view 16-B aligned with a row stride that is a multiple of 8 elements; buffers below 4 GB.
+int tl_launch_conv_blk(const ConvP& p, hipStream_t s) {
+  if (!p.blk_unit || !p.blk_counter || !p.blk_halo || !p.blk_lrb) return TL_ERR_UNSUPPORTED;
+  if (p.K != 27 || p.Cin != 32 || p.Cout != 32 || p.in_scale || p.in_relu || p.epi_mode != TL_EPI_NONE || p.n_in != p.n_out) return TL_ERR_UNSUPPORTED;
+  if (p.n_out >= (1 << 25)) return TL_ERR_UNSUPPORTED;
+  auto big = [&](int64_t ld) { return (p.n_out - 1) * ld * 2 + 64 >= 0x7FFFFFFFll * 2; };
+  if (big(p.in_ld) || big(p.out_ld) || (p.out2 && big(p.out2_ld)) || (p.out3 && big(p.out3_ld)) || (p.res && big(p.res_ld))) return TL_ERR_UNSUPPORTED;
+  if (p.out3 && !p.out2) return TL_ERR_UNSUPPORTED;
+  const int nv = p.out3 ? 3 : p.out2 ? 2 : 1;
+  if (p.res) {
+    switch (nv) {
+      case 1: return launch_blk<8, true, 1>(p, s);
+      case 2: return launch_blk<8, true, 2>(p, s);
+      default: return launch_blk<8, true, 3>(p, s);
+    }
+  }
+  switch (nv) {
+    case 1: return launch_blk<8, false, 1>(p, s);
+    case 2: return launch_blk<8, false, 2>(p, s);
+    default: return launch_blk<8, false, 3>(p, s);
+  }
+}

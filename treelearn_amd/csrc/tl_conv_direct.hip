@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) k_conv_ones27(ConvP p) {
     S[e >> 5][e & 31] = t;
   }
   __syncthreads();
-  const int32_t* mask = p.ctab + (int64_t)9 * p.n_out;
+  const int32_t* mask = p.blk_pmask ? p.blk_pmask : p.ctab + (int64_t)9 * p.n_out;   // block-local rows: tl_blk_build's presence masks
   const int64_t total = p.n_out * 4;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int64_t row = t >> 2; const int c0 = (int)(t & 3) * 8;
@@ -490,7 +490,7 @@ int dispatch(const ConvP& p, hipStream_t s) {
 
 // all-ones input (tl_conv_args.in_all_ones): bf16, K = 27 with the column-form rulebook, Cout = 32
 int tl_launch_conv_ones27(const ConvP& p, hipStream_t s) {
-  if (p.K != 27 || p.Cout != 32 || !p.ctab || p.Cin <= 0 || p.Cin > 64 || p.in_scale || p.in_relu || p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
+  if (p.K != 27 || p.Cout != 32 || (!p.ctab && !p.blk_pmask) || p.Cin <= 0 || p.Cin > 64 || p.in_scale || p.in_relu || p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
   k_conv_ones27<<<tl_grid(p.n_out * 4, 256), 256, 0, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }

@@ -13,6 +13,7 @@
 #define tl_launch_conv_small tl_launch_conv_small_f16
 #define tl_launch_conv_tinycin tl_launch_conv_tinycin_f16
 #define tl_launch_conv_bf16 tl_launch_conv_bf16_f16
+#define tl_launch_conv_blk tl_launch_conv_blk_f16
 #define g_small_mode g_small_mode_f16
 #endif
 
@@ -46,6 +47,8 @@ struct ConvP {
   const void* bn_x; int64_t bn_x_ld;
   const float* bn_mean; const float* bn_rstd; const float* bn_scale; const float* bn_shift; int bn_relu;
   int one_hot; // every output row has at most one valid table entry (inverse conv)
+  // block-local form of a 27-tap rulebook (tl_blk_build; tl_conv_args.blk_*), nullptr if absent
+  const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint16_t* blk_lrb; const int32_t* blk_pmask;
   int dbg;     // developer ablation bits (tl_set_tuning "dbg"): 1 no A loads, 2 no B loads, 4 no MFMA, 8 no stores
 };
 
@@ -302,6 +305,9 @@ int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   
 int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s);   // whole weight tensor resident in LDS, per-wave tiles
 int tl_launch_conv_ones27(const ConvP& p, hipStream_t s);               // every input element is 1: presence-mask table, no gather
 
+// tl_conv_blk.hip
+int tl_launch_conv_blk(const ConvP& p, hipStream_t s);                  // 16-bit, 27 taps, 32 -> 32: rows in block-local order, staged units
+
 // tl_conv_stream.hip
 int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s);   // per-wave register gathers, weights streamed through LDS per tap
 
@@ -326,6 +332,7 @@ int tl_launch_conv_streamq_f16(const ConvP& p, hipStream_t s);
 int tl_launch_conv_small_f16(const ConvP& p, int dtype, hipStream_t s);
 int tl_launch_conv_tinycin_f16(const ConvP& p, int dtype, hipStream_t s);
 int tl_launch_conv_bf16_f16(const ConvP& p, int depth, int units, hipStream_t s);
+int tl_launch_conv_blk_f16(const ConvP& p, hipStream_t s);
 #endif
 
 // tl_linear_small.hip

@@ -328,12 +328,15 @@ __global__ void __launch_bounds__(kBlock) k_expand_coords(const uint64_t* __rest
   expand_coords_body(bm, pf, d, coords, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
+// o2n (optional): the level's block-local order (tl_blk.hip) -- the map then holds NEW rows
 __global__ void __launch_bounds__(kBlock) k_point_rank(const int32_t* __restrict__ pc, int64_t N, const uint64_t* __restrict__ bm,
-                                                       const uint32_t* __restrict__ pf, TlDims d, int64_t* __restrict__ v2p) {
+                                                       const uint32_t* __restrict__ pf, TlDims d, int64_t* __restrict__ v2p,
+                                                       const int32_t* __restrict__ o2n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const int4 c = reinterpret_cast<const int4*>(pc)[i];
     int r = -1;
     if (c.x >= 0 && c.x < d.B && c.y < d.X && c.z < d.Y && c.w < d.Z) r = tl_rank_at(bm, pf, tl_col_word(d, c.x, c.y, c.z), c.w);
+    if (o2n && r >= 0) r = o2n[r];
     v2p[i] = r;
   }
 }
@@ -386,9 +389,11 @@ __global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restr
   rulebook_subm_body(coords, M, bm, pf, d, nbr, compact, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
+// fo2n (optional): block-local order of the FINE level (tl_blk.hip): its rows appear in that order in all three tables
 __device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
                                                    const uint32_t* __restrict__ fpf, const TlDims& f, int64_t Mf, int32_t* __restrict__ child,
-                                                   int32_t* __restrict__ parent, int32_t* __restrict__ inv, int64_t first, int64_t stride) {
+                                                   int32_t* __restrict__ parent, int32_t* __restrict__ inv, int64_t first, int64_t stride,
+                                                   const int32_t* __restrict__ fo2n = nullptr) {
   for (int64_t q = first; q < Mc; q += stride) {
     const int4 c = reinterpret_cast<const int4*>(cc)[q];
 #pragma unroll
@@ -396,6 +401,7 @@ __device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ c
       const int x = 2 * c.y + (k >> 2), y = 2 * c.z + ((k >> 1) & 1), z = 2 * c.w + (k & 1);
       int r = -1;
       if (x < f.X && y < f.Y && z < f.Z) r = tl_rank_at(fbm, fpf, tl_col_word(f, c.x, x, y), z);
+      if (fo2n && r >= 0) r = fo2n[r];
       child[(int64_t)k * Mc + q] = r;
       if (r >= 0) { parent[r] = (int)q; inv[(int64_t)k * Mf + r] = (int)q; }
     }
@@ -404,8 +410,9 @@ __device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ c
 
 __global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
                                                           const uint32_t* __restrict__ fpf, TlDims f, int64_t Mf,
-                                                          int32_t* __restrict__ child, int32_t* __restrict__ parent, int32_t* __restrict__ inv) {
-  rulebook_down_body(cc, Mc, fbm, fpf, f, Mf, child, parent, inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+                                                          int32_t* __restrict__ child, int32_t* __restrict__ parent, int32_t* __restrict__ inv,
+                                                          const int32_t* __restrict__ fo2n) {
+  rulebook_down_body(cc, Mc, fbm, fpf, f, Mf, child, parent, inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, fo2n);
 }
 
 // One launch over several small levels: workgroup b works on level l with first[l] <= b < first[l+1].
@@ -551,7 +558,7 @@ int tl_expand_coords(const uint64_t* bitmap, const uint32_t* prefix, const int32
 int tl_point_rank(const int32_t* pcoords, int64_t N, const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4],
                   int64_t* v2p, tl_stream_t stream) {
   if (!pcoords || !bitmap || !prefix || !dims || !v2p || N <= 0) return TL_ERR_ARG;
-  k_point_rank<<<tl_grid(N, kBlock), kBlock, 0, tl_s(stream)>>>(pcoords, N, bitmap, prefix, tl_dims(dims), v2p);
+  k_point_rank<<<tl_grid(N, kBlock), kBlock, 0, tl_s(stream)>>>(pcoords, N, bitmap, prefix, tl_dims(dims), v2p, nullptr);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
@@ -581,7 +588,7 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
   hipStream_t s = tl_s(stream);
   if (hipMemsetAsync(parent, 0xFF, Mf * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   if (hipMemsetAsync(inv, 0xFF, Mf * 8 * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
-  k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv);
+  k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv, nullptr);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
@@ -652,7 +659,10 @@ int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, i
                        const int32_t* pcoords, int64_t N, int64_t* v2p, tl_stream_t stream) {
   if (!lv || num_levels < 1 || num_levels > kPyrMaxLevels) return TL_ERR_ARG;
   for (int l = 0; l < num_levels; ++l) {
-    if (!lv[l].bitmap || !lv[l].prefix || !lv[l].coords || !lv[l].nbr || lv[l].n <= 0) return TL_ERR_ARG;
+    if (!lv[l].bitmap || !lv[l].prefix || lv[l].n <= 0) return TL_ERR_ARG;
+    if ((!lv[l].coords || !lv[l].nbr) && !lv[l].o2n) return TL_ERR_ARG;      // only a level in block-local order may go without them
+    if (lv[l].nbr && !lv[l].coords) return TL_ERR_ARG;
+    if (l > 0 && !lv[l].coords) return TL_ERR_ARG;                            // the down tables walk the coarse level's coordinates
     if (l + 1 < num_levels && (!lv[l].child || !lv[l].parent || !lv[l].inv)) return TL_ERR_ARG;
   }
   hipStream_t s = tl_s(stream);
@@ -665,13 +675,13 @@ int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, i
   }
   int small = num_levels;                               // levels small .. L-1 share launches
   for (int l = num_levels - 1; l >= 1; --l) {
-    if (tl_nwords(tl_dims(lv[l].dims)) <= kPyrSmallWords && lv[l].n <= 64 * kPyrSmallWords && !lv[l].compact) small = l; else break;
+    if (tl_nwords(tl_dims(lv[l].dims)) <= kPyrSmallWords && lv[l].n <= 64 * kPyrSmallWords && !lv[l].compact && !lv[l].o2n && !lv[l - 1].o2n) small = l; else break;
   }
   if (num_levels - small < 2) small = num_levels;
   for (int l = 0; l < small; ++l) {
     const TlDims d = tl_dims(lv[l].dims);
-    k_expand_coords<<<tl_grid(tl_nwords(d), kBlock), kBlock, 0, s>>>(lv[l].bitmap, lv[l].prefix, d, lv[l].coords);
-    k_rulebook_subm<<<tl_grid(lv[l].n, kBlock), kBlock, 0, s>>>(lv[l].coords, lv[l].n, lv[l].bitmap, lv[l].prefix, d, lv[l].nbr, lv[l].compact);
+    if (lv[l].coords) k_expand_coords<<<tl_grid(tl_nwords(d), kBlock), kBlock, 0, s>>>(lv[l].bitmap, lv[l].prefix, d, lv[l].coords);
+    if (lv[l].nbr) k_rulebook_subm<<<tl_grid(lv[l].n, kBlock), kBlock, 0, s>>>(lv[l].coords, lv[l].n, lv[l].bitmap, lv[l].prefix, d, lv[l].nbr, lv[l].compact);
   }
   LevelPack p;
   p.nl = num_levels - small;
@@ -689,7 +699,7 @@ int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, i
   }
   for (int l = 0; l + 1 < num_levels && l < small; ++l) {   // fine level l big (or the last big one): its own launch
     const tl_level &f = lv[l], &c = lv[l + 1];
-    k_rulebook_down<<<tl_grid(c.n, kBlock), kBlock, 0, s>>>(c.coords, c.n, f.bitmap, f.prefix, tl_dims(f.dims), f.n, f.child, f.parent, f.inv);
+    k_rulebook_down<<<tl_grid(c.n, kBlock), kBlock, 0, s>>>(c.coords, c.n, f.bitmap, f.prefix, tl_dims(f.dims), f.n, f.child, f.parent, f.inv, f.o2n);
   }
   if (p.nl > 1) {                                           // fine levels small .. L-2: workgroups over the coarse rows
     p.nl -= 1;                                              // slots 0 .. nl-2 are fine levels; slot j+1 is read as the coarse one
@@ -698,7 +708,7 @@ int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, i
   }
   if (v2p) {
     if (!pcoords || N <= 0) return TL_ERR_ARG;
-    k_point_rank<<<tl_grid(N, kBlock), kBlock, 0, s>>>(pcoords, N, lv[0].bitmap, lv[0].prefix, tl_dims(lv[0].dims), v2p);
+    k_point_rank<<<tl_grid(N, kBlock), kBlock, 0, s>>>(pcoords, N, lv[0].bitmap, lv[0].prefix, tl_dims(lv[0].dims), v2p, lv[0].o2n);
   }
   TL_CHECK_LAUNCH();
   return TL_OK;

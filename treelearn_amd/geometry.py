@@ -6,6 +6,7 @@ batch of tiles, the PointToVoxel call and `.tolist()` syncs of `voxelize`
 generation (`subm1..7`, `spconv1..6`; blocks.py:57-70,104-123).  Two host syncs per batch in total:
 the grid extent (3 ints) and the per-level voxel counts (L ints).
 """
+import ctypes
 import os
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -13,6 +14,53 @@ from typing import List, Optional
 import torch
 
 from . import _hip
+
+
+BLK_MIN_ROWS = 16384        # below this the level-1 convs run on the small-level kernel anyway (tl_conv_fwd's small_rows)
+BLK_MAX_ROWS = (1 << 25) - 64
+BLK_HALO_MAX = 126
+
+
+class BlockedRulebook:
+    """The block-local form of a level's 27-tap SubM rulebook (include/treelearn_hip.h `tl_blk`, csrc/tl_blk.hip): the level's rows are
+    re-ordered by 8x8x8 block (`o2n` / `perm`: canonical row <-> new row), cut into units of <= 64 rows with their halo lists and local
+    rulebooks.  Stands where the canonical table `nbr` stands (Level.nbr) when a geometry is built with `blocked=True`: every tensor
+    that holds or is indexed by rows of the level -- features, `child` entries, `inv` / `parent`, `v2p` -- is then in the NEW order."""
+    K = 27
+
+    def __init__(self, n, o2n, perm, coords_new, unit, counter, halo, lrb, pmask):
+        self.n, self.o2n, self.perm, self.coords_new = n, o2n, perm, coords_new
+        self.unit, self.counter, self.halo, self.lrb, self.pmask = unit, counter, halo, lrb, pmask
+        self.shape = (27, n)
+
+    def count_pairs(self):
+        """(output row, tap) pairs present -- what `(table >= 0).sum()` is for the canonical table."""
+        m = self.pmask.to(torch.int64) & 0x7FFFFFF
+        c = torch.zeros_like(m)
+        for k in range(27):
+            c += (m >> k) & 1
+        return int(c.sum())
+
+    def to_table(self):
+        """The canonical-form table i32[27, n] in the NEW row order, decoded from units / halo lists / local rulebooks (tests, tools)."""
+        n = self.n
+        nu = int(self.counter[0])
+        unit = self.unit[:nu].long()
+        row0, nown = unit[:, 0], unit[:, 1]
+        uid = torch.repeat_interleave(torch.arange(nu, device=unit.device), nown)          # unit of every row, in unit order
+        first = torch.cumsum(nown, 0) - nown
+        rows = row0[uid] + (torch.arange(uid.numel(), device=unit.device) - first[uid])
+        pos = (self.lrb.view(torch.int16).long() & 0xFFFF)[rows][:, :27] >> 6                # staged position of every (row, tap)
+        r0 = row0[uid][:, None]
+        halo = self.halo.long()
+        hidx = (r0 * 32 + (pos - 64)).clamp(0, halo.numel() - 1)
+        val = torch.where(pos < 64, r0 + pos, torch.where(pos == 191, torch.full_like(pos, -1), halo[hidx]))
+        out = torch.full((n, 27), -2, dtype=torch.int64, device=unit.device)
+        out[rows] = val
+        return out.t().contiguous().int()
+
+    def tensors(self):
+        return [self.o2n, self.perm, self.coords_new, self.unit, self.counter, self.halo, self.lrb, self.pmask]
 
 
 @dataclass
@@ -23,7 +71,8 @@ class Level:
     bitmap: torch.Tensor        # u64 words (int64 storage)
     prefix: torch.Tensor        # u32 (int32 storage)
     coords: torch.Tensor = None     # i32[n,4] (b,x,y,z), ascending key
-    nbr: torch.Tensor = None        # i32[27,n]   subm{l}
+    nbr: torch.Tensor = None        # i32[27,n]   subm{l}; a BlockedRulebook when the level is in block-local order
+    nbr_ref: torch.Tensor = None    # blocked level only, on request: the canonical table (rows in canonical order)
     child: torch.Tensor = None      # i32[8,n_next]  spconv{l} (down)
     parent: torch.Tensor = None     # i32[n]
     inv: torch.Tensor = None        # i32[8,n]    spconv{l} (inverse)
@@ -37,6 +86,7 @@ class TileGeometry:
     batch_size: int
     pcoords: torch.Tensor = None
     _backing: list = field(default_factory=list)         # pooled buffers the per-level views alias
+    blocked: bool = False        # level 1 lives in the block-local order (levels[0].nbr is a BlockedRulebook; v2p holds new rows)
 
     def tensors(self):
         """Every device tensor of this geometry (for Tensor.record_stream when built on a side stream)."""
@@ -44,7 +94,7 @@ class TileGeometry:
         if self.pcoords is not None:
             out.append(self.pcoords)
         for lv in self.levels:
-            out += [t for t in (lv.coords, lv.nbr, lv.child, lv.parent, lv.inv) if t is not None]
+            out += [t for t in (lv.coords, lv.nbr, lv.nbr_ref, lv.child, lv.parent, lv.inv) if isinstance(t, torch.Tensor)]
         return out
 
 
@@ -120,7 +170,11 @@ def _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_lev
 
 
 def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: int, voxel_size: float,
-                   num_levels: int, spatial_shape: Optional[List[int]] = None, need_inverse: bool = True) -> TileGeometry:
+                   num_levels: int, spatial_shape: Optional[List[int]] = None, need_inverse: bool = True,
+                   blocked: bool = False, ref_table: bool = False, blk_min_rows: int = None) -> TileGeometry:
+    """`blocked`: put level 1 into the block-local row order (BlockedRulebook) when it has BLK_MIN_ROWS..BLK_MAX_ROWS voxels -- the form
+    the inference engine's level-1 convs run on; the canonical level-1 table is then only built on request (`ref_table`).  Default:
+    every level in the canonical order of SURVEY.md Appendix F (what the bit-exact rulebook tests pin and the training path uses)."""
     L = _hip.lib()
     st = _hip.stream()
     _hip.require_cuda(coords, "coords"); _hip.require_cuda(batch_ids, "batch_ids")
@@ -146,7 +200,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         raise ValueError(f"tile extent {extent} voxels exceeds spatial_shape {shape1}")
     shapes = level_shapes(shape1, num_levels)
 
-    if os.environ.get("TL_GEOM") == "per_level":
+    if os.environ.get("TL_GEOM") == "per_level" and not blocked:
         return _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_levels)
 
     # 2. occupancy bitmaps + popcount prefix sums for every level: one call, one backing allocation
@@ -178,6 +232,8 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     #    tensor views are made after the launches are queued
     # level 1 (and, with the opt-in window conv kernel, every big level) also gets the column form of its rulebook (40 instead of
     # 108 B/voxel); it rides on the table tensor as an attribute
+    n1 = levels[0].n
+    blocked = bool(blocked) and (BLK_MIN_ROWS if blk_min_rows is None else blk_min_rows) <= n1 <= BLK_MAX_ROWS
     want_ct = lambda lv: lv.n >= 65536 and (lv is levels[0] or _hip.WIN_KERNEL)     # noqa: E731
     al = lambda w: (w + 63) & ~63                           # noqa: E731
     cur = 0
@@ -187,8 +243,16 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     o_v2p = take(2 * N)
     lay = []
     for li, lv in enumerate(levels):
-        lay.append(dict(coords=take(4 * lv.n), nbr=take(27 * lv.n), ct=take(10 * lv.n) if want_ct(lv) else None,
+        skip = blocked and li == 0 and not ref_table        # a blocked level needs neither canonical coordinates nor the canonical table
+        lay.append(dict(coords=None if skip else take(4 * lv.n), nbr=None if skip else take(27 * lv.n),
+                        ct=take(10 * lv.n) if (want_ct(lv) and not skip) else None,
                         child=take(8 * levels[li + 1].n) if li + 1 < num_levels else None))
+    if blocked:
+        # the halo lists are indexed by the unit's first row (32 slots per row: a one-row unit can have 26 outside neighbours), the
+        # unit array can hold one unit per row: worst cases that never occur, reserved but not touched
+        nblk_ws = int(L.tl_blk_ws_words(_hip.dims4(dims[0])))
+        bl = dict(o2n=take(n1), perm=take(n1), cnew=take(4 * n1), unit=take(4 * n1), counter=take(64), halo=take(32 * n1), lrb=take(16 * n1),
+                  pmask=take(n1), ws=take(nblk_ws))
     o_m1 = cur                                              # parent / inv of all levels: contiguous, one fill with -1
     for li, lv in enumerate(levels[:-1]):
         lay[li]["parent"] = take(lv.n); lay[li]["inv"] = take(8 * lv.n)
@@ -199,17 +263,29 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         a, y = arr[li], lay[li]
         a.dims[:] = lv.dims; a.n = lv.n
         a.bitmap = p0 + 8 * (sum(nw[:li])); a.prefix = p0 + 8 * tw + 4 * (sum(nw[:li]))
-        a.coords = b0 + 4 * y["coords"]; a.nbr = b0 + 4 * y["nbr"]
+        a.coords = b0 + 4 * y["coords"] if y["coords"] is not None else None
+        a.nbr = b0 + 4 * y["nbr"] if y["nbr"] is not None else None
         a.compact = b0 + 4 * y["ct"] if y["ct"] is not None else None
+        a.o2n = None
         if li + 1 < num_levels:
             a.child = b0 + 4 * y["child"]; a.parent = b0 + 4 * y["parent"]; a.inv = b0 + 4 * y["inv"]
-    _hip.check(L.tl_rulebooks_build(arr, num_levels, b0 + 4 * o_m1, cur - o_m1, _hip.ptr(pcoords), N, b0 + 4 * o_v2p, st),
+    o_m1_end = cur
+    if blocked:
+        bk = _hip.Blk()
+        bk.o2n = b0 + 4 * bl["o2n"]; bk.perm = b0 + 4 * bl["perm"]; bk.coords_new = b0 + 4 * bl["cnew"]; bk.unit = b0 + 4 * bl["unit"]
+        bk.counter = b0 + 4 * bl["counter"]; bk.halo = b0 + 4 * bl["halo"]; bk.lrb = b0 + 4 * bl["lrb"]; bk.pmask = b0 + 4 * bl["pmask"]
+        bk.cap_units = n1; bk.halo_max = BLK_HALO_MAX; bk.reserved = 0
+        _hip.check(L.tl_blk_build(arr[0].bitmap, arr[0].prefix, _hip.dims4(levels[0].dims), n1, ctypes.byref(bk), b0 + 4 * bl["ws"], st), "tl_blk_build")
+        arr[0].o2n = bk.o2n
+    _hip.check(L.tl_rulebooks_build(arr, num_levels, b0 + 4 * o_m1, o_m1_end - o_m1, _hip.ptr(pcoords), N, b0 + 4 * o_v2p, st),
                "tl_rulebooks_build")
     v2p = back[o_v2p:o_v2p + 2 * N].view(torch.int64)
     for li, lv in enumerate(levels):
         y = lay[li]
-        lv.coords = back[y["coords"]:y["coords"] + 4 * lv.n].view(lv.n, 4)
-        lv.nbr = back[y["nbr"]:y["nbr"] + 27 * lv.n].view(27, lv.n)
+        if y["coords"] is not None:
+            lv.coords = back[y["coords"]:y["coords"] + 4 * lv.n].view(lv.n, 4)
+        if y["nbr"] is not None:
+            lv.nbr = back[y["nbr"]:y["nbr"] + 27 * lv.n].view(27, lv.n)
         if y["ct"] is not None:
             lv.nbr._tl_compact = back[y["ct"]:y["ct"] + 10 * lv.n].view(10, lv.n)
         if li + 1 < num_levels:
@@ -217,7 +293,13 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
             lv.child = back[y["child"]:y["child"] + 8 * nc].view(8, nc)
             lv.parent = back[y["parent"]:y["parent"] + lv.n]
             lv.inv = back[y["inv"]:y["inv"] + 8 * lv.n].view(8, lv.n)
-    return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[pyr, back])
+    if blocked:
+        v = lambda k, words: back[bl[k]:bl[k] + words]       # noqa: E731
+        lv = levels[0]
+        lv.nbr_ref = lv.nbr
+        lv.nbr = BlockedRulebook(n1, v("o2n", n1), v("perm", n1), v("cnew", 4 * n1).view(n1, 4), v("unit", 4 * n1).view(n1, 4), v("counter", 64),
+                                 v("halo", 32 * n1), v("lrb", 16 * n1).view(n1, 16), v("pmask", n1))
+    return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[pyr, back], blocked=blocked)
 
 
 def voxel_mean_feats(point_feats: torch.Tensor, geom: TileGeometry, max_points: int) -> torch.Tensor:

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..geometry import TileGeometry
+from ..geometry import BlockedRulebook, TileGeometry
 
 
 def _bn_affine(bn: nn.BatchNorm1d):
@@ -62,9 +62,20 @@ class _Res:
         self.w2 = ops.pack_weight(cb[5].weight, dtype)
         ib = block.i_branch[0]
         self.w1x1 = None if isinstance(ib, nn.Identity) else ops.pack_weight(ib.weight, dtype)
+        # 2C -> C conv of a decoder block on block-local rows (level 1, C = 32): the staged-unit kernel contracts 32 input channels, so the
+        # conv runs as its two input-channel halves -- the second launch takes the first one's result as its residual
+        w = cb[2].weight
+        self.w1_halves = None
+        if w.shape[-1] == 64 and w.shape[0] == 32 and dtype != torch.float32:
+            self.w1_halves = (ops.pack_weight(w[..., :32], dtype), ops.pack_weight(w[..., 32:], dtype))
 
     def run(self, x_raw, x_act, nbr, n, views):
-        t = ops.conv_fwd(x_act, self.w1, nbr, n, out_scale=self.bn3[0], out_shift=self.bn3[1], out_relu=True)
+        if isinstance(nbr, BlockedRulebook) and x_act.shape[1] == 64 and self.w1_halves is not None:
+            part = ops.conv_fwd(x_act[:, :32], self.w1_halves[0], nbr, n, split=(0, 64))
+            t = ops.conv_fwd(x_act[:, 32:], self.w1_halves[1], nbr, n, residual=part, out_scale=self.bn3[0], out_shift=self.bn3[1], out_relu=True,
+                             split=(1, 64))
+        else:
+            t = ops.conv_fwd(x_act, self.w1, nbr, n, out_scale=self.bn3[0], out_shift=self.bn3[1], out_relu=True)
         res = x_raw if self.w1x1 is None else ops.conv_fwd(x_raw, self.w1x1, None, n)
         return _conv_views(t, self.w2, nbr, n, views, residual=res)
 
@@ -174,13 +185,27 @@ class InferencePlan:
         self.w2 = torch.cat([model.semantic_linear[3].weight.detach().float(), model.offset_linear[3].weight.detach().float()]).contiguous()
         self.b2 = torch.cat([model.semantic_linear[3].bias.detach().float(), model.offset_linear[3].bias.detach().float()]).contiguous()
 
+    def supports_blocked(self):
+        """Level 1 may live in the block-local row order (geometry.BlockedRulebook): the pre-activated 16-bit engine of a 32-channel net."""
+        return self.preact and self.dtype != torch.float32 and self.unet.C == 32 and os.environ.get("TL_BLK", "1") != "0"
+
     def run(self, voxel_feats, geom: TileGeometry, want_backbone=True, all_ones=False):
         """`all_ones`: the caller built voxel_feats as ones (use_feats = False, use_coords = False): the input conv then needs no gather."""
         lv = geom.levels[0]
         vf = voxel_feats.to(self.dtype).contiguous()
         if self.preact:
-            x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)],
-                                       all_ones=all_ones and os.environ.get("TL_NO_ONES_TABLE") != "1")
+            ones = all_ones and os.environ.get("TL_NO_ONES_TABLE") != "1"
+            if geom.blocked and not ones:
+                # block-local level 1 with real input features: the input conv runs on the canonical table, its two views are
+                # carried into the block-local order (not the default configuration: the reference feeds ones)
+                if lv.nbr_ref is None:
+                    raise RuntimeError("a blocked geometry needs ref_table=True when the input features are not all ones")
+                # (the voxel features were averaged through the blocked v2p map, so they arrive in the new order)
+                xs = _conv_views(vf.index_select(0, lv.nbr.o2n.long()), self.w_in, lv.nbr_ref, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)])
+                perm = lv.nbr.perm.long()
+                x_raw, x_act = (ops.gather_rows(t, perm) for t in xs)
+            else:
+                x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)], all_ones=ones)
             (x,) = self.unet.run(x_raw, x_act, geom, 0, [RAW()])
         else:
             x = ops.conv_fwd(vf, self.w_in, lv.nbr, lv.n)

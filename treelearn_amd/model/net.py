@@ -109,11 +109,13 @@ class TreeLearn(nn.Module):
             output = self.get_loss(model_output=output, **batch)
         return output
 
-    def _voxelize(self, coords, input_feats, batch_ids, batch_size):
+    def _voxelize(self, coords, input_feats, batch_ids, batch_size, blocked=False):
         """`voxelize` of tree_learn.py:129-167 on the HIP library: geometry + voxel features
-        ([M, dim_feat+dim_coord] in (feat, x, y, z) order; ones unless use_feats/use_coords)."""
+        ([M, dim_feat+dim_coord] in (feat, x, y, z) order; ones unless use_feats/use_coords).  `blocked`: level 1 in the block-local row
+        order of the fused inference engine (geometry.BlockedRulebook); the voxel features stay in canonical order (the engine's input
+        conv carries them over)."""
         geom = G.build_geometry(coords.contiguous(), batch_ids.contiguous(), int(batch_size), self.voxel_size,
-                                self.num_blocks, self.spatial_shape)
+                                self.num_blocks, self.spatial_shape, blocked=blocked, ref_table=self.use_coords or self.use_feats)
         M = geom.levels[0].n
         C = coords.shape[1] + input_feats.shape[1]
         if self.use_coords or self.use_feats:
@@ -147,9 +149,13 @@ class TreeLearn(nn.Module):
 
     @cuda_cast
     def forward_backbone(self, coords, input_feats, batch_ids, batch_size, **kwargs):
-        vfeats, geom = self._voxelize(coords.float(), input_feats.float(), batch_ids.long(), batch_size)
         dtype = self.active_dtype()
-        if self.training or torch.is_grad_enabled():
+        fused = not (self.training or torch.is_grad_enabled())
+        if fused and (self._plan is None or self._plan.dtype != dtype):
+            self._plan = InferencePlan(self, dtype)
+        vfeats, geom = self._voxelize(coords.float(), input_feats.float(), batch_ids.long(), batch_size,
+                                      blocked=fused and self._plan.supports_blocked())
+        if not fused:
             # module-by-module path (batch-statistics BatchNorm, autograd through the HIP convs)
             lv = geom.levels[0]
             x = spconv.SparseConvTensor(vfeats, lv.coords, list(lv.shape), batch_size, geometry=geom, level=0)
@@ -162,8 +168,6 @@ class TreeLearn(nn.Module):
             finally:
                 spconv.SparseConvolution.amp_dtype = prev
             return x, geom.v2p
-        if self._plan is None or self._plan.dtype != dtype:
-            self._plan = InferencePlan(self, dtype)
         return (vfeats, geom), geom.v2p
 
     # ------------------------------------------------------------------ two-phase inference (software-pipelined tile loop)
@@ -181,7 +185,7 @@ class TreeLearn(nn.Module):
         with torch.cuda.stream(self._geom_stream), torch.no_grad():
             mv = lambda t: t.cuda(non_blocking=True) if not t.is_cuda else t                 # noqa: E731
             vfeats, geom = self._voxelize(mv(batch['coords']).float(), mv(batch['input_feats']).float(),
-                                          mv(batch['batch_ids']).long(), batch['batch_size'])
+                                          mv(batch['batch_ids']).long(), batch['batch_size'], blocked=self._plan.supports_blocked())
             ev = torch.cuda.Event(); ev.record(self._geom_stream)
         return (vfeats, geom, ev)
 

@@ -6,6 +6,7 @@ import os
 import torch
 
 from . import _hip
+from .geometry import BlockedRulebook
 
 # When set to a list, every conv_fwd launch is bracketed by HIP events on the launch stream and
 # (start, end, meta) is appended -- bench.py's live per-kernel timing.  None = no overhead.
@@ -54,20 +55,27 @@ def _check_table(table, K, n_out, device):
         if K != 1:
             raise ValueError(f"a {K}-tap conv needs a rulebook")
         return
+    if isinstance(table, BlockedRulebook):
+        if K != 27 or table.n != n_out or table.unit.device != device:
+            raise ValueError(f"block-local rulebook of {table.n} rows on {table.unit.device} for a {K}-tap conv over {n_out} rows on {device}")
+        return
     if table.dtype != torch.int32 or table.dim() != 2 or tuple(table.shape) != (K, n_out) or not table.is_contiguous() or table.device != device:
         raise ValueError(f"rulebook must be a contiguous int32 [{K}, {n_out}] tensor on {device}, got {table.dtype} {tuple(table.shape)} on {table.device}")
 
 
 def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
              in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False,
-             out2=None, out3=None, one_hot=False, epi=None, all_ones=False):
+             out2=None, out3=None, one_hot=False, epi=None, all_ones=False, split=None):
     """out[o] = epi(sum_k W[k] . pro(x[table[k][o]])); x / out / residual may be column views of wider
     row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused.
 
     `epi` (training): "stats" -> the kernel also sums y and y^2 per channel (the statistics of the BatchNorm that consumes the result);
     ("bn_bwd", x_bn, st, relu) -> this is the input-gradient conv of a layer fed by relu?(bn(x_bn)): the result is masked by the ReLU
     and the sums of g and g * xhat are formed (tl_conv_args.epi_mode).  Returns (out, parts f64[.,2,Cout], nparts), or None when the
-    kernel family that serves the shape has no such epilogue (nothing was launched: the caller runs the separate passes)."""
+    kernel family that serves the shape has no such epilogue (nothing was launched: the caller runs the separate passes).
+
+    `table` may be a geometry.BlockedRulebook (K = 27): x / out / residual are then in the block-local row order.  `split` = (part, Cin of
+    the logical conv) marks a launch as one input-channel half of a wider conv (bench.py's per-launch accounting)."""
     L = _hip.lib()
     K, Cout, Cin = w_packed.shape
     if x.stride(1) != 1 or x.shape[1] != Cin:
@@ -82,6 +90,13 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a = _hip.ConvArgs()
     a.in_ = x.data_ptr(); a.in_ld = x.stride(0)
     a.weight = w_packed.data_ptr()
+    blk = table if isinstance(table, BlockedRulebook) else None
+    if blk is not None:                          # rows in block-local order: units / halo lists / local rulebooks instead of the table
+        table = None
+        if x.shape[0] != n_out:
+            raise ValueError("a block-local SubM conv maps the level onto itself")
+        a.blk_unit = blk.unit.data_ptr(); a.blk_counter = blk.counter.data_ptr(); a.blk_halo = blk.halo.data_ptr()
+        a.blk_lrb = blk.lrb.data_ptr(); a.blk_pmask = blk.pmask.data_ptr()
     a.table = table.data_ptr() if table is not None else None
     a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
     a.table_one_hot = int(bool(one_hot))          # inverse conv: one valid entry per output row
@@ -137,8 +152,8 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
         e0.record()
         _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
         e1.record()
-        PROFILE.append((e0, e1, dict(K=K, Cin=Cin, Cout=Cout, n_out=n_out, n_in=x.shape[0], table=table,
-                                     residual=residual is not None, esize=x.element_size())))
+        PROFILE.append((e0, e1, dict(K=K, Cin=Cin, Cout=Cout, n_out=n_out, n_in=x.shape[0], table=blk if blk is not None else table,
+                                     residual=residual is not None, esize=x.element_size(), split=split)))
         return out
     _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
     return out
