@@ -30,18 +30,34 @@ sys.path.insert(0, REPO)
 PEAK_MFMA_F32_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = vector rate
 PEAK_MFMA_BF16_TFLOPS = 2500.0     # dense
 PEAK_HBM_GBS = 8000.0
-GATHER_PATH_GBS = 32 * 256 * 2.4          # 32 B/clk/CU (measured, tools/gather_roof.hip) x 256 CUs x 2.4 GHz = 19 661 GB/s
 
 
 def conv_work(meta):
     """Algorithmic work of one conv launch (SURVEY.md §8d): flops = 2*pairs*Cin*Cout;
     compulsory bytes = (N_in*Cin + N_out*Cout [+ N_out*Cout residual]) * e + 8*pairs."""
     t = meta["table"]
-    pairs = int((t >= 0).sum()) if t is not None else meta["n_out"]
+    if t is None:
+        pairs = meta["n_out"]
+    elif hasattr(t, "count_pairs"):                          # block-local form of a rulebook (geometry.BlockedRulebook)
+        pairs = _PAIRS.get(id(t))
+        if pairs is None:
+            pairs = _PAIRS[id(t)] = t.count_pairs()
+    else:
+        pairs = int((t >= 0).sum())
     e = meta["esize"]
     flops = 2.0 * pairs * meta["Cin"] * meta["Cout"]
+    sp = meta.get("split")
+    if sp is not None:
+        # one input-channel half of a wider conv (the 64 -> 32 decoder conv of level 1 runs as two 32 -> 32 launches, the second taking the
+        # first one's result as residual): the LOGICAL conv's compulsory bytes are charged once, to part 0; the hand-over is not algorithmic
+        part, cin = sp
+        byts = ((meta["n_in"] * cin + meta["n_out"] * meta["Cout"]) * e + 8.0 * pairs) if part == 0 else 0.0
+        return flops, byts, pairs
     byts = (meta["n_in"] * meta["Cin"] + meta["n_out"] * meta["Cout"] * (2 if meta["residual"] else 1)) * e + 8.0 * pairs
     return flops, byts, pairs
+
+
+_PAIRS = {}
 
 
 def host_cores():
@@ -485,10 +501,9 @@ def main():
         recs = ops.PROFILE; ops.PROFILE = None
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / reps
         per = len(recs) // reps
-        flops = byts = slots = 0.0
+        flops = byts = 0.0
         for _, _, m in recs[:per]:
             f, b, _ = conv_work(m); flops += f; byts += b
-            slots += float(m["K"]) * m["n_out"] * m["Cin"] * m["esize"]          # bytes the gather path is ASKED for: every tap of every row, present or not
         avg_ms = tot_ms / per
         if args.layer_table:
             # per launch: measured time against its own two roofs -- matrix work if every tap of every 32-row block is contracted
@@ -514,14 +529,6 @@ def main():
             ach = byts / (tot_ms * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
                         mfma_tflops=flops / (tot_ms * 1e-3) / 1e12)
-        # Second roof, measured (tools/gather_roof.hip, profiles/r3_roofs/gather_roof.txt): a 16-B-per-lane gather instruction costs a CU 25-34
-        # clocks whatever its lanes fetch -- an absent neighbour (out-of-range lane) as much as a present one -- i.e. 32 B/clk/CU = 19.7 TB/s
-        # at 2.4 GHz is what the vector memory path returns (L2-resident rows, 16.3-19.6 TB/s measured).  Output-stationary sparse convs
-        # issue K * rows * Cin * esize of it.
-        roof["gather_path"] = dict(requested_gb_per_step=slots / 1e9, achieved_gbs=slots / (tot_ms * 1e-3) / 1e9, peak_gbs=GATHER_PATH_GBS,
-                                   frac=slots / (tot_ms * 1e-3) / 1e9 / GATHER_PATH_GBS,
-                                   note="bytes asked of the gather path (all taps, present or not) / conv time; peak = 32 B/clk/CU x 256 CUs x 2.4 GHz, "
-                                        "measured by tools/gather_roof.hip (profiles/r3_roofs/gather_roof.txt)")
         tr = pmc_traffic(args.dtype, args.workload)
         if tr is not None:
             roof["traffic"] = tr[0]["hbm_gb_per_step"]
@@ -531,7 +538,7 @@ def main():
             # the north-star's "HBM bandwidth on the rulebook gather": PMC bytes of the conv kernels / their measured time
             roof["traffic_gbs"] = roof["traffic"] / (tot_ms * 1e-3)
             roof["traffic_frac_of_peak"] = roof["traffic_gbs"] / PEAK_HBM_GBS
-        roof.update(kernel="tl_conv_fwd family (k_conv_streamq / k_conv_stream / k_conv_direct / k_conv_small / k_conv_in4)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
+        roof.update(kernel="tl_conv_fwd family (k_conv_streamq / k_conv_stream / k_conv_blk / k_conv_direct / k_conv_small / k_conv_ones27)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
                     algorithmic_gflop_per_step=flops / 1e9, algorithmic_gb_per_step=byts / 1e9)
 
     if rank == 0:

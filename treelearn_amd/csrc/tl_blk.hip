@@ -37,24 +37,57 @@ __device__ __forceinline__ void blk_decode(const BlkGrid& g, int64_t blk, int& b
 }
 
 // voxels per 8x8x8 block: one thread per block, 64 bitmap bytes (one per (x, y) column of the block)
-__global__ void __launch_bounds__(kBlock) k_blk_count(const uint64_t* __restrict__ bm, TlDims d, BlkGrid g, uint32_t* __restrict__ cnt) {
-  const int64_t blk = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (blk >= g.nblk) return;
-  int b, bx, by, bz;
-  blk_decode(g, blk, b, bx, by, bz);
-  const int sh = (bz & 7) * 8;
-  uint32_t c = 0;
-  for (int xi = 0; xi < 8; ++xi) {
-    const int x = bx * 8 + xi;
-    if (x >= d.X) break;
-    for (int yi = 0; yi < 8; ++yi) {
-      const int y = by * 8 + yi;
-      if (y >= d.Y) break;
-      const uint64_t w = bm[tl_col_word(d, b, x, y) + (bz >> 3)];
-      c += __popc((uint32_t)(w >> sh) & 0xFFu);
-    }
+__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* total) {      // kBlock threads
+  __shared__ uint32_t wsum[kBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+    if (lane >= off) inc += t;
   }
-  cnt[blk] = c;
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < kBlock / 64; ++w) { if (w < wid) base += wsum[w]; tot += wsum[w]; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// cnt[blk] and, per workgroup of kBlock blocks, their total (part[workgroup])
+__global__ void __launch_bounds__(kBlock) k_blk_count(const uint64_t* __restrict__ bm, TlDims d, BlkGrid g, uint32_t* __restrict__ cnt,
+                                                      uint32_t* __restrict__ part) {
+  const int64_t blk = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t c = 0;
+  if (blk < g.nblk) {
+    int b, bx, by, bz;
+    blk_decode(g, blk, b, bx, by, bz);
+    const int sh = (bz & 7) * 8;
+    for (int xi = 0; xi < 8; ++xi) {
+      const int x = bx * 8 + xi;
+      if (x >= d.X) break;
+      for (int yi = 0; yi < 8; ++yi) {
+        const int y = by * 8 + yi;
+        if (y >= d.Y) break;
+        const uint64_t w = bm[tl_col_word(d, b, x, y) + (bz >> 3)];
+        c += __popc((uint32_t)(w >> sh) & 0xFFu);
+      }
+    }
+    cnt[blk] = c;
+  }
+  uint32_t tot;
+  wg_exclusive_scan(c, &tot);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// bstart[blk] = part_excl[workgroup] + exclusive scan of cnt inside the workgroup
+__global__ void __launch_bounds__(kBlock) k_blk_starts(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ part_excl, int64_t nblk,
+                                                       uint32_t* __restrict__ bstart) {
+  const int64_t blk = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t c = blk < nblk ? cnt[blk] : 0;
+  uint32_t tot;
+  const uint32_t ex = wg_exclusive_scan(c, &tot);
+  if (blk < nblk) bstart[blk] = part_excl[blockIdx.x] + ex;
 }
 
 // exclusive scan of n u32 values by ONE workgroup of 1024 threads: every thread owns a contiguous slice
@@ -119,17 +152,17 @@ struct BlkOut {
   int64_t n; int64_t nchunks; int64_t cap_units; int halo_max;
 };
 
-__device__ __forceinline__ uint32_t hslot(uint32_t v) { return (v * 2654435761u) >> 21; }     // 11 bits
-
 // units, halo lists, local rulebooks: one wave per chunk of 64 new rows
 __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, TlDims d, BlkOut p) {
   __shared__ uint32_t s_tab[kBlock / 64][HASH];
   __shared__ uint32_t s_list[kBlock / 64][LIST];
+  __shared__ uint32_t s_lslot[kBlock / 64][LIST];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t chunk = (int64_t)blockIdx.x * (kBlock / 64) + wv;
   if (chunk >= p.nchunks) return;
   uint32_t* tab = s_tab[wv];
   uint32_t* list = s_list[wv];
+  uint32_t* lslot = s_lslot[wv];
   const int64_t base = chunk * 64;
   const int cnt = (int)(p.n - base < 64 ? p.n - base : 64);
   const int64_t r = base + lane;
@@ -171,6 +204,15 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     p.pmask[r] = (int32_t)pm;
   }
 
+  // the hash table is sized to the chunk: >= 2 x (outside references), 512 .. HASH slots
+  int nref = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) nref += (nn[k] >= 0 && (nn[k] < (int)base || nn[k] >= (int)base + cnt)) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) nref += __shfl_xor(nref, off);
+  const int TS = nref <= 256 ? 512 : (nref <= 512 ? 1024 : HASH);
+  const int tshift = nref <= 256 ? 23 : (nref <= 512 ? 22 : 21);
+  auto hs = [&](uint32_t v) __attribute__((always_inline)) { return (v * 2654435761u) >> tshift; };
+
   // depth-first halving of the chunk until every piece's halo fits
   int st_a[8], st_e[8];
   int sp = 1;
@@ -180,24 +222,58 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     --sp;
     const int a = st_a[sp], e = st_e[sp];
     const int lo = (int)base + a, hi = (int)base + e;                       // the piece's new rows [lo, hi)
-    for (int i = lane; i < HASH; i += 64) tab[i] = EMPTY;
+    for (int i = lane; i < TS; i += 64) tab[i] = EMPTY;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const bool inr = lane >= a && lane < e;
+    // Insert without atomics (an LDS compare-and-swap costs ~200 clocks per wave instruction) and without one LDS round trip per tap
+    // (the first version was latency-bound on ~190 dependent round trips per chunk): nine taps at a time, every pending key is read,
+    // written where its slot looks empty, read back; a key is placed when its slot holds it and moves to the next slot when another
+    // key won the slot.  The reads / writes of a round are independent of each other.
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      const int v = nn[k];
-      if (inr && v >= 0 && (v < lo || v >= hi)) {
-        uint32_t s = hslot((uint32_t)v);
-        while (true) {
-          const uint32_t old = atomicCAS(&tab[s], EMPTY, (uint32_t)v);
-          if (old == EMPTY || old == (uint32_t)v) break;
-          s = (s + 1) & (HASH - 1);
+    for (int g = 0; g < 3; ++g) {
+      uint32_t sl[9], pend = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int v = nn[9 * g + t];
+        if (inr && v >= 0 && (v < lo || v >= hi)) pend |= 1u << t;
+        sl[t] = hs((uint32_t)v);
+      }
+      while (__any(pend != 0)) {
+        uint32_t cur[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cur[t] = ((pend >> t) & 1u) ? tab[sl[t]] : 0u;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          if (((pend >> t) & 1u) && cur[t] == EMPTY) tab[sl[t]] = (uint32_t)nn[9 * g + t];
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cur[t] = ((pend >> t) & 1u) ? tab[sl[t]] : 0u;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          if ((pend >> t) & 1u) {
+            if (cur[t] == (uint32_t)nn[9 * g + t]) pend &= ~(1u << t); else sl[t] = (sl[t] + 1) & (uint32_t)(TS - 1);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // the distinct outside rows, compacted in slot order: list[i] = key, lslot[i] = its slot
     int H = 0;
-    for (int i = 0; i < HASH; i += 64) H += __popcll(__ballot(tab[i + lane] != EMPTY));
+    for (int i0 = 0; i0 < TS; i0 += 512) {
+      uint32_t sv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sv[q] = tab[i0 + q * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned long long m = __ballot(sv[q] != EMPTY);
+        if (sv[q] != EMPTY) {
+          const int at = H + __popcll(m & ((1ull << lane) - 1ull));
+          if (at < LIST) { list[at] = sv[q]; lslot[at] = (uint32_t)(i0 + q * 64 + lane); }
+        }
+        H += __popcll(m);
+      }
+    }
     if (H > p.halo_max && e - a > 1) {
       const int mid = a + (e - a) / 2;
       st_a[sp] = mid; st_e[sp] = e; ++sp;
@@ -217,54 +293,73 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
       if (lane == 0) atomicMax(p.counter + 1, 1);
       continue;
     }
-    // the distinct outside rows: compacted in slot order, then ranked (ascending row id = staged position - 64)
-    int run = 0;
-    for (int i = 0; i < HASH; i += 64) {
-      const uint32_t s = tab[i + lane];
-      const unsigned long long m = __ballot(s != EMPTY);
-      if (s != EMPTY) list[run + __popcll(m & ((1ull << lane) - 1ull))] = s;
-      run += __popcll(m);
-    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const int H16 = (H + 15) & ~15;
-    for (int j = lane; j < H16; j += 64) {
-      if (j < H) {
-        const uint32_t key = list[j];
-        int rank = 0;
-        for (int i = 0; i < H; ++i) rank += list[i] < key ? 1 : 0;
-        p.halo[(int64_t)lo * 32 + rank] = (int32_t)key;
-        uint32_t s = hslot(key);                                            // leave the rank with the key for the rulebook pass
-        while (tab[s] != key) s = (s + 1) & (HASH - 1);
-        tab[s] = key | ((uint32_t)rank << 25);
-      } else {
-        p.halo[(int64_t)lo * 32 + j] = -1;
+    // rank of every key among the keys (ascending row id = staged position - 64): lane j holds keys j and j + 64, the others come by
+    // readlane; the rank goes to the halo list and, packed above the key, back into the key's slot for the rulebook pass
+    {
+      const uint32_t k0 = lane < H ? list[lane] : EMPTY, k1 = lane + 64 < H ? list[lane + 64] : EMPTY;
+      const uint32_t s0 = lane < H ? lslot[lane] : 0u, s1 = lane + 64 < H ? lslot[lane + 64] : 0u;
+      int r0 = 0, r1 = 0;
+      const int h0 = H < 64 ? H : 64;
+      for (int i = 0; i < h0; ++i) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k0, i);
+        r0 += b < k0 ? 1 : 0; r1 += b < k1 ? 1 : 0;
       }
+      for (int i = 64; i < H; ++i) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k1, i - 64);
+        r0 += b < k0 ? 1 : 0; r1 += b < k1 ? 1 : 0;
+      }
+      const int H16 = (H + 15) & ~15;
+      if (lane < H) { p.halo[(int64_t)lo * 32 + r0] = (int32_t)k0; tab[s0] = k0 | ((uint32_t)r0 << 25); }
+      if (lane + 64 < H) { p.halo[(int64_t)lo * 32 + r1] = (int32_t)k1; tab[s1] = k1 | ((uint32_t)r1 << 25); }
+      if (lane >= H && lane < H16) p.halo[(int64_t)lo * 32 + lane] = -1;
+      if (lane + 64 >= H && lane + 64 < H16) p.halo[(int64_t)lo * 32 + lane + 64] = -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (inr) {
+    // local rulebook rows: own rows directly, outside rows through the table, again nine taps at a time
+    {
       uint32_t wds[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) wds[q] = 0;
+      constexpr uint32_t ZV = (uint32_t)(191 * 64 + 3 * 16);
 #pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        int pos = 191;
-        if (k < 27) {
-          const int v = nn[k];
-          if (v >= 0) {
-            if (v >= lo && v < hi) pos = v - lo;
-            else {
-              uint32_t s = hslot((uint32_t)v);
-              while ((tab[s] & KEYMASK) != (uint32_t)v) s = (s + 1) & (HASH - 1);
-              pos = 64 + (int)(tab[s] >> 25);
+      for (int g = 0; g < 3; ++g) {
+        uint32_t sl[9], pend = 0;
+        int pos[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int v = nn[9 * g + t];
+          pos[t] = 191;
+          if (inr && v >= 0) {
+            if (v >= lo && v < hi) pos[t] = v - lo; else pend |= 1u << t;
+          }
+          sl[t] = hs((uint32_t)v);
+        }
+        while (__any(pend != 0)) {
+          uint32_t cur[9];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) cur[t] = ((pend >> t) & 1u) ? tab[sl[t]] : 0u;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            if ((pend >> t) & 1u) {
+              if ((cur[t] & KEYMASK) == (uint32_t)nn[9 * g + t]) { pos[t] = 64 + (int)(cur[t] >> 25); pend &= ~(1u << t); }
+              else sl[t] = (sl[t] + 1) & (uint32_t)(TS - 1);
             }
           }
         }
-        const uint32_t val = (uint32_t)(pos * 64 + ((pos >> 2) & 3) * 16);
-        wds[k >> 1] |= val << ((k & 1) * 16);
-      }
-      uint4* dst = reinterpret_cast<uint4*>(p.lrb + r * 32);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[q] = make_uint4(wds[4 * q], wds[4 * q + 1], wds[4 * q + 2], wds[4 * q + 3]);
+        for (int t = 0; t < 9; ++t) {
+          const int k = 9 * g + t;
+          const uint32_t val = (uint32_t)(pos[t] * 64 + ((pos[t] >> 2) & 3) * 16);
+          wds[k >> 1] |= val << ((k & 1) * 16);
+        }
+      }
+      wds[13] |= ZV << 16; wds[14] = ZV | (ZV << 16); wds[15] = ZV | (ZV << 16);       // entries 27..31
+      if (inr) {
+        uint4* dst = reinterpret_cast<uint4*>(p.lrb + r * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = make_uint4(wds[4 * q], wds[4 * q + 1], wds[4 * q + 2], wds[4 * q + 3]);
+      }
     }
     if (lane == 0) reinterpret_cast<int4*>(p.unit)[u] = make_int4(lo, e - a, H, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -282,7 +377,7 @@ extern "C" {
 int64_t tl_blk_ws_words(const int32_t dims[4]) {
   if (!dims) return -1;
   const int64_t nblk = (int64_t)dims[0] * ((dims[1] + 7) / 8) * ((dims[2] + 7) / 8) * ((dims[3] + 7) / 8);
-  return 2 * nblk + 4;
+  return 2 * nblk + 2 * ((nblk + 255) / 256) + 8;
 }
 
 int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4], int64_t n, const tl_blk* o, uint32_t* ws,
@@ -298,10 +393,14 @@ int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t d
   hipStream_t s = tl_s(stream);
   uint32_t* cnt = ws;
   uint32_t* bstart = ws + g.nblk;
+  const int64_t nparts = tl_cdiv(g.nblk, kBlock);
+  uint32_t* part = ws + 2 * g.nblk;
+  uint32_t* part_excl = part + nparts;
   const int64_t nchunks = (n + 63) / 64;
   k_blk_init<<<1, 64, 0, s>>>(o->counter, (int32_t)nchunks);
-  k_blk_count<<<(unsigned)tl_cdiv(g.nblk, kBlock), kBlock, 0, s>>>(bitmap, d, g, cnt);
-  k_scan_u32<<<1, 1024, 0, s>>>(cnt, g.nblk, bstart, ws + 2 * g.nblk);
+  k_blk_count<<<(unsigned)nparts, kBlock, 0, s>>>(bitmap, d, g, cnt, part);
+  k_scan_u32<<<1, 1024, 0, s>>>(part, nparts, part_excl, part_excl + nparts);
+  k_blk_starts<<<(unsigned)nparts, kBlock, 0, s>>>(cnt, part_excl, g.nblk, bstart);
   k_blk_order<<<(unsigned)tl_cdiv(g.nblk, kBlock / 64), kBlock, 0, s>>>(bitmap, prefix, d, g, cnt, bstart, o->o2n, o->perm, o->coords_new);
   BlkOut p;
   p.o2n = o->o2n; p.coords_new = o->coords_new; p.unit = o->unit; p.counter = o->counter; p.halo = o->halo; p.lrb = o->lrb; p.pmask = o->pmask;

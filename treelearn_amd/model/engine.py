@@ -203,7 +203,7 @@ class InferencePlan:
                 # (the voxel features were averaged through the blocked v2p map, so they arrive in the new order)
                 xs = _conv_views(vf.index_select(0, lv.nbr.o2n.long()), self.w_in, lv.nbr_ref, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)])
                 perm = lv.nbr.perm.long()
-                x_raw, x_act = (ops.gather_rows(t, perm) for t in xs)
+                x_raw, x_act = (t.index_select(0, perm) for t in xs)
             else:
                 x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)], all_ones=ones)
             (x,) = self.unet.run(x_raw, x_act, geom, 0, [RAW()])
