@@ -430,6 +430,7 @@ def main():
             emit(res, used_rccl=True)
         return
 
+    used_rccl_extra = False
     cfg = CONFIGS[args.workload]
     tile = make_tile(**cfg, seed=rank)                                 # every rank its own tile
     batch = make_batch([tile])
@@ -557,6 +558,18 @@ def main():
                 for _ in range(8): step()
                 torch.cuda.synchronize(); d1 = (time.perf_counter() - t1) / 8
             res["one_tile_at_a_time"] = dict(value=n_pts / d1 / 1e6, unit="Mpoints/s", ms_per_step=d1 * 1e3)
+        # SURVEY.md 8d's latency definition next to the throughput `value`: wall time of ONE model(batch, return_loss=False), device-resident
+        # input to device-resident outputs, strictly sequential (a device synchronisation after every forward), median of 24
+        lat = []
+        with torch.no_grad():
+            for _ in range(3): step()
+            torch.cuda.synchronize()
+            for _ in range(24):
+                t1 = time.perf_counter(); step(); torch.cuda.synchronize(); lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        res["latency_ms_median"] = 0.5 * (lat[11] + lat[12])
+        res["latency"] = dict(median_ms=res["latency_ms_median"], min_ms=lat[0], max_ms=lat[-1], forwards=24,
+                              definition="one model(batch, return_loss=False) on device-resident input, torch.cuda.synchronize() after each (SURVEY.md 8d)")
         if world == 1 and args.dtype in ("bf16", "fp16") and not args.no_fp32_mode:
             # the fp32 parity mode (the precision the 1e-3 parity gate is checked in), same tile, for reference
             m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype=torch.float32)
@@ -583,6 +596,23 @@ def main():
                 res["config5"] = forward_block("config5", "fp16" if args.dtype == "bf16" else args.dtype, 5, 2, nfl, trained_like=True)
             except Exception as e:                                      # noqa: BLE001
                 res["config5"] = dict(error=f"{type(e).__name__}: {e}")
+        if world == 1 and args.workload == "config2" and not args.no_extra_workloads and dist is None:
+            # BASELINE config 4 in the default line: the 64-tile plot through the sharded tile loop at world 1 (reference
+            # tools/pipeline/pipeline.py:66-94 -> util/pipeline.py:79-109), inner-square filter and the device-resident record gather
+            # (2 collectives on a world-1 RCCL group) inside the timed region
+            try:
+                import torch.distributed as d4
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                d4.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+                used_rccl_extra = True
+                sec4, tp4, rows4 = sharded_plot(model, d4, 0, 1, args.plot_tiles, 1, 1)
+                res["config4"] = dict(value=tp4 / sec4 / 1e6, unit="Mpoints/s", ms_per_plot=sec4 * 1e3, ms_per_tile=sec4 * 1e3 / args.plot_tiles, tiles=args.plot_tiles,
+                                      total_points=tp4, gathered_rows=rows4, collectives_per_plot=2, n_gpus=1, dtype=args.dtype,
+                                      workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares) through "
+                                               "get_pointwise_preds_sharded on 1 GPU, record gather timed")
+                d4.destroy_process_group()
+            except Exception as e:                                      # noqa: BLE001
+                res["config4"] = dict(error=f"{type(e).__name__}: {e}")
         if world == 1 and not args.no_power_probe:
             pw = power_probe(step)
             if pw:
@@ -598,9 +628,14 @@ def main():
             res["sharded_plot"] = dict(value=tp / sec / 1e6, unit="Mpoints/s", tiles=8 * world, ms_per_plot=sec * 1e3, gathered_rows=rows,
                                        collectives_per_plot=2, note="tile loop + inner-square filter + device-resident record gather, timed together")
     if dist:
+        # proof that the collective library saw `world` ranks: an all-reduce of ones over the group the timing barriers used
+        one = torch.ones(1, device="cuda", dtype=torch.float32)
+        dist.all_reduce(one)
+        if rank == 0:
+            res["rccl_world"] = int(round(float(one)))
         dist.destroy_process_group()
     if rank == 0:
-        emit(res, used_rccl=bool(dist))
+        emit(res, used_rccl=bool(dist) or used_rccl_extra)
 
 
 if __name__ == "__main__":

@@ -169,8 +169,11 @@ typedef struct tl_blk {
   int32_t reserved;
 } tl_blk;
 int64_t tl_blk_ws_words(const int32_t dims[4]);
+/* phases: 1 = the order (o2n, perm, coords_new + the scratch the second phase reads), 2 = units / halo / lrb / pmask, 3 = both.  The
+ * two phases may be enqueued on different streams (phase 2 after phase 1): what tl_rulebooks_build needs of a blocked level is o2n only,
+ * so the unit builder -- instruction-bound, light on memory -- can run beside the rulebook kernels of the other levels. */
 int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4], int64_t n, const tl_blk* out, uint32_t* ws,
-                 tl_stream_t stream);
+                 int phases, tl_stream_t stream);
 
 /* Column form of a 27-tap SubM rulebook built by tl_rulebook_subm: compact i32[10][n] = the row of the first present
  * dz neighbour of each of the 9 (dx, dy) columns (or -1) followed by a 27-bit presence mask.  Present neighbours of a

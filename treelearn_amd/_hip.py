@@ -81,7 +81,7 @@ PROTOTYPES = {
     "tl_pyramid_build": (_i32, [_vp, _i64, _I4, _I3, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tl_rulebooks_build": (_i32, [_c.POINTER(Level), _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
     "tl_blk_ws_words": (_i64, [_I4]),
-    "tl_blk_build": (_i32, [_vp, _vp, _I4, _i64, _c.POINTER(Blk), _vp, _vp]),
+    "tl_blk_build": (_i32, [_vp, _vp, _I4, _i64, _c.POINTER(Blk), _vp, _i32, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_conv_red_parts": (_i64, [_i64]),
     "tl_bn_train_finish": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

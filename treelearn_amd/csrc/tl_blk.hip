@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(1024) k_scan_u32(const uint32_t* __restrict__ 
 // new row of every voxel: one wave per block, lane = (x, y) column of the block
 __global__ void __launch_bounds__(kBlock) k_blk_order(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, TlDims d, BlkGrid g,
                                                       const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bstart,
-                                                      int32_t* __restrict__ o2n, int32_t* __restrict__ perm, int32_t* __restrict__ coords_new) {
+                                                      int32_t* __restrict__ o2n, int32_t* __restrict__ perm, int32_t* __restrict__ coords_new,
+                                                      uint32_t* __restrict__ cs) {
   const int lane = threadIdx.x & 63;
   const int64_t blk = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (blk >= g.nblk) return;
@@ -136,6 +137,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_order(const uint64_t* __restrict
   if (!pc) return;
   int newr = (int)(bstart[blk] + inc - pc);
   int old = (int)(pf[w] + __popcll(word & ((1ull << sh) - 1ull)));
+  cs[(((int64_t)b * d.X + x) * d.Y + y) * g.BZ + bz] = (uint32_t)newr;       // new row of the first voxel of this (column, z byte)
   while (byte) {
     const int zb = __ffs((int)byte) - 1;
     byte &= byte - 1;
@@ -146,15 +148,16 @@ __global__ void __launch_bounds__(kBlock) k_blk_order(const uint64_t* __restrict
 }
 
 struct BlkOut {
-  const int32_t* o2n; const int32_t* coords_new;
+  const uint32_t* cs; int BZ;           // new row of the first voxel of every non-empty (column, z byte): [b][x][y][BZ]
+  const int32_t* coords_new;
   int32_t* unit; int32_t* counter;      // counter[0] = number of units (pre-set to n_chunks), counter[1] = error flag
   int32_t* halo; uint16_t* lrb; int32_t* pmask;
   int64_t n; int64_t nchunks; int64_t cap_units; int halo_max;
 };
 
 // units, halo lists, local rulebooks: one wave per chunk of 64 new rows
-__global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict__ bm, const uint32_t* __restrict__ pf, TlDims d, BlkOut p) {
-  __shared__ uint32_t s_tab[kBlock / 64][HASH];
+__global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict__ bm, TlDims d, BlkOut p) {
+  __shared__ uint32_t s_tab[kBlock / 64][HASH + 64];        // + the dummy slot idle lanes use
   __shared__ uint32_t s_list[kBlock / 64][LIST];
   __shared__ uint32_t s_lslot[kBlock / 64][LIST];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -168,50 +171,76 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
   const int64_t r = base + lane;
   const bool rvalid = lane < cnt;
 
-  // the lane's 27 neighbours as NEW row ids (-1 = absent): the rank probes of tl_voxel.hip's rulebook kernel, then o2n
+  // the lane's 27 neighbours as NEW row ids (-1 = absent).  Presence comes from the occupancy bitmap; the new row of a present cell is
+  // cs[column, z byte] + the set bits below it in its byte (rows of a column byte are consecutive in the block order) -- no rank
+  // prefix, no canonical -> new look-up.  The loads are issued in THREE batches (coordinates; the nine column words; the column-byte
+  // starts) with addresses selected instead of loads branched around: with a branch per column hipcc waits for every column's word
+  // before it requests the next one, and eighteen dependent round trips at ~2 us each were the whole kernel (0.31 ms).
   int nn[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) nn[k] = -1;
   uint32_t pm = 0;
-  if (rvalid) {
-    const int4 c = reinterpret_cast<const int4*>(p.coords_new)[r];
+  {
+    const int4 c = rvalid ? reinterpret_cast<const int4*>(p.coords_new)[r] : make_int4(0, 0, 0, 0);
+    const int z = c.w;
+    const bool hz0 = z > 0, hz2 = z + 1 < d.Z;
+    const int bA = (hz0 ? z - 1 : z) >> 3, bB = (hz2 ? z + 1 : z) >> 3;
+    const bool x0 = hz0 && ((z - 1) >> 6) != (z >> 6), x2 = hz2 && ((z + 1) >> 6) != (z >> 6);     // dz = -1 / +1 lies in the next word
+    bool inb[9]; int64_t wc[9], ci[9];
+    uint64_t w1[9], w0[9], w2[9];
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
+    for (int q = 0; q < 9; ++q) {
+      const int x = c.y + q / 3 - 1, y = c.z + q % 3 - 1;
+      inb[q] = rvalid && x >= 0 && x < d.X && y >= 0 && y < d.Y;
+      wc[q] = inb[q] ? tl_col_word(d, c.x, x, y) : 0;
+      ci[q] = inb[q] ? (((int64_t)c.x * d.X + x) * d.Y + y) * p.BZ : 0;
+      w1[q] = bm[wc[q] + (inb[q] ? (z >> 6) : 0)];
+      w0[q] = 0; w2[q] = 0;
+    }
+    if (__any(x0 || x2)) {                                   // rare (z on a 64-cell boundary): a second batch
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int x = c.y + dx, y = c.z + dy;
-        const int tap0 = (dx + 1) * 9 + (dy + 1) * 3;
-        int r0 = -1, r1 = -1, r2 = -1;
-        if (x >= 0 && x < d.X && y >= 0 && y < d.Y) {
-          const int64_t wc = tl_col_word(d, c.x, x, y);
-          const int z = c.w;
-          const int64_t w = wc + (z >> 6);
-          const uint64_t word = bm[w];
-          const uint32_t pbase = pf[w];
-          const int bit = z & 63;
-          const uint64_t below = (1ull << bit) - 1;
-          if (word & (1ull << bit)) r1 = (int)(pbase + __popcll(word & below));
-          if (bit > 0) { if (word & (1ull << (bit - 1))) r0 = (int)(pbase + __popcll(word & (below >> 1))); }
-          else if (z > 0) r0 = tl_rank_at(bm, pf, wc, z - 1);
-          if (bit < 63) { if (word & (2ull << bit)) r2 = (int)(pbase + __popcll(word & ((below << 1) | 1ull))); }
-          else if (z + 1 < d.Z) r2 = tl_rank_at(bm, pf, wc, z + 1);
-        }
-        if (r0 >= 0) { nn[tap0] = p.o2n[r0]; pm |= 1u << tap0; }
-        if (r1 >= 0) { nn[tap0 + 1] = p.o2n[r1]; pm |= 2u << tap0; }
-        if (r2 >= 0) { nn[tap0 + 2] = p.o2n[r2]; pm |= 4u << tap0; }
+      for (int q = 0; q < 9; ++q) {
+        w0[q] = bm[wc[q] + ((inb[q] && x0) ? ((z - 1) >> 6) : 0)];
+        w2[q] = bm[wc[q] + ((inb[q] && x2) ? ((z + 1) >> 6) : 0)];
       }
     }
-    p.pmask[r] = (int32_t)pm;
+    bool p0[9], p1[9], p2[9];
+    uint32_t sA[9], sB[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const uint64_t a0 = x0 ? w0[q] : w1[q], a2 = x2 ? w2[q] : w1[q];
+      w0[q] = a0; w2[q] = a2;
+      p0[q] = inb[q] && hz0 && ((a0 >> ((z - 1) & 63)) & 1ull);
+      p1[q] = inb[q] && ((w1[q] >> (z & 63)) & 1ull);
+      p2[q] = inb[q] && hz2 && ((a2 >> ((z + 1) & 63)) & 1ull);
+      const bool any = p0[q] || p1[q] || p2[q];
+      sA[q] = p.cs[any ? ci[q] + bA : 0];
+      sB[q] = p.cs[(any && bB != bA) ? ci[q] + bB : 0];
+    }
+    auto rowid = [](uint64_t w, int zz, uint32_t start) __attribute__((always_inline)) {
+      const uint32_t byte = (uint32_t)(w >> (zz & 56)) & 0xFFu;
+      return (int)(start + __popc(byte & ((1u << (zz & 7)) - 1u)));
+    };
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const uint32_t b_ = bB != bA ? sB[q] : sA[q];
+      if (p0[q]) { nn[3 * q] = rowid(w0[q], z - 1, sA[q]); pm |= 1u << (3 * q); }
+      if (p1[q]) { nn[3 * q + 1] = rowid(w1[q], z, (z >> 3) == bA ? sA[q] : b_); pm |= 2u << (3 * q); }
+      if (p2[q]) { nn[3 * q + 2] = rowid(w2[q], z + 1, b_); pm |= 4u << (3 * q); }
+    }
+    if (rvalid) p.pmask[r] = (int32_t)pm;
   }
 
-  // the hash table is sized to the chunk: >= 2 x (outside references), 512 .. HASH slots
-  int nref = 0;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) nref += (nn[k] >= 0 && (nn[k] < (int)base || nn[k] >= (int)base + cnt)) ? 1 : 0;
+  // the hash table is sized to the chunk (load factor <= 0.7 even if every present neighbour were a distinct outside row)
+  int nref = __popc(pm);
   for (int off = 32; off > 0; off >>= 1) nref += __shfl_xor(nref, off);
-  const int TS = nref <= 256 ? 512 : (nref <= 512 ? 1024 : HASH);
-  const int tshift = nref <= 256 ? 23 : (nref <= 512 ? 22 : 21);
-  auto hs = [&](uint32_t v) __attribute__((always_inline)) { return (v * 2654435761u) >> tshift; };
+  const int TS = nref <= 360 ? 512 : (nref <= 720 ? 1024 : HASH);
+  const int tshift = nref <= 360 ? 23 : (nref <= 720 ? 22 : 21);
+  // slot of every neighbour (hoisted: the halving re-uses them); tab[TS] is a dummy slot that idle lanes read and write, so the passes
+  // below need no exec-mask juggling per tap (the first version spent 1 700 scalar instructions per wave on that)
+  uint32_t sl[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) sl[k] = ((uint32_t)nn[k] * 2654435761u) >> tshift;
 
   // depth-first halving of the chunk until every piece's halo fits
   int st_a[8], st_e[8];
@@ -225,37 +254,40 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     for (int i = lane; i < TS; i += 64) tab[i] = EMPTY;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const bool inr = lane >= a && lane < e;
-    // Insert without atomics (an LDS compare-and-swap costs ~200 clocks per wave instruction) and without one LDS round trip per tap
-    // (the first version was latency-bound on ~190 dependent round trips per chunk): nine taps at a time, every pending key is read,
-    // written where its slot looks empty, read back; a key is placed when its slot holds it and moves to the next slot when another
-    // key won the slot.  The reads / writes of a round are independent of each other.
+    // Insert without atomics (an LDS compare-and-swap costs ~200 clocks per wave instruction): every outside neighbour is WRITTEN to
+    // its home slot (equal keys agree, of different keys one wins), then read back; the few keys that lost their slot go through a
+    // probing loop (write where the slot looks empty, read back, move on while another key holds it).
+    uint32_t outm = 0;                                                      // bit k: tap k reaches outside the piece
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      uint32_t sl[9], pend = 0;
+    for (int k = 0; k < 27; ++k) {
+      const int v = nn[k];
+      const bool out = inr && v >= 0 && (v < lo || v >= hi);
+      outm |= out ? (1u << k) : 0u;
+      tab[out ? sl[k] : (uint32_t)TS] = (uint32_t)v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    uint32_t lost = 0;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int v = nn[9 * g + t];
-        if (inr && v >= 0 && (v < lo || v >= hi)) pend |= 1u << t;
-        sl[t] = hs((uint32_t)v);
-      }
-      while (__any(pend != 0)) {
-        uint32_t cur[9];
+    for (int k = 0; k < 27; ++k) {
+      const uint32_t cur = tab[sl[k]];
+      lost |= (((outm >> k) & 1u) && cur != (uint32_t)nn[k]) ? (1u << k) : 0u;
+    }
+    if (__any(lost != 0)) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) cur[t] = ((pend >> t) & 1u) ? tab[sl[t]] : 0u;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          if (((pend >> t) & 1u) && cur[t] == EMPTY) tab[sl[t]] = (uint32_t)nn[9 * g + t];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-        for (int t = 0; t < 9; ++t) cur[t] = ((pend >> t) & 1u) ? tab[sl[t]] : 0u;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          if ((pend >> t) & 1u) {
-            if (cur[t] == (uint32_t)nn[9 * g + t]) pend &= ~(1u << t); else sl[t] = (sl[t] + 1) & (uint32_t)(TS - 1);
+      for (int k = 0; k < 27; ++k) {
+        bool todo = (lost >> k) & 1u;
+        if (__any(todo)) {
+          uint32_t s_ = sl[k];
+          while (__any(todo)) {
+            if (todo) {
+              s_ = (s_ + 1) & (uint32_t)(TS - 1);
+              if (tab[s_] == EMPTY) tab[s_] = (uint32_t)nn[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (todo && tab[s_] == (uint32_t)nn[k]) todo = false;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       }
     }
     // the distinct outside rows, compacted in slot order: list[i] = key, lslot[i] = its slot
@@ -297,62 +329,68 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     // rank of every key among the keys (ascending row id = staged position - 64): lane j holds keys j and j + 64, the others come by
     // readlane; the rank goes to the halo list and, packed above the key, back into the key's slot for the rulebook pass
     {
-      const uint32_t k0 = lane < H ? list[lane] : EMPTY, k1 = lane + 64 < H ? list[lane + 64] : EMPTY;
-      const uint32_t s0 = lane < H ? lslot[lane] : 0u, s1 = lane + 64 < H ? lslot[lane + 64] : 0u;
-      int r0 = 0, r1 = 0;
-      const int h0 = H < 64 ? H : 64;
-      for (int i = 0; i < h0; ++i) {
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k0, i);
-        r0 += b < k0 ? 1 : 0; r1 += b < k1 ? 1 : 0;
-      }
-      for (int i = 64; i < H; ++i) {
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k1, i - 64);
-        r0 += b < k0 ? 1 : 0; r1 += b < k1 ? 1 : 0;
-      }
+      const uint32_t k0 = lane < H ? list[lane] : EMPTY, s0 = lane < H ? lslot[lane] : (uint32_t)TS;
+      int r0 = 0;
       const int H16 = (H + 15) & ~15;
-      if (lane < H) { p.halo[(int64_t)lo * 32 + r0] = (int32_t)k0; tab[s0] = k0 | ((uint32_t)r0 << 25); }
-      if (lane + 64 < H) { p.halo[(int64_t)lo * 32 + r1] = (int32_t)k1; tab[s1] = k1 | ((uint32_t)r1 << 25); }
-      if (lane >= H && lane < H16) p.halo[(int64_t)lo * 32 + lane] = -1;
-      if (lane + 64 >= H && lane + 64 < H16) p.halo[(int64_t)lo * 32 + lane + 64] = -1;
+      if (H <= 64) {
+        for (int i = 0; i < H; ++i) r0 += (uint32_t)__builtin_amdgcn_readlane((int)k0, i) < k0 ? 1 : 0;
+        if (lane < H) p.halo[(int64_t)lo * 32 + r0] = (int32_t)k0;
+        tab[s0] = k0 | ((uint32_t)r0 << 25);
+        if (lane >= H && lane < H16) p.halo[(int64_t)lo * 32 + lane] = -1;
+      } else {
+        const uint32_t k1 = lane + 64 < H ? list[lane + 64] : EMPTY, s1 = lane + 64 < H ? lslot[lane + 64] : (uint32_t)TS;
+        int r1 = 0;
+        for (int i = 0; i < 64; ++i) {
+          const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k0, i);
+          r0 += b < k0 ? 1 : 0; r1 += b < k1 ? 1 : 0;
+        }
+        for (int i = 64; i < H; ++i) {
+          const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)k1, i - 64);
+          r0 += b < k0 ? 1 : 0; r1 += b < k1 ? 1 : 0;
+        }
+        p.halo[(int64_t)lo * 32 + r0] = (int32_t)k0;
+        tab[s0] = k0 | ((uint32_t)r0 << 25);
+        if (lane + 64 < H) p.halo[(int64_t)lo * 32 + r1] = (int32_t)k1;
+        tab[s1] = k1 | ((uint32_t)r1 << 25);
+        if (lane + 64 >= H && lane + 64 < H16) p.halo[(int64_t)lo * 32 + lane + 64] = -1;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    // local rulebook rows: own rows directly, outside rows through the table, again nine taps at a time
+    // local rulebook rows: own rows directly, outside rows through the table (home slot first; the few displaced keys probe on)
     {
       uint32_t wds[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) wds[q] = 0;
       constexpr uint32_t ZV = (uint32_t)(191 * 64 + 3 * 16);
+      uint32_t miss = 0;
+      uint32_t cur[27];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        uint32_t sl[9], pend = 0;
-        int pos[9];
+      for (int k = 0; k < 27; ++k) cur[k] = tab[sl[k]];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int v = nn[9 * g + t];
-          pos[t] = 191;
-          if (inr && v >= 0) {
-            if (v >= lo && v < hi) pos[t] = v - lo; else pend |= 1u << t;
-          }
-          sl[t] = hs((uint32_t)v);
-        }
-        while (__any(pend != 0)) {
-          uint32_t cur[9];
+      for (int k = 0; k < 27; ++k) miss |= (((outm >> k) & 1u) && (cur[k] & KEYMASK) != (uint32_t)nn[k]) ? (1u << k) : 0u;
+      if (__any(miss != 0)) {
 #pragma unroll
-          for (int t = 0; t < 9; ++t) cur[t] = ((pend >> t) & 1u) ? tab[sl[t]] : 0u;
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            if ((pend >> t) & 1u) {
-              if ((cur[t] & KEYMASK) == (uint32_t)nn[9 * g + t]) { pos[t] = 64 + (int)(cur[t] >> 25); pend &= ~(1u << t); }
-              else sl[t] = (sl[t] + 1) & (uint32_t)(TS - 1);
+        for (int k = 0; k < 27; ++k) {
+          bool todo = (miss >> k) & 1u;
+          if (__any(todo)) {
+            uint32_t s_ = sl[k];
+            while (__any(todo)) {
+              if (todo) {
+                s_ = (s_ + 1) & (uint32_t)(TS - 1);
+                const uint32_t c_ = tab[s_];
+                if ((c_ & KEYMASK) == (uint32_t)nn[k]) { cur[k] = c_; todo = false; }
+              }
             }
           }
         }
+      }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int k = 9 * g + t;
-          const uint32_t val = (uint32_t)(pos[t] * 64 + ((pos[t] >> 2) & 3) * 16);
-          wds[k >> 1] |= val << ((k & 1) * 16);
-        }
+      for (int k = 0; k < 27; ++k) {
+        const int v = nn[k];
+        const bool out = (outm >> k) & 1u;
+        const int pos = out ? 64 + (int)(cur[k] >> 25) : ((inr && v >= 0) ? v - lo : 191);
+        const uint32_t val = (uint32_t)(pos * 64 + ((pos >> 2) & 3) * 16);
+        wds[k >> 1] |= val << ((k & 1) * 16);
       }
       wds[13] |= ZV << 16; wds[14] = ZV | (ZV << 16); wds[15] = ZV | (ZV << 16);       // entries 27..31
       if (inr) {
@@ -377,12 +415,13 @@ extern "C" {
 int64_t tl_blk_ws_words(const int32_t dims[4]) {
   if (!dims) return -1;
   const int64_t nblk = (int64_t)dims[0] * ((dims[1] + 7) / 8) * ((dims[2] + 7) / 8) * ((dims[3] + 7) / 8);
-  return 2 * nblk + 2 * ((nblk + 255) / 256) + 8;
+  const int64_t ncb = (int64_t)dims[0] * dims[1] * dims[2] * ((dims[3] + 7) / 8);       // (column, z byte) starts
+  return 2 * nblk + 2 * ((nblk + 255) / 256) + 8 + ncb;
 }
 
 int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t dims[4], int64_t n, const tl_blk* o, uint32_t* ws,
-                 tl_stream_t stream) {
-  if (!bitmap || !prefix || !dims || !o || !ws || n <= 0 || n >= (1 << 25)) return TL_ERR_ARG;
+                 int phases, tl_stream_t stream) {
+  if (!bitmap || !prefix || !dims || !o || !ws || n <= 0 || n >= (1 << 25) || !(phases & 3)) return TL_ERR_ARG;
   if (!o->o2n || !o->perm || !o->coords_new || !o->unit || !o->counter || !o->halo || !o->lrb || !o->pmask) return TL_ERR_ARG;
   if (o->halo_max < 26 || o->halo_max > TL_BLK_HALO_MAX || o->cap_units < (n + 63) / 64) return TL_ERR_ARG;
   if (((uintptr_t)o->lrb) % 16 || ((uintptr_t)o->unit) % 16 || ((uintptr_t)o->coords_new) % 16) return TL_ERR_ARG;
@@ -396,16 +435,20 @@ int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t d
   const int64_t nparts = tl_cdiv(g.nblk, kBlock);
   uint32_t* part = ws + 2 * g.nblk;
   uint32_t* part_excl = part + nparts;
+  uint32_t* cs = ws + 2 * g.nblk + 2 * nparts + 8;
   const int64_t nchunks = (n + 63) / 64;
-  k_blk_init<<<1, 64, 0, s>>>(o->counter, (int32_t)nchunks);
-  k_blk_count<<<(unsigned)nparts, kBlock, 0, s>>>(bitmap, d, g, cnt, part);
-  k_scan_u32<<<1, 1024, 0, s>>>(part, nparts, part_excl, part_excl + nparts);
-  k_blk_starts<<<(unsigned)nparts, kBlock, 0, s>>>(cnt, part_excl, g.nblk, bstart);
-  k_blk_order<<<(unsigned)tl_cdiv(g.nblk, kBlock / 64), kBlock, 0, s>>>(bitmap, prefix, d, g, cnt, bstart, o->o2n, o->perm, o->coords_new);
+  if (phases & 1) {
+    k_blk_init<<<1, 64, 0, s>>>(o->counter, (int32_t)nchunks);
+    k_blk_count<<<(unsigned)nparts, kBlock, 0, s>>>(bitmap, d, g, cnt, part);
+    k_scan_u32<<<1, 1024, 0, s>>>(part, nparts, part_excl, part_excl + nparts);
+    k_blk_starts<<<(unsigned)nparts, kBlock, 0, s>>>(cnt, part_excl, g.nblk, bstart);
+    k_blk_order<<<(unsigned)tl_cdiv(g.nblk, kBlock / 64), kBlock, 0, s>>>(bitmap, prefix, d, g, cnt, bstart, o->o2n, o->perm, o->coords_new, cs);
+  }
+  if (!(phases & 2)) { TL_CHECK_LAUNCH(); return TL_OK; }
   BlkOut p;
-  p.o2n = o->o2n; p.coords_new = o->coords_new; p.unit = o->unit; p.counter = o->counter; p.halo = o->halo; p.lrb = o->lrb; p.pmask = o->pmask;
+  p.cs = cs; p.BZ = g.BZ; p.coords_new = o->coords_new; p.unit = o->unit; p.counter = o->counter; p.halo = o->halo; p.lrb = o->lrb; p.pmask = o->pmask;
   p.n = n; p.nchunks = nchunks; p.cap_units = o->cap_units; p.halo_max = o->halo_max;
-  k_blk_units<<<(unsigned)tl_cdiv(nchunks, kBlock / 64), kBlock, 0, s>>>(bitmap, prefix, d, p);
+  k_blk_units<<<(unsigned)tl_cdiv(nchunks, kBlock / 64), kBlock, 0, s>>>(bitmap, d, p);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
