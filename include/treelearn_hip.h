@@ -147,7 +147,8 @@ int tl_rulebooks_build(const tl_level* levels, int num_levels, int32_t* minus_on
 /* ---- block-local row order + staged rulebook of a level (what the level-1 convs of the inference engine run on; csrc/tl_blk.hip).
  * The reference's spconv keeps voxels in hash order and gathers every tap of every output row (blocks.py:57-70 -> spconv's
  * implicit-GEMM gather); the canonical order here (ascending key) pins the bit-exact rulebook tests.  For the matrix-core kernel a
- * THIRD, internal order is better: voxels sorted by (batch, x >> 3, y >> 3, z >> 3), canonical order inside a block.  Units of <= 64
+ * THIRD, internal order is better: voxels sorted by 8x8x8 block -- blocks ordered by (batch, x >> 5, y >> 5, (x >> 3) & 3, (y >> 3) & 3,
+ * z >> 3), i.e. tiles of 4 x 4 block columns --, canonical order inside a block.  Units of <= 64
  * consecutive rows of that order then reach few rows outside themselves (their "halo"), so a wave can stage own + halo rows once in
  * LDS and read all 27 taps from there.
  *   o2n / perm     i32[n]: canonical row -> new row and back;  coords_new i32[n][4] = (b,x,y,z) in the new order
@@ -156,14 +157,15 @@ int tl_rulebooks_build(const tl_level* levels, int num_levels, int32_t* minus_on
  *                  behind the ceil(n / 64) regular units in arrival order.  counter[0] (DEVICE) = number of units, counter[1] = error flag
  *   halo           i32[32 n]: the unit that starts at row r0 lists its DISTINCT outside rows ascending at halo + 32 r0, padded with -1
  *                  to a multiple of 16
- *   lrb            u16[n][32]: entry k of a row = byte offset of tap k's input row in the unit's stage: pos * 64 + ((pos >> 2) & 3) * 16
- *                  with pos = own row index (0..63), 64 + halo rank, or 191 = absent (the stage's zero row); entries 27..31 = absent
+ *   lrb            u32[n][9]: 27 ten-bit entries per row, tap k in word k / 3 at bits 10 (k % 3): entry = 4 * pos + ((pos >> 2) & 3), so that
+ *                  entry * 16 is the byte offset of tap k's input row in the unit's stage (64-B rows, 16-B pieces XOR-swizzled), with
+ *                  pos = own row index (0..63), 64 + halo rank, or 191 = absent (the stage's zero row)
  *   pmask          i32[n]: 27-bit presence mask of the row's taps
  * n < 2^25.  ws u32[tl_blk_ws_words(dims)].  Deterministic apart from the order of the appended units. */
 #define TL_BLK_HALO_MAX 126
 typedef struct tl_blk {
   int32_t* o2n; int32_t* perm; int32_t* coords_new;
-  int32_t* unit; int32_t* counter; int32_t* halo; uint16_t* lrb; int32_t* pmask;
+  int32_t* unit; int32_t* counter; int32_t* halo; uint32_t* lrb; int32_t* pmask;
   int64_t cap_units;        /* rows of `unit` (>= ceil(n / 64); n always suffices) */
   int32_t halo_max;         /* 26 .. TL_BLK_HALO_MAX */
   int32_t reserved;
@@ -237,7 +239,7 @@ typedef struct tl_conv_args {
    * block-local row order, `table` may be NULL, and K = 27, Cin = Cout = 32, TL_BF16 / TL_F16, no prologue, epi_mode = 0 are served by
    * the staged-unit kernel (csrc/tl_conv_blk.hip; same summation order as the gather kernels: bit-identical results); with
    * in_all_ones the presence masks come from blk_pmask.  Other shapes fall through to `table` (TL_ERR_UNSUPPORTED without one). */
-  const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint16_t* blk_lrb; const int32_t* blk_pmask;
+  const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint32_t* blk_lrb; const int32_t* blk_pmask;
 } tl_conv_args;
 
 #define TL_EPI_NONE 0

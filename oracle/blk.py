@@ -14,9 +14,10 @@ ZERO_POS = 191
 
 def block_order(coords):
     """coords i32[n,4] (b,x,y,z) in canonical (ascending key) order -> perm (new row -> canonical row), o2n (canonical -> new):
-    stable sort by (b, x >> 3, y >> 3, z >> 3)."""
+    stable sort by (b, x >> 5, y >> 5, (x >> 3) & 3, (y >> 3) & 3, z >> 3): 8x8x8 blocks, ordered in tiles of 4 x 4 block columns."""
     c = coords.astype(np.int64)
-    key = ((c[:, 0] * 8192 + (c[:, 1] >> 3)) * 8192 + (c[:, 2] >> 3)) * 8192 + (c[:, 3] >> 3)
+    bx, by, bz = c[:, 1] >> 3, c[:, 2] >> 3, c[:, 3] >> 3
+    key = (((((c[:, 0] * 4096 + (bx >> 2)) * 4096 + (by >> 2)) * 4 + (bx & 3)) * 4 + (by & 3)) * 8192) + bz
     perm = np.argsort(key, kind="stable")
     o2n = np.empty_like(perm)
     o2n[perm] = np.arange(len(perm))
@@ -24,7 +25,21 @@ def block_order(coords):
 
 
 def entry(pos):
-    return pos * 64 + ((pos >> 2) & 3) * 16
+    """ten-bit rulebook entry of a staged position: x 16 = byte offset of the row's piece 0 (64-B rows, pieces XOR-swizzled by (pos >> 2) & 3)"""
+    return pos * 4 + ((pos >> 2) & 3)
+
+
+def pack(ent):
+    """entries i64[n, 27] -> the rulebook rows u32[n, 9] (tap k in word k // 3 at bits 10 (k % 3))"""
+    out = np.zeros((ent.shape[0], 9), np.int64)
+    for k in range(27):
+        out[:, k // 3] |= ent[:, k] << (10 * (k % 3))
+    return out.astype(np.uint32)
+
+
+def unpack(lrb):
+    w = lrb.astype(np.int64)
+    return np.stack([(w[:, k // 3] >> (10 * (k % 3))) & 1023 for k in range(27)], 1)
 
 
 def build(coords, nbr, halo_max=HALO_MAX):
@@ -61,7 +76,7 @@ def build(coords, nbr, halo_max=HALO_MAX):
                 extra.append((lo, hi - lo, h))
             is_first = False
     units = first + extra
-    lrb = np.full((n, 32), entry(ZERO_POS), dtype=np.int64)
+    ent = np.full((n, 27), entry(ZERO_POS), dtype=np.int64)
     for lo, cnt, h in units:
         v = nn[:, lo:lo + cnt].T                                              # [cnt, 27]
         inside = (v >= lo) & (v < lo + cnt)
@@ -69,8 +84,8 @@ def build(coords, nbr, halo_max=HALO_MAX):
         pos[inside] = (v - lo)[inside]
         outside = (v >= 0) & ~inside
         pos[outside] = 64 + np.searchsorted(h, v[outside])
-        lrb[lo:lo + cnt, :27] = entry(pos)
-    return dict(perm=perm, o2n=o2n, coords_new=coords[perm], pmask=pmask, nn=nn, units=units, lrb=lrb.astype(np.uint16))
+        ent[lo:lo + cnt] = entry(pos)
+    return dict(perm=perm, o2n=o2n, coords_new=coords[perm], pmask=pmask, nn=nn, units=units, lrb=pack(ent))
 
 
 def build_fast(coords, nbr, halo_max=HALO_MAX):
@@ -130,16 +145,14 @@ def build_fast(coords, nbr, halo_max=HALO_MAX):
     ukey = np.repeat(np.arange(len(units)), hcnt) * n + hl                         # sorted within a unit, units ascending
     q = np.broadcast_to(row_unit[None, :], nn.shape)[out] * n + nn[out]
     pos[out] = 64 + np.searchsorted(ukey, q) - hstart[np.broadcast_to(row_unit[None, :], nn.shape)[out]]
-    lrb = np.full((n, 32), entry(ZERO_POS), dtype=np.int64)
-    lrb[:, :27] = entry(pos).T
-    return dict(perm=perm, o2n=o2n, coords_new=coords[perm], pmask=pmask, nn=nn, units=units, lrb=lrb.astype(np.uint16))
+    return dict(perm=perm, o2n=o2n, coords_new=coords[perm], pmask=pmask, nn=nn, units=units, lrb=pack(entry(pos).T))
 
 
 def decode(units, lrb, n):
     """units + local rulebooks -> the table in new rows i64[27, n] (what the conv kernel contracts)."""
     out = np.full((27, n), -2, dtype=np.int64)
     for lo, cnt, h in units:
-        pos = (lrb[lo:lo + cnt, :27].astype(np.int64) >> 6)
+        pos = unpack(lrb[lo:lo + cnt]) >> 2
         v = np.where(pos < 64, lo + pos, -1)
         hm = (pos >= 64) & (pos != ZERO_POS)
         v[hm] = h[(pos - 64)[hm]]

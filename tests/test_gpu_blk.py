@@ -56,7 +56,7 @@ def _check_blocked_geometry(can, blk, halo_max):
         H = len(h); H16 = (H + 15) // 16 * 16
         got = halo[32 * lo:32 * lo + H16]
         assert np.array_equal(got[:H], h) and (got[H:] == -1).all(), (lo, cnt)
-    np.testing.assert_array_equal(r.lrb.view(torch.int16).cpu().numpy().view(np.uint16).reshape(n, 32), o["lrb"])
+    np.testing.assert_array_equal(r.lrb.cpu().numpy().view(np.uint32), o["lrb"])
     # the staged form decodes to the canonical table carried into the new order
     np.testing.assert_array_equal(r.to_table().cpu().numpy().astype(np.int64), o["nn"])
     # tables that hold / are indexed by level-1 rows, and v2p

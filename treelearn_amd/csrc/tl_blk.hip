@@ -11,8 +11,9 @@
 //           ("halo") number <= TL_BLK_HALO_MAX; otherwise the chunk is halved (recursively) until every piece fits.  The first piece of a
 //           chunk is unit c, further pieces are appended behind the n_chunks regular units (rare: ~1.5 % of the chunks of a forest tile).
 //   halo  : per unit the DISTINCT outside rows in ascending order (new row ids), at halo + 32 * row0, padded with -1 to a multiple of 16.
-//   lrb   : per output row 32 x u16: entry k = LDS byte offset of tap k's input row inside the unit's stage (position * 64 + swizzle;
-//           own rows at positions 0..63, halo rows from position 64, absent -> the all-zero row at position 191).
+//   lrb   : per output row 9 x u32 holding 27 ten-bit entries (tap k in word k / 3, bits 10 (k % 3) ..): entry = 4 * position + swizzle, i.e.
+//           entry * 16 = LDS byte offset of tap k's input row inside the unit's stage (own rows at positions 0..63, halo rows from
+//           position 64, absent -> the all-zero row at position 191): 36 B per row, less than half of the 27-entry table's 108.
 //   pmask : 27-bit presence mask per (new) row.
 //
 // Integer / bit work on the occupancy bitmap + popcount prefix of tl_voxel.hip; no MFMA.  Everything is a pure function of the
@@ -27,13 +28,19 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEYMASK = 0x01FFFFFFu;  // rows < 2^25; the upper 7 bits of a slot receive the halo rank
 constexpr int LIST = 128;
 
-struct BlkGrid { int B, BX, BY, BZ; int64_t nblk; };
+// Block order: (batch, x tile, y tile, x in tile, y in tile, z) with tiles of 4 x 4 blocks -- the blocks a round of resident waves works on
+// form a compact brick, so the halo rows of a unit (rows of the neighbouring blocks) are mostly in the same XCD's L2 (with z-columns of
+// blocks simply ordered by (x, y), every block's x neighbours were ~1 100 units away: 18 % of the conv kernel's fetch was halo re-reads).
+// Blocks of a partial tile beyond the grid are empty.
+struct BlkGrid { int B, BX, BY, BZ, TX, TY; int64_t nblk; };
 
 __device__ __forceinline__ void blk_decode(const BlkGrid& g, int64_t blk, int& b, int& bx, int& by, int& bz) {
   bz = (int)(blk % g.BZ); blk /= g.BZ;
-  by = (int)(blk % g.BY); blk /= g.BY;
-  bx = (int)(blk % g.BX);
-  b = (int)(blk / g.BX);
+  const int iy = (int)(blk & 3), ix = (int)((blk >> 2) & 3); blk >>= 4;
+  const int ty = (int)(blk % g.TY); blk /= g.TY;
+  const int tx = (int)(blk % g.TX);
+  b = (int)(blk / g.TX);
+  bx = tx * 4 + ix; by = ty * 4 + iy;
 }
 
 // voxels per 8x8x8 block: one thread per block, 64 bitmap bytes (one per (x, y) column of the block)
@@ -151,7 +158,7 @@ struct BlkOut {
   const uint32_t* cs; int BZ;           // new row of the first voxel of every non-empty (column, z byte): [b][x][y][BZ]
   const int32_t* coords_new;
   int32_t* unit; int32_t* counter;      // counter[0] = number of units (pre-set to n_chunks), counter[1] = error flag
-  int32_t* halo; uint16_t* lrb; int32_t* pmask;
+  int32_t* halo; uint32_t* lrb; int32_t* pmask;
   int64_t n; int64_t nchunks; int64_t cap_units; int halo_max;
 };
 
@@ -358,10 +365,9 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     // local rulebook rows: own rows directly, outside rows through the table (home slot first; the few displaced keys probe on)
     {
-      uint32_t wds[16];
+      uint32_t wds[9];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) wds[q] = 0;
-      constexpr uint32_t ZV = (uint32_t)(191 * 64 + 3 * 16);
+      for (int q = 0; q < 9; ++q) wds[q] = 0;
       uint32_t miss = 0;
       uint32_t cur[27];
 #pragma unroll
@@ -389,14 +395,13 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
         const int v = nn[k];
         const bool out = (outm >> k) & 1u;
         const int pos = out ? 64 + (int)(cur[k] >> 25) : ((inr && v >= 0) ? v - lo : 191);
-        const uint32_t val = (uint32_t)(pos * 64 + ((pos >> 2) & 3) * 16);
-        wds[k >> 1] |= val << ((k & 1) * 16);
+        const uint32_t val = (uint32_t)(pos * 4 + ((pos >> 2) & 3));                    // x 16 = byte offset of the row's piece 0 in the stage
+        wds[k / 3] |= val << ((k % 3) * 10);
       }
-      wds[13] |= ZV << 16; wds[14] = ZV | (ZV << 16); wds[15] = ZV | (ZV << 16);       // entries 27..31
       if (inr) {
-        uint4* dst = reinterpret_cast<uint4*>(p.lrb + r * 32);
+        uint32_t* dst = p.lrb + r * 9;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = make_uint4(wds[4 * q], wds[4 * q + 1], wds[4 * q + 2], wds[4 * q + 3]);
+        for (int q = 0; q < 9; ++q) dst[q] = wds[q];
       }
     }
     if (lane == 0) reinterpret_cast<int4*>(p.unit)[u] = make_int4(lo, e - a, H, 0);
@@ -414,7 +419,7 @@ extern "C" {
 
 int64_t tl_blk_ws_words(const int32_t dims[4]) {
   if (!dims) return -1;
-  const int64_t nblk = (int64_t)dims[0] * ((dims[1] + 7) / 8) * ((dims[2] + 7) / 8) * ((dims[3] + 7) / 8);
+  const int64_t nblk = (int64_t)dims[0] * ((dims[1] + 31) / 32) * ((dims[2] + 31) / 32) * 16 * ((dims[3] + 7) / 8);
   const int64_t ncb = (int64_t)dims[0] * dims[1] * dims[2] * ((dims[3] + 7) / 8);       // (column, z byte) starts
   return 2 * nblk + 2 * ((nblk + 255) / 256) + 8 + ncb;
 }
@@ -424,11 +429,11 @@ int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t d
   if (!bitmap || !prefix || !dims || !o || !ws || n <= 0 || n >= (1 << 25) || !(phases & 3)) return TL_ERR_ARG;
   if (!o->o2n || !o->perm || !o->coords_new || !o->unit || !o->counter || !o->halo || !o->lrb || !o->pmask) return TL_ERR_ARG;
   if (o->halo_max < 26 || o->halo_max > TL_BLK_HALO_MAX || o->cap_units < (n + 63) / 64) return TL_ERR_ARG;
-  if (((uintptr_t)o->lrb) % 16 || ((uintptr_t)o->unit) % 16 || ((uintptr_t)o->coords_new) % 16) return TL_ERR_ARG;
+  if (((uintptr_t)o->unit) % 16 || ((uintptr_t)o->coords_new) % 16) return TL_ERR_ARG;
   const TlDims d = tl_dims(dims);
   BlkGrid g;
-  g.B = d.B; g.BX = (d.X + 7) / 8; g.BY = (d.Y + 7) / 8; g.BZ = (d.Z + 7) / 8;
-  g.nblk = (int64_t)g.B * g.BX * g.BY * g.BZ;
+  g.B = d.B; g.BX = (d.X + 7) / 8; g.BY = (d.Y + 7) / 8; g.BZ = (d.Z + 7) / 8; g.TX = (g.BX + 3) / 4; g.TY = (g.BY + 3) / 4;
+  g.nblk = (int64_t)g.B * g.TX * g.TY * 16 * g.BZ;
   hipStream_t s = tl_s(stream);
   uint32_t* cnt = ws;
   uint32_t* bstart = ws + g.nblk;

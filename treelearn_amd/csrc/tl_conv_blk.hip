@@ -34,6 +34,8 @@ constexpr int WS_B = 27 * 32 * 64;            // all taps of the weights
 constexpr int AFF_B = 3 * 2 * 32 * 4;         // scale / shift of up to three views
 constexpr int STAGE_B = 192 * 64;             // positions 0..63 own rows, 64..189 halo rows, 191 the zero row
 constexpr int HCH = 8;                        // halo chunks of 16 rows (TL_BLK_HALO_MAX = 126 <= 128)
+struct RbRow { u32x4 a, b; uint32_t c; };     // one row of the local rulebook
+static __device__ __forceinline__ uint32_t rb_word(const RbRow& r, int w) { return w < 4 ? r.a[w] : (w < 8 ? r.b[w - 4] : r.c); }
 
 template <int W, bool RES, int NV>
 __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
   for (int s_ = 0; s_ < 2; ++s_) boff[s_] = lds0 + (unsigned)(fi * 64 + (((2 * s_ + fh) ^ ((fi >> 2) & 3)) * 16));
   const unsigned in_ldb = (unsigned)(p.in_ld * 2);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)((p.n_in - 1) * (int64_t)in_ldb + 64), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.blk_lrb), 0, (int)(p.n_out * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.blk_lrb), 0, (int)(p.n_out * 36), 0x00020000);
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(p.blk_halo), 0, (int)(p.n_out * 128), 0x00020000);
   const unsigned o_ldb[3] = {(unsigned)(p.out_ld * 2), (unsigned)(p.out2_ld * 2), (unsigned)(p.out3_ld * 2)};
   void* const o_ptr[3] = {p.out, p.out2, p.out3};
@@ -97,14 +99,14 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
       asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(h[c]) : "v"(off), "s"(rh));
     }
   };
-  auto load_rb = [&](const int4& d, u32x4 (&rb)[2][4]) __attribute__((always_inline)) {
+  // the lane's rulebook row: 9 words = 27 ten-bit entries (36 B per row)
+  auto load_rb = [&](const int4& d, RbRow (&rb)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const unsigned off = d.y > 0 ? (unsigned)(d.x + t * 32 + fi) * 64u : 0xFFFFFFFFu;
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[t][0]) : "v"(off), "s"(rl));
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[t][1]) : "v"(off), "s"(rl));
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(rb[t][2]) : "v"(off), "s"(rl));
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:48" : "=v"(rb[t][3]) : "v"(off), "s"(rl));
+      const unsigned off = d.y > 0 ? (unsigned)(d.x + t * 32 + fi) * 36u : 0xFFFFFFFFu;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb[t].a) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(rb[t].b) : "v"(off), "s"(rl));
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:32" : "=v"(rb[t].c) : "v"(off), "s"(rl));
     }
   };
   // staging: 4 own chunks + as many halo chunks as the unit has (the counted wait at the top does not depend on their number)
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
     dc = desc_fin(r0, u0); d1 = desc_fin(r1, u0 + nw); d2 = desc_fin(r2, u0 + 2 * nw);
   }
   int hn[HCH];
-  u32x4 rbc[2][4], rbn[2][4];
+  RbRow rbc[2], rbn[2];
   {
     int h0[HCH];
     load_hidx(dc, h0); load_hidx(d1, hn); load_rb(dc, rbc);
@@ -151,16 +153,12 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
     if (firstu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NV) : "memory");
     if (!firstu) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { TL_KEEP(rbn[t][q]); rbc[t][q] = rbn[t][q]; }
+      for (int t = 0; t < 2; ++t) { TL_KEEP(rbn[t].a); TL_KEEP(rbn[t].b); TL_KEEP(rbn[t].c); rbc[t] = rbn[t]; }
 #pragma unroll
       for (int c = 0; c < HCH; ++c) TL_KEEP(hn[c]);
     } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) TL_KEEP(rbc[t][q]);
+      for (int t = 0; t < 2; ++t) { TL_KEEP(rbc[t].a); TL_KEEP(rbc[t].b); TL_KEEP(rbc[t].c); }
     }
     firstu = false;
     int hcur[HCH];
@@ -175,15 +173,14 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     {
-      u32x4 A[2][2][2], B[2][2];                                                    // 6 reads per tap: lgkmcnt counts to 15
+      u32x4 A[2][2][2], B[2][2];                                                    // 6 reads per tap
       auto issue = [&](int k, int s_) __attribute__((always_inline)) {
         B[s_][0] = lds_r128(boff[0] + (unsigned)(k * 2048));
         B[s_][1] = lds_r128(boff[1] + (unsigned)(k * 2048));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const uint32_t wd = rbc[t][k >> 3][(k >> 1) & 3];
-          const unsigned val = (k & 1) ? (wd >> 16) : (wd & 0xFFFFu);
-          const unsigned a0 = st_a + val;
+          const uint32_t wd = rb_word(rbc[t], k / 3);
+          const unsigned a0 = st_a + (((wd >> (10 * (k % 3))) & 1023u) << 4);
           A[s_][t][0] = lds_r128(a0 ^ pc16[0]);
           A[s_][t][1] = lds_r128(a0 ^ pc16[1]);
         }

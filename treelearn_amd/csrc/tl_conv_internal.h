@@ -48,7 +48,7 @@ struct ConvP {
   const float* bn_mean; const float* bn_rstd; const float* bn_scale; const float* bn_shift; int bn_relu;
   int one_hot; // every output row has at most one valid table entry (inverse conv)
   // block-local form of a 27-tap rulebook (tl_blk_build; tl_conv_args.blk_*), nullptr if absent
-  const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint16_t* blk_lrb; const int32_t* blk_pmask;
+  const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint32_t* blk_lrb; const int32_t* blk_pmask;
   int dbg;     // developer ablation bits (tl_set_tuning "dbg"): 1 no A loads, 2 no B loads, 4 no MFMA, 8 no stores
 };
 

@@ -23,7 +23,7 @@ BLK_HALO_MAX = 126
 
 class BlockedRulebook:
     """The block-local form of a level's 27-tap SubM rulebook (include/treelearn_hip.h `tl_blk`, csrc/tl_blk.hip): the level's rows are
-    re-ordered by 8x8x8 block (`o2n` / `perm`: canonical row <-> new row), cut into units of <= 64 rows with their halo lists and local
+    re-ordered by 8x8x8 block, blocks in tiles of 4 x 4 columns (`o2n` / `perm`: canonical row <-> new row), cut into units of <= 64 rows with their halo lists and local
     rulebooks.  Stands where the canonical table `nbr` stands (Level.nbr) when a geometry is built with `blocked=True`: every tensor
     that holds or is indexed by rows of the level -- features, `child` entries, `inv` / `parent`, `v2p` -- is then in the NEW order."""
     K = 27
@@ -50,7 +50,9 @@ class BlockedRulebook:
         uid = torch.repeat_interleave(torch.arange(nu, device=unit.device), nown)          # unit of every row, in unit order
         first = torch.cumsum(nown, 0) - nown
         rows = row0[uid] + (torch.arange(uid.numel(), device=unit.device) - first[uid])
-        pos = (self.lrb.view(torch.int16).long() & 0xFFFF)[rows][:, :27] >> 6                # staged position of every (row, tap)
+        w = self.lrb.long()[rows]                                                            # [rows, 9] words of 3 ten-bit entries
+        ent = torch.stack([(w[:, k // 3] >> (10 * (k % 3))) & 1023 for k in range(27)], 1)
+        pos = ent >> 2                                                                       # staged position of every (row, tap)
         r0 = row0[uid][:, None]
         halo = self.halo.long()
         hidx = (r0 * 32 + (pos - 64)).clamp(0, halo.numel() - 1)
@@ -263,7 +265,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         # the halo lists are indexed by the unit's first row (32 slots per row: a one-row unit can have 26 outside neighbours), the
         # unit array can hold one unit per row: worst cases that never occur, reserved but not touched
         nblk_ws = int(L.tl_blk_ws_words(_hip.dims4(dims[0])))
-        bl = dict(o2n=take(n1), perm=take(n1), cnew=take(4 * n1), unit=take(4 * n1), counter=take(64), halo=take(32 * n1), lrb=take(16 * n1),
+        bl = dict(o2n=take(n1), perm=take(n1), cnew=take(4 * n1), unit=take(4 * n1), counter=take(64), halo=take(32 * n1), lrb=take(9 * n1),
                   pmask=take(n1), ws=take(nblk_ws))
     o_m1 = cur                                              # parent / inv of all levels: contiguous, one fill with -1
     for li, lv in enumerate(levels[:-1]):
@@ -289,18 +291,23 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         bk.cap_units = n1; bk.halo_max = BLK_HALO_MAX; bk.reserved = 0
         _hip.check(L.tl_blk_build(arr[0].bitmap, arr[0].prefix, _hip.dims4(levels[0].dims), n1, ctypes.byref(bk), b0 + 4 * bl["ws"], 1, st), "tl_blk_build")
         arr[0].o2n = bk.o2n
-        # the unit builder (instruction-bound, ~0.27 ms) runs on a side stream beside the rulebook kernels of the other levels
+        # The unit builder (instruction-bound, ~0.27 ms) runs on a side stream beside the rulebook kernels of the other levels -- when the
+        # forward is on the DEFAULT stream (a lone forward: -0.15 ms).  Callers that keep several tiles in flight on their own streams
+        # (util/pipeline.get_pointwise_preds, bench.py) already fill those gaps, and one more stream per tile in flight oversubscribes
+        # the hardware queues (measured: 7.23 -> 7.67 ms per tile with three tiles in flight).  TL_BLK_SIDE=0 / 1 forces either.
         main = torch.cuda.current_stream()
-        side = _side_stream(dev)
+        want_side = os.environ.get("TL_BLK_SIDE")
+        use_side = (main == torch.cuda.default_stream(dev)) if want_side is None else want_side != "0"
+        side = _side_stream(dev) if use_side else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             _hip.check(L.tl_blk_build(arr[0].bitmap, arr[0].prefix, _hip.dims4(levels[0].dims), n1, ctypes.byref(bk), b0 + 4 * bl["ws"], 2, _hip.stream()), "tl_blk_build")
     _hip.check(L.tl_rulebooks_build(arr, num_levels, b0 + 4 * o_m1, o_m1_end - o_m1, _hip.ptr(pcoords), N, b0 + 4 * o_v2p, st),
                "tl_rulebooks_build")
-    if blocked:
+    if blocked and side is not main:
+        # (no record_stream: the main stream waits for the side stream right here, before anything that could free or re-use the buffers
+        # is enqueued on it; recording would make the caching allocator hold every geometry block until an event query, i.e. allocate anew)
         main.wait_stream(side)
-        for t in (back, pyr):
-            t.record_stream(side)
     v2p = back[o_v2p:o_v2p + 2 * N].view(torch.int64)
     for li, lv in enumerate(levels):
         y = lay[li]
@@ -320,7 +327,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         lv = levels[0]
         lv.nbr_ref = lv.nbr
         lv.nbr = BlockedRulebook(n1, v("o2n", n1), v("perm", n1), v("cnew", 4 * n1).view(n1, 4), v("unit", 4 * n1).view(n1, 4), v("counter", 64),
-                                 v("halo", 32 * n1), v("lrb", 16 * n1).view(n1, 16), v("pmask", n1))
+                                 v("halo", 32 * n1), v("lrb", 9 * n1).view(n1, 9), v("pmask", n1))
     return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[pyr, back], blocked=blocked)
 
 
