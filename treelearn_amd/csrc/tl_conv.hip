@@ -339,6 +339,7 @@ extern int g_wgrad_dma, g_wgrad_dense_gx;         // tl_wgrad_dense.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
+static int g_direct_oh = 1;                       // ... and its gather-once form for the level-1 inverse conv
 static int g_blk = 1;                             // use the staged-unit kernel when the caller passes the block-local rulebook form
 #ifdef TL_DEV                                     // the window kernel lives in the developer build only (python -m treelearn_amd.build --dev)
 static int g_win = 0;                             // window kernel (opt-in, TL_CONV_WIN=1: measured at parity with the gather kernels): 1 = shapes with >= 64 channels, 2 = all, 0 = off
@@ -354,6 +355,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
   if (!strcmp(key, "blk")) { g_blk = (int)value; return TL_OK; }
+  if (!strcmp(key, "direct_oh")) { g_direct_oh = (int)value; return TL_OK; }
 #ifdef TL_DEV
   if (!strcmp(key, "win")) { g_win = (int)value; return TL_OK; }
   if (!strcmp(key, "win_rows")) { g_win_rows = (int)value; return TL_OK; }
@@ -467,6 +469,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
   {
+    if (p.one_hot && g_direct && g_direct_oh && a->K == 8 && a->Cin == 64 && a->Cout == 32 && !train) {   // level-1 inverse conv: weights resident, no barriers
+      const int rc = L_direct(p, TL_BF16, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
     if (p.one_hot && g_stream && a->K == 8) {                  // inverse convs: the stream kernel's gather-once form
       const int rc = L_stream(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;

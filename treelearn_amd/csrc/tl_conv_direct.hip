@@ -24,7 +24,9 @@ namespace {
 __device__ unsigned long long g_tmd[8];   // developer timing mode (ABL bit 16): cycles summed over waves per tile segment
 
 // TR: the training-mode epilogue (tl_conv_args.epi_mode) is compiled in; the inference instantiations (TR = false) carry none of it
-template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false>
+// OH: every output row has at most ONE valid table entry (inverse conv): that row is gathered once and routed to its tap by a per-lane
+// select (K gathers of which K - 1 fetch nothing otherwise); all K taps are still contracted, against zeros except one
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles, int walk) {
   constexpr bool TM = (ABL & 16) != 0;
   [[maybe_unused]] unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -148,6 +150,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
         }
       }
     };
+    if constexpr (OH) {
+      int mytap = -1, myidx = -1;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { if (idx[k] >= 0) { mytap = k; myidx = idx[k]; } }
+      u32x4 a1[UN][NJ];
+      const unsigned base1 = (unsigned)myidx * (unsigned)in_ld_b + lane_off;
+#pragma unroll
+      for (int c = 0; c < UN; ++c)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a1[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base1 + c * UB + j * 32), 0, 0));
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool mine = mytap == k;
+#pragma unroll
+        for (int c = 0; c < UN; ++c)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            u32x4 av;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = mine ? a1[c][j][q] : 0u;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const u32x4 bf = *reinterpret_cast<const u32x4*>(wl + ((k * UN + c) * COUT + nb * 32) * UB + (((2 * j + fh) ^ swz) * 16));
+              mma16<BF16>(acc[nb], av, bf);
+            }
+          }
+      }
+    } else {
     if constexpr (TM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     tick(0);                                           // 0: rulebook entries (behind the previous tile's stores: vmcnt is in-order)
     issue(0, a[0]);
@@ -182,6 +212,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
         }
       }
       tick(3);                                         // 3: LDS weight fragments + MFMAs
+    }
     }
 
     // epilogue (wave-private): acc -> LDS fp32 -> rows as 8-channel vectors
@@ -413,9 +444,9 @@ __global__ void __launch_bounds__(256) k_conv_ones27(ConvP p) {
 
 int g_direct_walk = 0;
 
-template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false>
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false>
 int launch(const ConvP& p, hipStream_t s) {
-  if constexpr (!TR && BF16 && ABL == 0) {
+  if constexpr (!TR && BF16 && ABL == 0 && !OH) {
     if (p.epi_mode != TL_EPI_NONE) return launch<BF16, K, NB, UN, G, WAVES, ABL, CT, true>(p, s);      // training-mode epilogue: its own instantiation
   } else if constexpr (!TR) {
     if (p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
@@ -427,7 +458,7 @@ int launch(const ConvP& p, hipStream_t s) {
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
@@ -436,7 +467,7 @@ int launch(const ConvP& p, hipStream_t s) {
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
+  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
   if (p.red_nparts) *p.red_nparts = grid;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
   }
@@ -474,6 +505,11 @@ int dispatch(const ConvP& p, hipStream_t s) {
 #ifdef TL_DEV
     if (p.ctab && g_direct_abl == 13 && nb == 1 && un == 1) return launch<true, 27, 1, 1, G, 16, 32, true>(p, s);   // rulebook words not requested ahead
 #endif
+  }
+  if constexpr (BF16 && K == 8) {
+    // inverse conv of level 1 (64 -> 32, one valid entry per row): the row gathered once, no per-tap barrier (the stream kernel's one-hot
+    // form took 0.171 ms for 0.38 GB of traffic: eight barrier steps per 256 rows)
+    if (p.one_hot && p.epi_mode == TL_EPI_NONE && nb == 1 && un == 2) return launch<true, 8, 1, 2, G, 16, 0, false, false, true>(p, s);
   }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \
