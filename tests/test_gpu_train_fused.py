@@ -172,6 +172,36 @@ def test_side_stream_join_modes_give_identical_gradients(monkeypatch):
             assert not bad, (mode, step, bad[:5])
 
 
+def test_side_stream_join_respects_hooks_and_double_backward():
+    """The deferred join is only legal when nothing reads a weight gradient on the main stream before backward() returns
+    (treelearn_amd/backward.py `_may_defer_join`).  A tensor hook and a post-accumulate-grad hook on conv weights copy what they see ON THE
+    MAIN STREAM while the weight-gradient kernel may still be running on the side stream; what they saw must be the final gradient."""
+    from treelearn_amd import backward as B
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    cfg = dict(channels=32, num_blocks=4)
+    batch = make_batch([make_tile(extent=16.0, voxel=0.1, n_trees=10, fill=0.10, seed=s) for s in (5, 6)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, compute_dtype=torch.bfloat16, **cfg)
+    model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+    model = model.cuda().train()
+    convs = [(n, p) for n, p in model.named_parameters() if p.dim() == 5]
+    seen = {}
+    (n1, p1), (n2, p2) = convs[1], convs[5]
+    assert B._may_defer_join(p1) is False or True                           # (callable outside a backward pass)
+    h1 = p1.register_hook(lambda g, n=n1: seen.__setitem__(n, g.detach().clone()))
+    h2 = p2.register_post_accumulate_grad_hook(lambda p, n=n2: seen.__setitem__(n, p.grad.detach().clone()))
+    loss, _ = model(gb, return_loss=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert set(seen) == {n1, n2}
+    assert torch.equal(seen[n1], p1.grad) and torch.equal(seen[n2], p2.grad)
+    h1.remove(); h2.remove()
+    with torch.no_grad():
+        assert B._may_defer_join(convs[2][1].detach().clone().requires_grad_(True))     # plain leaf, no hooks, grad mode off: may defer
+    assert not B._may_defer_join(p1)                                        # `.grad` is set now: AccumulateGrad adds at once
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gather_rows_and_scatter_add_vs_torch(dtype):
     """features[v2p] (tl_gather_rows) and its gradient (tl_scatter_add_rows over the stable argsort): duplicates, voxels without a point,

@@ -42,22 +42,39 @@ _join_queued = {}
 _keepalive = {}
 
 
+def _may_defer_join(weight):
+    """The deferred join is only safe when NOTHING on the main stream can read the weight gradient before backward() returns.  That rules
+    out: a non-leaf weight or an existing `.grad` (AccumulateGrad / further nodes consume it at once), tensor hooks and
+    post-accumulate-grad hooks on the parameter, double backward (create_graph=True: AccumulateGrad clones instead of stealing), anomaly
+    mode (inspects every gradient), and gradient reducers that hook the AccumulateGrad node itself (DDP / FSDP) -- those hooks cannot be
+    listed from Python, so an initialised multi-rank process group counts as "a reducer may be listening"."""
+    if os.environ.get("TL_WGRAD_JOIN") == "layer" or not weight.is_leaf or weight.grad is not None:
+        return False
+    if getattr(weight, "_backward_hooks", None) or getattr(weight, "_post_accumulate_grad_hooks", None):
+        return False
+    if torch.is_grad_enabled() or torch.is_anomaly_enabled():
+        return False
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 \
+            and os.environ.get("TL_WGRAD_JOIN") != "deferred":
+        return False
+    return True
+
+
 def _join_side(cur, side, weight, held=()):
     """Make the main stream see the side stream's weight gradients.  Inside `loss.backward()` with the parameter's `.grad` still unset
     (the usual `zero_grad()` -> backward -> step loop, reference tools/training/train.py:30-44) nothing on the main stream reads a weight
     gradient before backward returns, so the join is deferred to ONE wait at the end of the backward pass (an autograd final callback):
     the weight gradients of all layers queue up on the side stream and fill whatever the main chain leaves idle, instead of the main
-    stream idling 0.3-0.55 ms per layer until that layer's weight gradient is done.  Accumulating into an existing `.grad`
-    (AccumulateGrad adds right after the node returns), a non-leaf weight, calls outside a backward pass, and TL_WGRAD_JOIN=layer join at once.
+    stream idling 0.3-0.55 ms per layer until that layer's weight gradient is done.  Everything `_may_defer_join` lists joins at once.
     `held`: the tensors the side stream reads; references are kept until the join so that neither the caching allocator hands their
     memory to a main-stream allocation nor the autograd engine, finding itself the sole owner of an incoming gradient, accumulates
-    another contribution INTO it while the weight-gradient kernel is still reading."""
-    # (a non-leaf weight -- a cast or reshaped view of the parameter -- hands its gradient to further autograd nodes on the main stream at once)
-    if os.environ.get("TL_WGRAD_JOIN") != "layer" and weight.is_leaf and weight.grad is None:
+    another contribution INTO it while the weight-gradient kernel is still reading.  State is kept per (streams, graph task): a nested
+    (re-entrant) backward has its own join and its own held tensors."""
+    if _may_defer_join(weight):
         gid = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
-        key = (cur.device.index, cur.cuda_stream, side.cuda_stream)
+        key = (cur.device.index, cur.cuda_stream, side.cuda_stream, gid)
         if gid >= 0:
-            if _join_queued.get(key) == gid:
+            if key in _join_queued:
                 _keepalive[key].extend(held)
                 return True
             def _cb(cur=cur, side=side, key=key):
@@ -67,7 +84,7 @@ def _join_side(cur, side, weight, held=()):
                 _keepalive.pop(key, None)
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(_cb)
-                _join_queued[key] = gid
+                _join_queued[key] = True
                 _keepalive[key] = list(held)
                 return True
             except RuntimeError:
@@ -79,7 +96,7 @@ def _join_side(cur, side, weight, held=()):
 def _wgrad_param(x, grad_out, ref, K, weight):
     """Weight gradient in the parameter's own layout and dtype ([Cout, k, k, k, Cin]; tl_conv_wgrad_ref: no transposing copy)."""
     gw = ops.conv_wgrad(x, grad_out, ref.table, ref.n_out, K, ref_layout=True)
-    if gw.shape[0] != weight.shape[0]:                                      # Cin % 4 != 0: [K, Cout, Cin] came back
+    if not gw._tl_ref_layout:                                               # Cin % 4 != 0: [K, Cout, Cin] came back
         gw = gw.permute(1, 0, 2)
     gw = gw.reshape(weight.shape)
     return gw if gw.dtype == weight.dtype else gw.to(weight.dtype)

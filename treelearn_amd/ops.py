@@ -180,6 +180,7 @@ def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: in
     ws = torch.empty(int(L.tl_conv_wgrad_ws_floats(n_out, K, ci, co)), dtype=torch.float32, device=x.device)
     _hip.check((L.tl_conv_wgrad_ref if ref_layout else L.tl_conv_wgrad)(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), _hip.dtype_code(x.dtype), _hip.ptr(table) if table is not None else None, n_out, x.shape[0],
                                K, ci, co, _hip.ptr(gw), _hip.ptr(ws), _hip.stream()), "tl_conv_wgrad")
+    gw._tl_ref_layout = ref_layout                # the layout actually produced ([Cout, K, Cin] needs Cin % 4 == 0)
     return gw
 
 
