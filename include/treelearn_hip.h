@@ -169,6 +169,8 @@ typedef struct tl_blk {
   int64_t cap_units;        /* rows of `unit` (>= ceil(n / 64); n always suffices) */
   int32_t halo_max;         /* 26 .. TL_BLK_HALO_MAX */
   int32_t reserved;
+  int32_t* nn;              /* optional (NULL = not wanted): the rulebook as a plain table i32[27][n] in the NEW row order (entry = new input row or
+                             * -1) -- what the kernels without a staged form read (weight gradient, convs of other widths) */
 } tl_blk;
 int64_t tl_blk_ws_words(const int32_t dims[4]);
 /* phases: 1 = the order (o2n, perm, coords_new + the scratch the second phase reads), 2 = units / halo / lrb / pmask, 3 = both.  The

@@ -251,3 +251,81 @@ def test_forward_blocked_vs_oracle_bf16():
         ref = o[k].double().numpy()
         err = np.abs(a[k].numpy() - ref).max() / np.abs(ref).max()
         assert err < 5e-2, (k, err)
+
+
+# =============================================================================================== training on the block-local level
+def test_blk_conv_training_epilogues_equal_gather_kernel():
+    """The staged-unit kernel's training epilogues (tl_conv_args.epi_mode) against the gather kernel's on the same rulebook: TL_EPI_STATS
+    (with a residual) and TL_EPI_BN_BWD give the same stored tensor bit for bit and the same finished reductions (per-lane fp32 partial sums
+    here, per-tile there: 1e-5)."""
+    from treelearn_amd import ops
+    batch = _batch(14.0, [3])
+    can, blk = _geoms(batch)
+    n = can.levels[0].n
+    dev = can.v2p.device
+    r = blk.levels[0].nbr
+    perm, o2n = r.perm.long(), r.o2n.long()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = (torch.randn(n, 32, generator=g) * 0.7).bfloat16().to(dev)
+    res = torch.randn(n, 32, generator=g).bfloat16().to(dev)
+    w = ops.pack_weight((torch.randn(32, 3, 3, 3, 32, generator=g) * 0.08).to(dev), torch.bfloat16)
+    xb = torch.randn(n, 32, generator=g).bfloat16().to(dev)                               # the BatchNorm input of the BN_BWD mode
+    st = torch.stack([torch.randn(32, generator=g) * 0.1, torch.rand(32, generator=g) + 0.5, torch.rand(32, generator=g) + 0.5,
+                      torch.randn(32, generator=g) * 0.2]).to(dev).contiguous()            # mean, rstd, scale, shift
+    for epi_c, epi_b, kw_c, kw_b in (("stats", "stats", dict(residual=res), dict(residual=res[perm].contiguous())),
+                                     (("bn_bwd", xb, st, True), ("bn_bwd", xb[perm].contiguous(), st, True), {}, {})):
+        a = ops.conv_fwd(x, w, can.levels[0].nbr, n, epi=epi_c, **kw_c)
+        b = ops.conv_fwd(x[perm].contiguous(), w, r, n, epi=epi_b, **kw_b)
+        assert a is not None and b is not None
+        assert torch.equal(a[0], b[0][o2n]), epi_c if isinstance(epi_c, str) else epi_c[0]
+        sa = a[1][:a[2]].sum(0); sb = b[1][:b[2]].sum(0)                                    # [2, 32] fp64 totals
+        assert float((sa - sb).abs().max() / sa.abs().max()) < 1e-5
+
+
+def _train_grads(blocked, gb, dtype=torch.bfloat16):
+    from treelearn_amd.model import TreeLearn
+    old = os.environ.get("TL_BLK_TRAIN")
+    os.environ["TL_BLK_TRAIN"] = "1" if blocked else "0"
+    try:
+        m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=dtype)
+        m.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
+        m = m.cuda().train()
+        loss, ld = m(gb, return_loss=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().double().flatten() for n, p in m.named_parameters()}, \
+            m.output_layer[0].running_mean.detach().clone()
+    finally:
+        if old is None:
+            os.environ.pop("TL_BLK_TRAIN")
+        else:
+            os.environ["TL_BLK_TRAIN"] = old
+
+
+def test_training_step_on_the_block_local_level():
+    """A mixed-precision training step (two 16 m crops) with level 1 in the block-local order against the canonical-order step: same
+    loss (forward results are identical row for row; BatchNorm sums differ in summation order only), every gradient tensor at cosine
+    >= 0.999 of the canonical step's, running statistics equal to 1e-5."""
+    from treelearn_amd import ops
+    batch = make_batch([make_tile(extent=16.0, voxel=0.1, n_trees=10, fill=0.10, seed=s) for s in (5, 6)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    n0 = ops.BLK_LAUNCHES
+    lb, gbk, rmb = _train_grads(True, gb)
+    assert ops.BLK_LAUNCHES - n0 >= 16, ops.BLK_LAUNCHES - n0                              # level-1 forward and input-gradient convs
+    n0 = ops.BLK_LAUNCHES
+    lc, gc, rmc = _train_grads(False, gb)
+    assert ops.BLK_LAUNCHES == n0
+    assert lb == pytest.approx(lc, rel=1e-3)
+    assert float((rmb - rmc).abs().max()) < 1e-5 * float(rmc.abs().max()) + 1e-6
+    nmax = max(float(v.norm()) for v in gc.values())
+    worst = (1.0, None)
+    for nme, b in gc.items():
+        if float(b.norm()) <= 1e-5 * nmax:
+            continue
+        a = gbk[nme]
+        assert bool(torch.isfinite(a).all()), nme
+        cos = float(a @ b / (a.norm() * b.norm()))
+        worst = min(worst, (cos, nme))
+        assert abs(float(a.norm() / b.norm()) - 1) < 0.05, nme
+    print("blocked vs canonical training step: worst cosine", worst)
+    assert worst[0] >= 0.999, worst

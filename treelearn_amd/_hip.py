@@ -51,7 +51,7 @@ class Level(_c.Structure):                 # tl_level
 
 class Blk(_c.Structure):                   # tl_blk
     _fields_ = [("o2n", _vp), ("perm", _vp), ("coords_new", _vp), ("unit", _vp), ("counter", _vp), ("halo", _vp), ("lrb", _vp), ("pmask", _vp),
-                ("cap_units", _i64), ("halo_max", _i32), ("reserved", _i32)]
+                ("cap_units", _i64), ("halo_max", _i32), ("reserved", _i32), ("nn", _vp)]
 
 
 class HdbGrid(_c.Structure):               # TlHdbGrid

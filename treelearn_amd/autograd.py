@@ -34,6 +34,14 @@ FUSE_BN = os.environ.get("TL_TRAIN_FUSE", "1") != "0"      # conv-epilogue Batch
 # test hook: when set to a dict, every training-mode BatchNorm + ReLU served by the HIP kernels stores its ReLU decisions there
 # ({BatchNorm module: bool [rows, C] = output > 0}), so that a float64 reference can differentiate the same piecewise-linear function
 RELU_MASK_SINK = None
+# test hook, the other direction: {BatchNorm module: bool [rows, C]} -- the ReLU behind that BatchNorm takes the GIVEN branches instead of
+# deciding them from its own pre-activations (forward: affine without ReLU, times the mask; backward: the plain input-gradient conv, the
+# mask, tl_bn_train_bwd without ReLU).  Lets two runs of different precision differentiate the same piecewise-linear function.
+RELU_MASK_SOURCE = None
+
+
+def _forced_mask(bn, relu):
+    return RELU_MASK_SOURCE.get(bn) if (RELU_MASK_SOURCE is not None and relu) else None
 
 
 def _conv_with_stats(x, w_packed, ref, residual, holder):
@@ -182,12 +190,16 @@ class _BNReLUConvFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, weight, residual, bn, relu, ref, want_skip, stats_in, holder):
         x = x.contiguous()
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
-        a = ops.affine_relu(x, st[2], st[3], relu)
+        fm = _forced_mask(bn, relu)
+        if fm is not None:
+            a = ops.affine_relu(x, st[2], st[3], False) * fm.to(x.dtype)
+        else:
+            a = ops.affine_relu(x, st[2], st[3], relu)
         if RELU_MASK_SINK is not None and relu:
-            RELU_MASK_SINK[bn] = a > 0
+            RELU_MASK_SINK[bn] = fm if fm is not None else a > 0
         y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder)
         ctx.save_for_backward(x, a, st, weight)
-        ctx.ref, ctx.relu = ref, relu
+        ctx.ref, ctx.relu, ctx.fm = ref, relu, fm
         if want_skip:
             return y, x.view_as(x)
         return y
@@ -202,7 +214,11 @@ class _BNReLUConvFn(torch.autograd.Function):
         if gskip is not None and (gskip.dtype != x.dtype or gskip.stride(1) != 1 or gskip.stride(0) % 8 or gskip.data_ptr() % 16):
             gskip = gskip.to(x.dtype).contiguous()
         need_gw = ctx.needs_input_grad[3]
-        dx, dgamma, dbeta, gw = bw.bn_conv_backward(x, a, st, ctx.relu, weight, ctx.ref, gy, need_gw, gskip)
+        if ctx.fm is not None:                                   # test hook (RELU_MASK_SOURCE): the given ReLU branches
+            ga, gw = bw.conv_backward(a, weight, ctx.ref, gy, True, need_gw)
+            dx, dgamma, dbeta = ops.bn_train_bwd(x, ga * ctx.fm.to(ga.dtype), st, False, dx_add=gskip)
+        else:
+            dx, dgamma, dbeta, gw = bw.bn_conv_backward(x, a, st, ctx.relu, weight, ctx.ref, gy, need_gw, gskip)
         return dx, dgamma, dbeta, gw, (gy if ctx.needs_input_grad[4] else None), None, None, None, None, None, None
 
 
@@ -233,11 +249,15 @@ class _BNReLUTrainFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, bn, relu, skip, stats_in=None):
         x = x.contiguous()
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
-        y = ops.affine_relu(x, st[2], st[3], relu)
+        fm = _forced_mask(bn, relu)
+        if fm is not None:
+            y = ops.affine_relu(x, st[2], st[3], False) * fm.to(x.dtype)
+        else:
+            y = ops.affine_relu(x, st[2], st[3], relu)
         if RELU_MASK_SINK is not None and relu:
-            RELU_MASK_SINK[bn] = y > 0
+            RELU_MASK_SINK[bn] = fm if fm is not None else y > 0
         ctx.save_for_backward(x, st)
-        ctx.relu = relu
+        ctx.relu, ctx.fm = relu, fm
         if skip:
             return y, x.view_as(x)
         return y
@@ -251,7 +271,10 @@ class _BNReLUTrainFn(torch.autograd.Function):
             dy = dy.float()
         if dskip is not None and (dskip.dtype != x.dtype or dskip.stride(1) != 1 or dskip.stride(0) % 8 or dskip.data_ptr() % 16):
             dskip = dskip.to(x.dtype).contiguous()
-        dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu, dx_add=dskip)    # dx in x's dtype (bf16 stays bf16 under mixed precision)
+        if ctx.fm is not None:                                   # test hook (RELU_MASK_SOURCE)
+            dx, dgamma, dbeta = ops.bn_train_bwd(x, dy * ctx.fm.to(dy.dtype), st, False, dx_add=dskip)
+        else:
+            dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, ctx.relu, dx_add=dskip)    # dx in x's dtype (bf16 stays bf16 under mixed precision)
         return dx, dgamma, dbeta, None, None, None, None
 
 

@@ -15,6 +15,7 @@ import os
 import torch
 
 from . import ops
+from .geometry import BlockedRulebook
 
 
 class TableRef:
@@ -131,8 +132,8 @@ def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, g
     step = ci
     if ci > 224:
         step = 128 if ci % 128 == 0 else (96 if ci % 96 == 0 else 32)
-    elif K == 27 and ci == 2 * co and ci >= 128:
-        step = co
+    elif K == 27 and ci == 2 * co and (ci >= 128 or isinstance(ref.t_table, BlockedRulebook)):
+        step = co                              # (block-local level 1: the staged-unit kernel computes 32 output channels per launch)
     slices = [(s0, step) for s0 in range(0, ci, step)]
     wts = [wt] if len(slices) == 1 else [wt[:, s0:s0 + w_].contiguous() for s0, w_ in slices]
     res = None

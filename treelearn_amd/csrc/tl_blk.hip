@@ -158,7 +158,7 @@ struct BlkOut {
   const uint32_t* cs; int BZ;           // new row of the first voxel of every non-empty (column, z byte): [b][x][y][BZ]
   const int32_t* coords_new;
   int32_t* unit; int32_t* counter;      // counter[0] = number of units (pre-set to n_chunks), counter[1] = error flag
-  int32_t* halo; uint32_t* lrb; int32_t* pmask;
+  int32_t* halo; uint32_t* lrb; int32_t* pmask; int32_t* nn_out;
   int64_t n; int64_t nchunks; int64_t cap_units; int halo_max;
 };
 
@@ -235,7 +235,13 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
       if (p1[q]) { nn[3 * q + 1] = rowid(w1[q], z, (z >> 3) == bA ? sA[q] : b_); pm |= 2u << (3 * q); }
       if (p2[q]) { nn[3 * q + 2] = rowid(w2[q], z + 1, b_); pm |= 4u << (3 * q); }
     }
-    if (rvalid) p.pmask[r] = (int32_t)pm;
+    if (rvalid) {
+      p.pmask[r] = (int32_t)pm;
+      if (p.nn_out) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) p.nn_out[(int64_t)k * p.n + r] = nn[k];
+      }
+    }
   }
 
   // the hash table is sized to the chunk (load factor <= 0.7 even if every present neighbour were a distinct outside row)
@@ -451,7 +457,7 @@ int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t d
   }
   if (!(phases & 2)) { TL_CHECK_LAUNCH(); return TL_OK; }
   BlkOut p;
-  p.cs = cs; p.BZ = g.BZ; p.coords_new = o->coords_new; p.unit = o->unit; p.counter = o->counter; p.halo = o->halo; p.lrb = o->lrb; p.pmask = o->pmask;
+  p.cs = cs; p.BZ = g.BZ; p.coords_new = o->coords_new; p.unit = o->unit; p.counter = o->counter; p.halo = o->halo; p.lrb = o->lrb; p.pmask = o->pmask; p.nn_out = o->nn;
   p.n = n; p.nchunks = nchunks; p.cap_units = o->cap_units; p.halo_max = o->halo_max;
   k_blk_units<<<(unsigned)tl_cdiv(nchunks, kBlock / 64), kBlock, 0, s>>>(bitmap, d, p);
   TL_CHECK_LAUNCH();

@@ -431,7 +431,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     const int rc = L_ones27(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
-  if (has_blk && !train && dt == TL_BF16 && g_blk && vec_ok && out_vec && (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
+  if (has_blk && dt == TL_BF16 && g_blk && vec_ok && out_vec && (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 4 == 0 && ((uintptr_t)a->out_shift) % 4 == 0))) {
     const int rc = L_blk(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
@@ -469,7 +469,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0)))
   {
-    if (p.one_hot && g_direct && g_direct_oh && a->K == 8 && a->Cin == 64 && a->Cout == 32 && !train) {   // level-1 inverse conv: weights resident, no barriers
+    if (p.one_hot && g_direct && g_direct_oh && a->K == 8 && a->Cin == 64 && a->Cout == 32) {   // level-1 inverse conv: weights resident, no barriers
       const int rc = L_direct(p, TL_BF16, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }

@@ -37,7 +37,10 @@ constexpr int HCH = 8;                        // halo chunks of 16 rows (TL_BLK_
 struct RbRow { u32x4 a, b; uint32_t c; };     // one row of the local rulebook
 static __device__ __forceinline__ uint32_t rb_word(const RbRow& r, int w) { return w < 4 ? r.a[w] : (w < 8 ? r.b[w - 4] : r.c); }
 
-template <int W, bool RES, int NV>
+// TR: the training-mode epilogue (tl_conv_args.epi_mode: TL_EPI_STATS / TL_EPI_BN_BWD; one view, residual through the shared row-vector
+// helper of tl_conv_internal.h): every lane sums its row vectors' summands over all of its wave's units in fp32, the waves' totals
+// are combined in fp64 -> one partial row per workgroup, in the format of the other kernel families
+template <int W, bool RES, int NV, bool TR = false>
 __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,11 +51,16 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
       const int s_ = v & 3, n = (v >> 2) & 31, k = v >> 7;
       *reinterpret_cast<u32x4*>(smem + (k * 32 + n) * 64 + ((s_ ^ ((n >> 2) & 3)) * 16)) = wsrc[v];
     }
-    float* aff = reinterpret_cast<float*>(smem + WS_B);                   // [view][scale | shift][32]
+    float* aff = reinterpret_cast<float*>(smem + WS_B);                   // [view][scale | shift][32]; training: [mean | rstd | scale | shift][32]
     for (int e = tid; e < 3 * 64; e += W * 64) {
       const int v = e >> 6, c = e & 31, sh = (e >> 5) & 1;
       const float* src = v == 0 ? (sh ? p.out_shift : p.out_scale) : v == 1 ? (sh ? p.out2_shift : p.out2_scale) : (sh ? p.out3_shift : p.out3_scale);
-      aff[e] = src ? src[c] : (sh ? 0.f : 1.f);
+      if constexpr (TR) {
+        const float* bsrc[4] = {p.bn_mean, p.bn_rstd, p.bn_scale, p.bn_shift};
+        if (e < 128) aff[e] = (p.epi_mode == TL_EPI_BN_BWD) ? bsrc[e >> 5][c] : 0.f;
+      } else {
+        aff[e] = src ? src[c] : (sh ? 0.f : 1.f);
+      }
     }
   }
   char* stage = smem + WS_B + AFF_B + wv * STAGE_B;
@@ -75,6 +83,11 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
   const unsigned res_ldb = (unsigned)(p.res_ld * 2);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rr =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(RES ? p.res : p.in), 0, RES ? (int)((p.n_out - 1) * (int64_t)res_ldb + 64) : 0, 0x00020000);
+  const bool bnb = TR && p.epi_mode == TL_EPI_BN_BWD;
+  const bool tr_loads = TR && (bnb || p.res != nullptr);
+  const unsigned tr_ldb = (unsigned)((bnb ? p.bn_x_ld : p.res_ld) * 2);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rtr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tr_loads ? (bnb ? p.bn_x : p.res) : p.in), 0, tr_loads ? (int)((p.n_out - 1) * (int64_t)tr_ldb + 64) : 0, 0x00020000);
   const bool aff_on[3] = {p.out_scale != nullptr, p.out2_scale != nullptr, p.out3_scale != nullptr};
   const bool relu_on[3] = {p.out_relu != 0, p.out2_relu != 0, p.out3_relu != 0};
 
@@ -145,6 +158,7 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
     for (int c = 0; c < HCH; ++c) { TL_KEEP(h0[c]); TL_KEEP(hn[c]); }
     stage_unit(dc, h0);
   }
+  [[maybe_unused]] float ts0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ts1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool firstu = true;
   for (int u = u0; u < uhi; u += nw) {
     const int row0 = dc.x, nown = dc.y;
@@ -210,6 +224,16 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rres[it]) : "v"(off), "s"(rr));
       }
     }
+    if constexpr (TR) {                                                              // training: the residual, or the BatchNorm input of TL_EPI_BN_BWD
+      if (tr_loads) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rr_ = (lane >> 2) + 16 * it;
+          const unsigned off = rr_ < nown ? (unsigned)(row0 + rr_) * tr_ldb + (unsigned)((lane & 3) * 16) : 0xFFFFFFFFu;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rres[it]) : "v"(off), "s"(rtr));
+        }
+      }
+    }
     float* ew = reinterpret_cast<float*>(stage);                                    // 64 rows x 36 floats over the dead stage
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -243,6 +267,56 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
         for (int q = 0; q < 4; ++q) { y[it][2 * q] += bf16_lo(rres[it][q]); y[it][2 * q + 1] += bf16_hi(rres[it][q]); }
       }
     }
+    if constexpr (TR) {
+      // training (the arithmetic of tl_conv_internal.h's epi_views8_red, so that the stored tensor equals the gather kernels' bit for bit):
+      //   TL_EPI_STATS : v = bf16(y + residual);                      summands v, v^2
+      //   TL_EPI_BN_BWD: v = [x * scale + shift > 0] ? bf16(y) : 0;    summands v, v * (x - mean) * rstd
+      float pm[8], pr[8], ps[8], ph[8];
+      if (bnb) {
+        const u32x4 m0 = lds_r128(aff_a), m1 = lds_r128(aff_a + 16), r0_ = lds_r128(aff_a + 128), r1_ = lds_r128(aff_a + 144);
+        const u32x4 s0_ = lds_r128(aff_a + 256), s1_ = lds_r128(aff_a + 272), h0_ = lds_r128(aff_a + 384), h1_ = lds_r128(aff_a + 400);
+        TL_LGKM(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          pm[q] = __uint_as_float(m0[q]); pm[q + 4] = __uint_as_float(m1[q]); pr[q] = __uint_as_float(r0_[q]); pr[q + 4] = __uint_as_float(r1_[q]);
+          ps[q] = __uint_as_float(s0_[q]); ps[q + 4] = __uint_as_float(s1_[q]); ph[q] = __uint_as_float(h0_[q]); ph[q + 4] = __uint_as_float(h1_[q]);
+        }
+      }
+      if (tr_loads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      u32x4 o[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rr_ = (lane >> 2) + 16 * it;
+        float xv[8];
+        if (tr_loads) {
+          TL_KEEP(rres[it]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { xv[2 * q] = bf16_lo(rres[it][q]); xv[2 * q + 1] = bf16_hi(rres[it][q]); }
+        }
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (bnb) {
+            const bool keep = !p.bn_relu || fmaf(xv[q], ps[q], ph[q]) > 0.f;
+            v[q] = keep ? round_to(y[it][q], true) : 0.f;
+          } else {
+            v[q] = round_to(tr_loads ? y[it][q] + xv[q] : y[it][q], true);
+          }
+        }
+        if (rr_ < nown) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { ts0[q] += v[q]; ts1[q] += bnb ? v[q] * ((xv[q] - pm[q]) * pr[q]) : v[q] * v[q]; }
+        }
+        o[it] = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      }
+      stage_unit(d1, hcur);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rr_ = (lane >> 2) + 16 * it;
+        const unsigned off = rr_ < nown ? (unsigned)(row0 + rr_) * o_ldb[0] + (unsigned)((lane & 3) * 16) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o[it]), ro[0], (int)off, 0, 0);
+      }
+    } else {
     // the stage is free (the results are in registers): the next unit's staging goes out BEFORE this unit's stores
     stage_unit(d1, hcur);
 #pragma unroll
@@ -277,21 +351,44 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ro[v], (int)off, 0, 0);
       }
     }
+    }
     dc = d1; d1 = d2; d2 = desc_fin(d3r, u + 3 * nw);
+  }
+  if constexpr (TR) {
+    // lanes l, l + 4, ... hold the same eight channels: add them (fp64), then the waves in wave order -> the workgroup's partial row
+    double* Ds = reinterpret_cast<double*>(smem + WS_B + AFF_B + W * STAGE_B);           // [W][2][32]
+    double d0[8], d1_[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { d0[q] = (double)ts0[q]; d1_[q] = (double)ts1[q]; }
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { d0[q] += __shfl_xor(d0[q], off, 64); d1_[q] += __shfl_xor(d1_[q], off, 64); }
+    if (lane < 4) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { Ds[(wv * 2 + 0) * 32 + lane * 8 + q] = d0[q]; Ds[(wv * 2 + 1) * 32 + lane * 8 + q] = d1_[q]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double t = 0.0;
+      for (int w = 0; w < W; ++w) t += Ds[(w * 2 + (tid >> 5)) * 32 + (tid & 31)];
+      p.red_part[(int64_t)blockIdx.x * 64 + tid] = t;
+    }
   }
 }
 
-template <int W, bool RES, int NV>
+template <int W, bool RES, int NV, bool TR = false>
 int launch_blk(const ConvP& p, hipStream_t s) {
-  constexpr size_t lds = (size_t)WS_B + AFF_B + (size_t)W * STAGE_B;
+  constexpr size_t lds = (size_t)WS_B + AFF_B + (size_t)W * STAGE_B + (TR ? (size_t)W * 2 * 32 * 8 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
-  k_conv_blk<W, RES, NV><<<256, W * 64, lds, s>>>(p);
+  k_conv_blk<W, RES, NV, TR><<<256, W * 64, lds, s>>>(p);
+  if (TR && p.red_nparts) *p.red_nparts = 256;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -301,11 +398,19 @@ int launch_blk(const ConvP& p, hipStream_t s) {
 // training epilogue.  Every view 16-B aligned with a row stride that is a multiple of 8 elements; buffers below 4 GB.
 int tl_launch_conv_blk(const ConvP& p, hipStream_t s) {
   if (!p.blk_unit || !p.blk_counter || !p.blk_halo || !p.blk_lrb) return TL_ERR_UNSUPPORTED;
-  if (p.K != 27 || p.Cin != 32 || p.Cout != 32 || p.in_scale || p.in_relu || p.epi_mode != TL_EPI_NONE || p.n_in != p.n_out) return TL_ERR_UNSUPPORTED;
+  if (p.K != 27 || p.Cin != 32 || p.Cout != 32 || p.in_scale || p.in_relu || p.n_in != p.n_out) return TL_ERR_UNSUPPORTED;
   if (p.n_out >= (1 << 25)) return TL_ERR_UNSUPPORTED;
   auto big = [&](int64_t ld) { return (p.n_out - 1) * ld * 2 + 64 >= 0x7FFFFFFFll * 2; };
   if (big(p.in_ld) || big(p.out_ld) || (p.out2 && big(p.out2_ld)) || (p.out3 && big(p.out3_ld)) || (p.res && big(p.res_ld))) return TL_ERR_UNSUPPORTED;
   if (p.out3 && !p.out2) return TL_ERR_UNSUPPORTED;
+  if (p.epi_mode != TL_EPI_NONE) {
+#ifdef TL_F16_BUILD
+    return TL_ERR_UNSUPPORTED;                                   // the training epilogues are bf16
+#else
+    if (p.out2 || p.out_scale || p.out_relu || p.out_ld % 8 || ((uintptr_t)p.out) % 16) return TL_ERR_UNSUPPORTED;
+    return launch_blk<8, false, 1, true>(p, s);                   // (a residual goes through the shared row stage)
+#endif
+  }
   const int nv = p.out3 ? 3 : p.out2 ? 2 : 1;
   if (p.res) {
     switch (nv) {

@@ -446,8 +446,8 @@ int g_direct_walk = 0;
 
 template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false>
 int launch(const ConvP& p, hipStream_t s) {
-  if constexpr (!TR && BF16 && ABL == 0 && !OH) {
-    if (p.epi_mode != TL_EPI_NONE) return launch<BF16, K, NB, UN, G, WAVES, ABL, CT, true>(p, s);      // training-mode epilogue: its own instantiation
+  if constexpr (!TR && BF16 && ABL == 0) {
+    if (p.epi_mode != TL_EPI_NONE) return launch<BF16, K, NB, UN, G, WAVES, ABL, CT, true, OH>(p, s);  // training-mode epilogue: its own instantiation
   } else if constexpr (!TR) {
     if (p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
   }
@@ -509,7 +509,7 @@ int dispatch(const ConvP& p, hipStream_t s) {
   if constexpr (BF16 && K == 8) {
     // inverse conv of level 1 (64 -> 32, one valid entry per row): the row gathered once, no per-tap barrier (the stream kernel's one-hot
     // form took 0.171 ms for 0.38 GB of traffic: eight barrier steps per 256 rows)
-    if (p.one_hot && p.epi_mode == TL_EPI_NONE && nb == 1 && un == 2) return launch<true, 8, 1, 2, G, 16, 0, false, false, true>(p, s);
+    if (p.one_hot && nb == 1 && un == 2) return launch<true, 8, 1, 2, G, 16, 0, false, false, true>(p, s);
   }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \

@@ -28,9 +28,10 @@ class BlockedRulebook:
     that holds or is indexed by rows of the level -- features, `child` entries, `inv` / `parent`, `v2p` -- is then in the NEW order."""
     K = 27
 
-    def __init__(self, n, o2n, perm, coords_new, unit, counter, halo, lrb, pmask):
+    def __init__(self, n, o2n, perm, coords_new, unit, counter, halo, lrb, pmask, nn_table=None):
         self.n, self.o2n, self.perm, self.coords_new = n, o2n, perm, coords_new
         self.unit, self.counter, self.halo, self.lrb, self.pmask = unit, counter, halo, lrb, pmask
+        self.nn_table = nn_table            # optional i32[27, n]: the plain table in the new row order (training: weight gradients, other widths)
         self.shape = (27, n)
 
     def count_pairs(self):
@@ -62,7 +63,7 @@ class BlockedRulebook:
         return out.t().contiguous().int()
 
     def tensors(self):
-        return [self.o2n, self.perm, self.coords_new, self.unit, self.counter, self.halo, self.lrb, self.pmask]
+        return [t for t in (self.o2n, self.perm, self.coords_new, self.unit, self.counter, self.halo, self.lrb, self.pmask, self.nn_table) if t is not None]
 
 
 @dataclass
@@ -78,6 +79,10 @@ class Level:
     child: torch.Tensor = None      # i32[8,n_next]  spconv{l} (down)
     parent: torch.Tensor = None     # i32[n]
     inv: torch.Tensor = None        # i32[8,n]    spconv{l} (inverse)
+
+    def row_coords(self):
+        """(b, x, y, z) of the level's rows in the order its feature matrices use (the block-local order when the level is blocked)."""
+        return self.nbr.coords_new if isinstance(self.nbr, BlockedRulebook) else self.coords
 
 
 @dataclass
@@ -185,10 +190,12 @@ def _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_lev
 
 def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: int, voxel_size: float,
                    num_levels: int, spatial_shape: Optional[List[int]] = None, need_inverse: bool = True,
-                   blocked: bool = False, ref_table: bool = False, blk_min_rows: int = None) -> TileGeometry:
+                   blocked: bool = False, ref_table: bool = False, blk_min_rows: int = None, nn_table: bool = False) -> TileGeometry:
     """`blocked`: put level 1 into the block-local row order (BlockedRulebook) when it has BLK_MIN_ROWS..BLK_MAX_ROWS voxels -- the form
     the inference engine's level-1 convs run on; the canonical level-1 table is then only built on request (`ref_table`).  Default:
-    every level in the canonical order of SURVEY.md Appendix F (what the bit-exact rulebook tests pin and the training path uses)."""
+    every level in the canonical order of SURVEY.md Appendix F (what the bit-exact rulebook tests pin).  `nn_table`: a blocked level
+    also gets its rulebook as a plain table in the NEW row order (BlockedRulebook.nn_table: the training path's weight gradients and the
+    convs the staged-unit kernel does not serve read it)."""
     L = _hip.lib()
     st = _hip.stream()
     _hip.require_cuda(coords, "coords"); _hip.require_cuda(batch_ids, "batch_ids")
@@ -266,7 +273,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         # unit array can hold one unit per row: worst cases that never occur, reserved but not touched
         nblk_ws = int(L.tl_blk_ws_words(_hip.dims4(dims[0])))
         bl = dict(o2n=take(n1), perm=take(n1), cnew=take(4 * n1), unit=take(4 * n1), counter=take(64), halo=take(32 * n1), lrb=take(9 * n1),
-                  pmask=take(n1), ws=take(nblk_ws))
+                  pmask=take(n1), ws=take(nblk_ws), nn=take(27 * n1) if nn_table else None)
     o_m1 = cur                                              # parent / inv of all levels: contiguous, one fill with -1
     for li, lv in enumerate(levels[:-1]):
         lay[li]["parent"] = take(lv.n); lay[li]["inv"] = take(8 * lv.n)
@@ -289,6 +296,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         bk.o2n = b0 + 4 * bl["o2n"]; bk.perm = b0 + 4 * bl["perm"]; bk.coords_new = b0 + 4 * bl["cnew"]; bk.unit = b0 + 4 * bl["unit"]
         bk.counter = b0 + 4 * bl["counter"]; bk.halo = b0 + 4 * bl["halo"]; bk.lrb = b0 + 4 * bl["lrb"]; bk.pmask = b0 + 4 * bl["pmask"]
         bk.cap_units = n1; bk.halo_max = BLK_HALO_MAX; bk.reserved = 0
+        bk.nn = b0 + 4 * bl["nn"] if bl["nn"] is not None else None
         _hip.check(L.tl_blk_build(arr[0].bitmap, arr[0].prefix, _hip.dims4(levels[0].dims), n1, ctypes.byref(bk), b0 + 4 * bl["ws"], 1, st), "tl_blk_build")
         arr[0].o2n = bk.o2n
         # The unit builder (instruction-bound, ~0.27 ms) runs on a side stream beside the rulebook kernels of the other levels -- when the
@@ -327,7 +335,8 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         lv = levels[0]
         lv.nbr_ref = lv.nbr
         lv.nbr = BlockedRulebook(n1, v("o2n", n1), v("perm", n1), v("cnew", 4 * n1).view(n1, 4), v("unit", 4 * n1).view(n1, 4), v("counter", 64),
-                                 v("halo", 32 * n1), v("lrb", 9 * n1).view(n1, 9), v("pmask", n1))
+                                 v("halo", 32 * n1), v("lrb", 9 * n1).view(n1, 9), v("pmask", n1),
+                                 nn_table=v("nn", 27 * n1).view(27, n1) if bl["nn"] is not None else None)
     return TileGeometry(levels=levels, v2p=v2p, n_points=N, batch_size=batch_size, pcoords=pcoords, _backing=[pyr, back], blocked=blocked)
 
 

@@ -109,13 +109,14 @@ class TreeLearn(nn.Module):
             output = self.get_loss(model_output=output, **batch)
         return output
 
-    def _voxelize(self, coords, input_feats, batch_ids, batch_size, blocked=False):
+    def _voxelize(self, coords, input_feats, batch_ids, batch_size, blocked=False, nn_table=False):
         """`voxelize` of tree_learn.py:129-167 on the HIP library: geometry + voxel features
         ([M, dim_feat+dim_coord] in (feat, x, y, z) order; ones unless use_feats/use_coords).  `blocked`: level 1 in the block-local row
         order of the fused inference engine (geometry.BlockedRulebook); the voxel features stay in canonical order (the engine's input
         conv carries them over)."""
         geom = G.build_geometry(coords.contiguous(), batch_ids.contiguous(), int(batch_size), self.voxel_size,
-                                self.num_blocks, self.spatial_shape, blocked=blocked, ref_table=self.use_coords or self.use_feats)
+                                self.num_blocks, self.spatial_shape, blocked=blocked, ref_table=(self.use_coords or self.use_feats) and not nn_table,
+                                nn_table=nn_table)
         M = geom.levels[0].n
         C = coords.shape[1] + input_feats.shape[1]
         if self.use_coords or self.use_feats:
@@ -153,12 +154,16 @@ class TreeLearn(nn.Module):
         fused = not (self.training or torch.is_grad_enabled())
         if fused and (self._plan is None or self._plan.dtype != dtype):
             self._plan = InferencePlan(self, dtype)
+        # training under mixed precision: level 1 in the block-local order too (the staged-unit kernel serves its 32 -> 32 forward and
+        # input-gradient convs; weight gradients and the other widths read the plain table in the new order, BlockedRulebook.nn_table)
+        blk_train = (not fused and dtype == torch.bfloat16 and self.unet.nPlanes[0] == 32 and os.environ.get("TL_BLK", "1") != "0"
+                     and os.environ.get("TL_BLK_TRAIN", "1") != "0")
         vfeats, geom = self._voxelize(coords.float(), input_feats.float(), batch_ids.long(), batch_size,
-                                      blocked=fused and self._plan.supports_blocked())
+                                      blocked=(fused and self._plan.supports_blocked()) or blk_train, nn_table=blk_train)
         if not fused:
             # module-by-module path (batch-statistics BatchNorm, autograd through the HIP convs)
             lv = geom.levels[0]
-            x = spconv.SparseConvTensor(vfeats, lv.coords, list(lv.shape), batch_size, geometry=geom, level=0)
+            x = spconv.SparseConvTensor(vfeats, lv.row_coords(), list(lv.shape), batch_size, geometry=geom, level=0)
             prev = spconv.SparseConvolution.amp_dtype
             spconv.SparseConvolution.amp_dtype = None if dtype == torch.float32 else dtype
             if torch.is_grad_enabled() and os.environ.get("TL_PACK_BATCH", "1") != "0":

@@ -11,6 +11,7 @@ from .geometry import BlockedRulebook
 # When set to a list, every conv_fwd launch is bracketed by HIP events on the launch stream and
 # (start, end, meta) is appended -- bench.py's live per-kernel timing.  None = no overhead.
 PROFILE = None
+BLK_LAUNCHES = 0        # conv_fwd calls that carried the block-local rulebook form (a test / tool counter)
 
 HEAD_WIDTHS = (8, 16, 32, 64)      # backbone widths tl_head_mlp is instantiated for
 
@@ -92,7 +93,9 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.weight = w_packed.data_ptr()
     blk = table if isinstance(table, BlockedRulebook) else None
     if blk is not None:                          # rows in block-local order: units / halo lists / local rulebooks instead of the table
-        table = None
+        table = blk.nn_table                     # (the plain table in the new order, if the geometry carries one: shapes the staged-unit kernel does not serve)
+        global BLK_LAUNCHES
+        BLK_LAUNCHES += 1
         if x.shape[0] != n_out:
             raise ValueError("a block-local SubM conv maps the level onto itself")
         a.blk_unit = blk.unit.data_ptr(); a.blk_counter = blk.counter.data_ptr(); a.blk_halo = blk.halo.data_ptr()
@@ -174,6 +177,10 @@ def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: in
     ci, co = x.shape[1], g.shape[1]
     if g.shape[0] != n_out:
         raise ValueError(f"grad_out has {g.shape[0]} rows, the rulebook {n_out}")
+    if isinstance(table, BlockedRulebook):
+        if table.nn_table is None:
+            raise ValueError("the weight gradient over a block-local level needs the geometry's nn_table (build_geometry(nn_table=True))")
+        table = table.nn_table
     _check_table(table, K, n_out, x.device)
     ref_layout = bool(ref_layout) and ci % 4 == 0
     gw = torch.empty((co, K, ci) if ref_layout else (K, co, ci), dtype=torch.float32, device=x.device)

@@ -148,7 +148,7 @@ class SparseConvolution(SparseModule):
         if residual is not None and not fuse:
             feats = feats + residual.to(feats.dtype)
         lv = x.geometry.levels[out_level]
-        res = SparseConvTensor(feats, lv.coords, list(lv.shape), x.batch_size, x.geometry, out_level)
+        res = SparseConvTensor(feats, lv.row_coords(), list(lv.shape), x.batch_size, x.geometry, out_level)
         res.indice_dict = x.indice_dict
         res.grid = x.grid
         return res, skip
@@ -167,7 +167,7 @@ class SparseConvolution(SparseModule):
         if self.bias is not None:
             feats = feats + self.bias
         lv = x.geometry.levels[out_level]
-        out = SparseConvTensor(feats, lv.coords, list(lv.shape), x.batch_size, x.geometry, out_level)
+        out = SparseConvTensor(feats, lv.row_coords(), list(lv.shape), x.batch_size, x.geometry, out_level)
         out.indice_dict = x.indice_dict
         out.grid = x.grid
         return out
