@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts (treelearn_amd/__init__.py: streams of the tile loop + side streams)
+
 import numpy as np
 import torch
 
@@ -369,7 +371,7 @@ def main():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the config-3 training step and the config-5 tile that ride along in the default line")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 2.5 s rocm-smi power/clock sample (profiling runs)")
-    ap.add_argument("--tiles-in-flight", type=int, default=3, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
+    ap.add_argument("--tiles-in-flight", type=int, default=4, help="independent steps overlapped on this many streams (1 = strictly one after the other)")
     ap.add_argument("--layer-table", default=None, help="write the per-launch table of the conv event pass (time, work, both roofs) to this file")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"])
     ap.add_argument("--plot-tiles", type=int, default=64, help="config4: tiles of the plot")

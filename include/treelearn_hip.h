@@ -154,14 +154,14 @@ int tl_rulebooks_build(const tl_level* levels, int num_levels, int32_t* minus_on
  *   o2n / perm     i32[n]: canonical row -> new row and back;  coords_new i32[n][4] = (b,x,y,z) in the new order
  *   unit           i32[cap_units][4] = {first new row, rows (1..64), halo rows, 0}.  Chunk c = new rows [64 c, 64 c + 64) is unit c when
  *                  its halo has <= halo_max rows; otherwise it is halved (recursively) and the pieces after the first are appended
- *                  behind the ceil(n / 64) regular units in arrival order.  counter[0] (DEVICE) = number of units, counter[1] = error flag
+ *                  behind the ceil(n / 64) regular units, ascending by first row.  counter[0] (DEVICE) = number of units, counter[1] = error flag
  *   halo           i32[32 n]: the unit that starts at row r0 lists its DISTINCT outside rows ascending at halo + 32 r0, padded with -1
  *                  to a multiple of 16
  *   lrb            u32[n][9]: 27 ten-bit entries per row, tap k in word k / 3 at bits 10 (k % 3): entry = 4 * pos + ((pos >> 2) & 3), so that
  *                  entry * 16 is the byte offset of tap k's input row in the unit's stage (64-B rows, 16-B pieces XOR-swizzled), with
  *                  pos = own row index (0..63), 64 + halo rank, or 191 = absent (the stage's zero row)
  *   pmask          i32[n]: 27-bit presence mask of the row's taps
- * n < 2^25.  ws u32[tl_blk_ws_words(dims)].  Deterministic apart from the order of the appended units. */
+ * n < 2^25.  ws u32[tl_blk_ws_words(dims)] (16-B aligned).  Deterministic: the appended units are sorted by their first row. */
 #define TL_BLK_HALO_MAX 126
 typedef struct tl_blk {
   int32_t* o2n; int32_t* perm; int32_t* coords_new;

@@ -46,7 +46,7 @@ def build(coords, nbr, halo_max=HALO_MAX):
     """coords i32[n,4], nbr i32[27,n] (canonical) -> dict(perm, o2n, coords_new, pmask, nn (table in new rows, i64[27,n]),
     units = list of (row0, n_own, halo rows ascending), lrb u16[n,32]).  Units: chunk c = new rows [64c, 64c+64) is one unit if its
     distinct outside neighbours number <= halo_max, else it is halved recursively (left piece first); `units` lists the first piece
-    of every chunk at index c and all further pieces behind them in depth-first order."""
+    of every chunk at index c and all further pieces behind them, ascending by first row."""
     n = coords.shape[0]
     perm, o2n = block_order(coords)
     t = nbr[:, perm].astype(np.int64)
@@ -75,7 +75,7 @@ def build(coords, nbr, halo_max=HALO_MAX):
             else:
                 extra.append((lo, hi - lo, h))
             is_first = False
-    units = first + extra
+    units = first + sorted(extra, key=lambda u: u[0])
     ent = np.full((n, 27), entry(ZERO_POS), dtype=np.int64)
     for lo, cnt, h in units:
         v = nn[:, lo:lo + cnt].T                                              # [cnt, 27]
@@ -130,7 +130,7 @@ def build_fast(coords, nbr, halo_max=HALO_MAX):
             else:
                 extra.append((a, e - a, h))
             is_first = False
-    units = first + extra
+    units = first + sorted(extra, key=lambda u: u[0])
     # local rulebook, vectorised over all rows: unit of every row, then position of every (row, tap)
     u_lo = np.array([u[0] for u in units]); u_cnt = np.array([u[1] for u in units])
     order = np.argsort(u_lo, kind="stable")

@@ -391,7 +391,13 @@ def test_config3_default_architecture_training_step_bf16_vs_float64(golden_dir):
     loss.backward()
     assert float(loss.detach()) == pytest.approx(float(g["train_loss"]), rel=3e-2)
     mod_name = {m: n for n, m in model.named_modules()}
-    masks = {mod_name[m]: v.cpu() for m, v in sink.items()}
+    # mixed-precision training keeps level 1 in the block-local row order: carry the level-1 masks back into the canonical order the
+    # oracle works in (mask_canonical[r] = mask_new[o2n[r]]); the heads' masks are per point
+    geom = model._last_geom
+    assert geom.blocked, "the golden batch is large enough for the block-local level-1 path"
+    o2n, n1 = geom.levels[0].nbr.o2n.long(), geom.levels[0].n
+    is_l1 = lambda name: not name.startswith(("semantic_linear", "offset_linear")) and ".u." not in name + "."     # noqa: E731
+    masks = {mod_name[m]: (v[o2n] if (is_l1(mod_name[m]) and v.shape[0] == n1) else v).cpu() for m, v in sink.items()}
     _, g64 = om.train_step_grads(random_state_dict(cfg["seed"], **cfg["cfg"]), {k: batch[k] for k in batch}, cfg["voxel_size"],
                                  cfg["cfg"]["num_blocks"], cfg["spatial_shape"], relu_masks=masks)
     P = dict(model.named_parameters())

@@ -1,11 +1,12 @@
-# same-box A/B of the forward: TL_BLK=0 | TL_BLK=1 (unit builder on the main stream) | TL_BLK=1 + side stream; 3 tiles in flight and 1
+# same-box A/B of the forward: TL_BLK=0 | TL_BLK=1 with the unit builder's side stream forced off / on / automatic; 3 tiles in flight and 1
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-ab}; mkdir -p $O
 Q="--no-cpu-baseline --no-fp32-mode --no-power-probe --no-extra-workloads"
 for rep in 1 2; do
-for cfg in "0 1" "1 0" "1 1"; do
+for cfg in "0 0" "1 0" "1 1" "1 auto"; do
   set -- $cfg
-  TL_BLK=$1 TL_BLK_SIDE=$2 python bench.py $Q > $O/b_$1$2_$rep.json 2>/dev/null
+  if [ "$2" = "auto" ]; then unset TL_BLK_SIDE; else export TL_BLK_SIDE=$2; fi
+  TL_BLK=$1 python bench.py $Q > $O/b_$1$2_$rep.json 2>/dev/null
   python - <<PY
 import json
 d=json.loads(open("$O/b_$1$2_$rep.json").read().strip().splitlines()[-1])

@@ -17,7 +17,7 @@
 //   pmask : 27-bit presence mask per (new) row.
 //
 // Integer / bit work on the occupancy bitmap + popcount prefix of tl_voxel.hip; no MFMA.  Everything is a pure function of the
-// bitmap (deterministic, no atomics) except the ORDER of the appended units, which follows an atomic counter.
+// bitmap: deterministic (the appended units are claimed through an atomic counter and then sorted by their first row).
 #include "tl_common.h"
 
 namespace {
@@ -193,47 +193,61 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     const bool hz0 = z > 0, hz2 = z + 1 < d.Z;
     const int bA = (hz0 ? z - 1 : z) >> 3, bB = (hz2 ? z + 1 : z) >> 3;
     const bool x0 = hz0 && ((z - 1) >> 6) != (z >> 6), x2 = hz2 && ((z + 1) >> 6) != (z >> 6);     // dz = -1 / +1 lies in the next word
-    bool inb[9]; int64_t wc[9], ci[9];
-    uint64_t w1[9], w0[9], w2[9];
+    // column (x + dx, y + dy) = the lane's own column + a WAVE-UNIFORM offset (scalar registers); a column outside the grid reads the
+    // lane's own column instead (always valid) and is masked afterwards
+    const int64_t wc0 = rvalid ? tl_col_word(d, c.x, c.y, c.z) : 0;
+    const int64_t ci0 = rvalid ? (((int64_t)c.x * d.X + c.y) * d.Y + c.z) * p.BZ : 0;
+    const bool xin[3] = {rvalid && c.y > 0, rvalid, rvalid && c.y + 1 < d.X}, yin[3] = {c.z > 0, true, c.z + 1 < d.Y};
+    const int zw1 = rvalid ? (z >> 6) : 0, zw0 = (rvalid && x0) ? ((z - 1) >> 6) : zw1, zw2 = (rvalid && x2) ? ((z + 1) >> 6) : zw1;
+    bool inb[9];
+    uint64_t w1[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const int x = c.y + q / 3 - 1, y = c.z + q % 3 - 1;
-      inb[q] = rvalid && x >= 0 && x < d.X && y >= 0 && y < d.Y;
-      wc[q] = inb[q] ? tl_col_word(d, c.x, x, y) : 0;
-      ci[q] = inb[q] ? (((int64_t)c.x * d.X + x) * d.Y + y) * p.BZ : 0;
-      w1[q] = bm[wc[q] + (inb[q] ? (z >> 6) : 0)];
-      w0[q] = 0; w2[q] = 0;
+      const int dx = q / 3 - 1, dy = q % 3 - 1;
+      inb[q] = xin[q / 3] && yin[q % 3];
+      w1[q] = bm[wc0 + (inb[q] ? (dx * d.Y + dy) * d.Zw : 0) + zw1];                      // (the offset is wave-uniform)
     }
-    if (__any(x0 || x2)) {                                   // rare (z on a 64-cell boundary): a second batch
+    // the bytes that hold z - 1, z, z + 1 of every column, packed (bits 0-7, 8-15, 16-23); the 64-bit words go away
+    uint32_t by3[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const uint32_t b1 = (uint32_t)(w1[q] >> (z & 56)) & 0xFFu;
+      const uint32_t b0 = (uint32_t)(w1[q] >> ((hz0 ? z - 1 : z) & 56)) & 0xFFu, b2 = (uint32_t)(w1[q] >> ((hz2 ? z + 1 : z) & 56)) & 0xFFu;
+      by3[q] = b0 | (b1 << 8) | (b2 << 16);
+    }
+    if (__any(x0 || x2)) {                                   // rare (z on a 64-cell boundary): dz = -1 / +1 lies in the neighbouring word
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        w0[q] = bm[wc[q] + ((inb[q] && x0) ? ((z - 1) >> 6) : 0)];
-        w2[q] = bm[wc[q] + ((inb[q] && x2) ? ((z + 1) >> 6) : 0)];
+        const int dx = q / 3 - 1, dy = q % 3 - 1;
+        const int64_t wcq = wc0 + (inb[q] ? (dx * d.Y + dy) * d.Zw : 0);
+        const uint64_t a0 = bm[wcq + zw0], a2 = bm[wcq + zw2];
+        if (x0) by3[q] = (by3[q] & ~0xFFu) | ((uint32_t)(a0 >> ((z - 1) & 56)) & 0xFFu);
+        if (x2) by3[q] = (by3[q] & ~0xFF0000u) | (((uint32_t)(a2 >> ((z + 1) & 56)) & 0xFFu) << 16);
       }
     }
     bool p0[9], p1[9], p2[9];
     uint32_t sA[9], sB[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      const uint64_t a0 = x0 ? w0[q] : w1[q], a2 = x2 ? w2[q] : w1[q];
-      w0[q] = a0; w2[q] = a2;
-      p0[q] = inb[q] && hz0 && ((a0 >> ((z - 1) & 63)) & 1ull);
-      p1[q] = inb[q] && ((w1[q] >> (z & 63)) & 1ull);
-      p2[q] = inb[q] && hz2 && ((a2 >> ((z + 1) & 63)) & 1ull);
+      const int dx = q / 3 - 1, dy = q % 3 - 1;
+      p0[q] = inb[q] && hz0 && ((by3[q] >> ((z - 1) & 7)) & 1u);
+      p1[q] = inb[q] && ((by3[q] >> (8 + (z & 7))) & 1u);
+      p2[q] = inb[q] && hz2 && ((by3[q] >> (16 + ((z + 1) & 7))) & 1u);
+      // (only where a cell is present: the starts of the ~80 % absent columns would each touch a cache line of their own)
       const bool any = p0[q] || p1[q] || p2[q];
-      sA[q] = p.cs[any ? ci[q] + bA : 0];
-      sB[q] = p.cs[(any && bB != bA) ? ci[q] + bB : 0];
+      const int64_t ciq = ci0 + (inb[q] ? (dx * d.Y + dy) * p.BZ : 0);
+      sA[q] = p.cs[any ? ciq + bA : 0];
+      sB[q] = p.cs[(any && bB != bA) ? ciq + bB : 0];
     }
-    auto rowid = [](uint64_t w, int zz, uint32_t start) __attribute__((always_inline)) {
-      const uint32_t byte = (uint32_t)(w >> (zz & 56)) & 0xFFu;
+    auto rowid = [](uint32_t byte, int zz, uint32_t start) __attribute__((always_inline)) {
       return (int)(start + __popc(byte & ((1u << (zz & 7)) - 1u)));
     };
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const uint32_t b_ = bB != bA ? sB[q] : sA[q];
-      if (p0[q]) { nn[3 * q] = rowid(w0[q], z - 1, sA[q]); pm |= 1u << (3 * q); }
-      if (p1[q]) { nn[3 * q + 1] = rowid(w1[q], z, (z >> 3) == bA ? sA[q] : b_); pm |= 2u << (3 * q); }
-      if (p2[q]) { nn[3 * q + 2] = rowid(w2[q], z + 1, b_); pm |= 4u << (3 * q); }
+      if (p0[q]) { nn[3 * q] = rowid(by3[q] & 0xFFu, z - 1, sA[q]); pm |= 1u << (3 * q); }
+      if (p1[q]) { nn[3 * q + 1] = rowid((by3[q] >> 8) & 0xFFu, z, (z >> 3) == bA ? sA[q] : b_); pm |= 2u << (3 * q); }
+      if (p2[q]) { nn[3 * q + 2] = rowid((by3[q] >> 16) & 0xFFu, z + 1, b_); pm |= 4u << (3 * q); }
     }
     if (rvalid) {
       p.pmask[r] = (int32_t)pm;
@@ -251,9 +265,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
   const int tshift = nref <= 360 ? 23 : (nref <= 720 ? 22 : 21);
   // slot of every neighbour (hoisted: the halving re-uses them); tab[TS] is a dummy slot that idle lanes read and write, so the passes
   // below need no exec-mask juggling per tap (the first version spent 1 700 scalar instructions per wave on that)
-  uint32_t sl[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) sl[k] = ((uint32_t)nn[k] * 2654435761u) >> tshift;
+  auto hs = [&](int v) __attribute__((always_inline)) { return ((uint32_t)v * 2654435761u) >> tshift; };      // (recomputed where used: 27 registers less)
 
   // depth-first halving of the chunk until every piece's halo fits
   int st_a[8], st_e[8];
@@ -276,13 +288,13 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
       const int v = nn[k];
       const bool out = inr && v >= 0 && (v < lo || v >= hi);
       outm |= out ? (1u << k) : 0u;
-      tab[out ? sl[k] : (uint32_t)TS] = (uint32_t)v;
+      tab[out ? hs(v) : (uint32_t)TS] = (uint32_t)v;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     uint32_t lost = 0;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
-      const uint32_t cur = tab[sl[k]];
+      const uint32_t cur = tab[hs(nn[k])];
       lost |= (((outm >> k) & 1u) && cur != (uint32_t)nn[k]) ? (1u << k) : 0u;
     }
     if (__any(lost != 0)) {
@@ -290,7 +302,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
       for (int k = 0; k < 27; ++k) {
         bool todo = (lost >> k) & 1u;
         if (__any(todo)) {
-          uint32_t s_ = sl[k];
+          uint32_t s_ = hs(nn[k]);
           while (__any(todo)) {
             if (todo) {
               s_ = (s_ + 1) & (uint32_t)(TS - 1);
@@ -377,7 +389,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
       uint32_t miss = 0;
       uint32_t cur[27];
 #pragma unroll
-      for (int k = 0; k < 27; ++k) cur[k] = tab[sl[k]];
+      for (int k = 0; k < 27; ++k) cur[k] = tab[hs(nn[k])];
 #pragma unroll
       for (int k = 0; k < 27; ++k) miss |= (((outm >> k) & 1u) && (cur[k] & KEYMASK) != (uint32_t)nn[k]) ? (1u << k) : 0u;
       if (__any(miss != 0)) {
@@ -385,7 +397,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
         for (int k = 0; k < 27; ++k) {
           bool todo = (miss >> k) & 1u;
           if (__any(todo)) {
-            uint32_t s_ = sl[k];
+            uint32_t s_ = hs(nn[k]);
             while (__any(todo)) {
               if (todo) {
                 s_ = (s_ + 1) & (uint32_t)(TS - 1);
@@ -413,6 +425,37 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     if (lane == 0) reinterpret_cast<int4*>(p.unit)[u] = make_int4(lo, e - a, H, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }
+}
+
+// The pieces appended behind the regular units arrive in the order of an atomic counter; rank them by their first row so that the unit
+// array -- and with it which wave works on which unit, i.e. the order in which the training epilogue's partial sums are formed -- is the
+// same from run to run.  Few entries (~1.5 % of the chunks): a rank sort through a scratch copy.
+// (scratch = the unused end of the unit array itself: cap_units >= n rows were reserved, nchunks + 2 m of them are needed here)
+__global__ void __launch_bounds__(kBlock) k_blk_tail_rank(int32_t* __restrict__ unit, const int32_t* __restrict__ counter, int nchunks, int64_t cap_units) {
+  __shared__ int keys[kBlock];
+  const int m = counter[0] - nchunks;
+  if (m <= 1 || (int64_t)nchunks + 2 * (int64_t)m > cap_units) return;
+  const int4* u = reinterpret_cast<const int4*>(unit) + nchunks;
+  int4* tmp = reinterpret_cast<int4*>(unit) + (cap_units - m);
+  for (int t0 = blockIdx.x * kBlock; t0 < m; t0 += gridDim.x * kBlock) {          // (uniform per workgroup: every thread reaches the barriers)
+    const int t = t0 + threadIdx.x;
+    const int4 me = t < m ? u[t] : make_int4(0, 0, 0, 0);
+    int rank = 0;
+    for (int j0 = 0; j0 < m; j0 += kBlock) {
+      keys[threadIdx.x] = j0 + (int)threadIdx.x < m ? u[j0 + threadIdx.x].x : 0x7FFFFFFF;
+      __syncthreads();
+      const int lim = m - j0 < kBlock ? m - j0 : kBlock;
+      for (int j = 0; j < lim; ++j) rank += keys[j] < me.x ? 1 : 0;
+      __syncthreads();
+    }
+    if (t < m) tmp[rank] = me;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_blk_tail_copy(int32_t* __restrict__ unit, const int32_t* __restrict__ counter, int nchunks, int64_t cap_units) {
+  const int m = counter[0] - nchunks;
+  if (m <= 1 || (int64_t)nchunks + 2 * (int64_t)m > cap_units) return;
+  const int4* tmp = reinterpret_cast<const int4*>(unit) + (cap_units - m);
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < m; t += gridDim.x * kBlock) reinterpret_cast<int4*>(unit)[nchunks + t] = tmp[t];
 }
 
 __global__ void k_blk_init(int32_t* counter, int32_t nchunks) {
@@ -460,6 +503,8 @@ int tl_blk_build(const uint64_t* bitmap, const uint32_t* prefix, const int32_t d
   p.cs = cs; p.BZ = g.BZ; p.coords_new = o->coords_new; p.unit = o->unit; p.counter = o->counter; p.halo = o->halo; p.lrb = o->lrb; p.pmask = o->pmask; p.nn_out = o->nn;
   p.n = n; p.nchunks = nchunks; p.cap_units = o->cap_units; p.halo_max = o->halo_max;
   k_blk_units<<<(unsigned)tl_cdiv(nchunks, kBlock / 64), kBlock, 0, s>>>(bitmap, d, p);
+  k_blk_tail_rank<<<32, kBlock, 0, s>>>(o->unit, o->counter, (int)nchunks, o->cap_units);
+  k_blk_tail_copy<<<32, kBlock, 0, s>>>(o->unit, o->counter, (int)nchunks, o->cap_units);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

@@ -427,7 +427,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
                        (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));
-  if (a->in_all_ones && !train && dt == TL_BF16 && out_vec && g_direct && ((uintptr_t)a->weight) % 2 == 0 && !a->residual) {
+  if (a->in_all_ones && !train && dt == TL_BF16 && out_vec && (g_direct || !a->table) && ((uintptr_t)a->weight) % 2 == 0 && !a->residual) {
     const int rc = L_ones27(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }

@@ -162,6 +162,9 @@ class TreeLearn(nn.Module):
                                       blocked=(fused and self._plan.supports_blocked()) or blk_train, nn_table=blk_train)
         if not fused:
             # module-by-module path (batch-statistics BatchNorm, autograd through the HIP convs)
+            from .. import autograd as _ag
+            if _ag.RELU_MASK_SINK is not None:
+                self._last_geom = geom                                # test hook: the exported masks of level 1 are in this geometry's row order
             lv = geom.levels[0]
             x = spconv.SparseConvTensor(vfeats, lv.row_coords(), list(lv.shape), batch_size, geometry=geom, level=0)
             prev = spconv.SparseConvolution.amp_dtype
