@@ -217,10 +217,12 @@ def _fwd(m, batch, blocked):
 
 @pytest.mark.parametrize("use_feats", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_forward_blocked_vs_canonical_order(dtype, use_feats):
-    """Same tile, level 1 in block-local vs canonical order.  Everything but the 64 -> 32 decoder conv (run as two input-channel halves) is
-    bit-identical, so the outputs agree to 16-bit rounding of one layer; rows come back in point order either way."""
+def test_forward_blocked_vs_canonical_order(dtype, use_feats, monkeypatch):
+    """Same tile, level 1 in block-local vs canonical order, with the two-view producers of the canonical path (TL_BLK_PRO=0).  Everything
+    but the 64 -> 32 decoder conv (run as two input-channel halves) is bit-identical, so the outputs agree to 16-bit rounding of one layer;
+    rows come back in point order either way."""
     from treelearn_amd import ops
+    monkeypatch.setenv("TL_BLK_PRO", "0")
     batch = _batch(16.0, [5])
     m = _model(dtype, use_feats, settle_on=batch if dtype == torch.float16 else None)
     ops.PROFILE = []
@@ -234,6 +236,35 @@ def test_forward_blocked_vs_canonical_order(dtype, use_feats):
         assert torch.isfinite(a[k]).all()
         assert float((a[k] - b[k]).abs().max() / ref) < 2e-2, k
         assert float((a[k] - b[k]).abs().mean() / b[k].abs().mean()) < 2e-3, k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_forward_prologue_at_staging_vs_fp32(dtype, monkeypatch):
+    """The default level-1 form stores each conv result once (rounded to 16 bits) and applies BatchNorm + ReLU when the consumer stages the
+    row -- the reference's own order of operations (conv output tensor, then BatchNorm1d + ReLU on it, tree_learn/model/blocks.py:57-70) --
+    where the two-view form rounds the activated value from the fp32 accumulator.  Neither is `the' 16-bit result, so both are held
+    against the fp32 forward: the staged form is no further from it than the canonical-order 16-bit forward (factor 1.25)."""
+    from treelearn_amd import ops
+    batch = _batch(16.0, [5])
+    m = _model(torch.bfloat16, False, settle_on=batch)
+    m.compute_dtype = torch.float32
+    ref = _fwd(m, batch, False)
+    m.compute_dtype = dtype
+    can = _fwd(m, batch, False)
+    monkeypatch.setenv("TL_BLK_PRO", "1")
+    ops.PROFILE = []
+    stg = _fwd(m, batch, True)
+    pro = [bool(meta.get("in_scale")) for _, _, meta in ops.PROFILE if type(meta["table"]).__name__ == "BlockedRulebook"]
+    ops.PROFILE = None
+    assert len(pro) >= 9 and sum(pro) >= 5                       # conv1 of the four blocks + both halves of the 64 -> 32 conv
+    for k in ref:
+        e_can = float((can[k] - ref[k]).abs().mean() / ref[k].abs().mean())
+        e_stg = float((stg[k] - ref[k]).abs().mean() / ref[k].abs().mean())
+        m_can = float((can[k] - ref[k]).abs().max() / ref[k].abs().max())
+        m_stg = float((stg[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert torch.isfinite(stg[k]).all()
+        assert e_stg < 1.25 * e_can + 1e-4, (k, e_stg, e_can)
+        assert m_stg < 1.5 * m_can + 1e-3, (k, m_stg, m_can)
 
 
 def test_forward_blocked_vs_oracle_bf16():
@@ -327,3 +358,30 @@ def test_training_step_on_the_block_local_level():
         assert abs(float(a.norm() / b.norm()) - 1) < 0.05, nme
     print("blocked vs canonical training step: worst cosine", worst)
     assert worst[0] >= 0.999, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("residual", [False, True])
+def test_blk_conv_prologue_at_staging(dtype, residual):
+    """tl_conv_fwd's gather-side prologue relu(x * in_scale + in_shift) on the staged-unit kernel (applied once per staged row in LDS) equals
+    the same conv over a materialised activated tensor (tl_affine_relu: the same fmaf / max / round), bit for bit; also through column views
+    of a wider buffer, as the skip concat's halves come."""
+    from treelearn_amd import ops
+    batch = _batch(14.0, [3])
+    _, blk = _geoms(batch)
+    r = blk.levels[0].nbr
+    n = r.n
+    dev = r.unit.device
+    g = torch.Generator(device="cpu").manual_seed(2)
+    wide = torch.zeros(n, 64, dtype=dtype, device=dev)
+    wide[:, 32:] = (torch.randn(n, 32, generator=g) * 0.7).to(dtype).to(dev)
+    x = wide[:, 32:]
+    res = torch.randn(n, 32, generator=g).to(dtype).to(dev) if residual else None
+    w = ops.pack_weight((torch.randn(32, 3, 3, 3, 32, generator=g) * 0.08).to(dev), dtype)
+    sc, sh = (torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.3).to(dev)
+    osc, osh = (torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.3).to(dev)
+    act = ops.affine_relu(x.contiguous(), sc, sh, True)
+    a = ops.conv_fwd(act, w, r, n, residual=res, out_scale=osc, out_shift=osh, out_relu=True)
+    b = ops.conv_fwd(x, w, r, n, in_scale=sc, in_shift=sh, in_relu=True, residual=res, out_scale=osc, out_shift=osh, out_relu=True)
+    assert torch.equal(a, b), int((a != b).any(dim=1).sum())
+    assert float(a.float().abs().max()) > 0.1

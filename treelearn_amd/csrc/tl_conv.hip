@@ -432,7 +432,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (has_blk && dt == TL_BF16 && g_blk && vec_ok && out_vec && (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
-      (!a->out_scale || (((uintptr_t)a->out_scale) % 4 == 0 && ((uintptr_t)a->out_shift) % 4 == 0))) {
+      (!a->out_scale || (((uintptr_t)a->out_scale) % 4 == 0 && ((uintptr_t)a->out_shift) % 4 == 0)) && (!a->in_relu || a->in_scale)) {
     const int rc = L_blk(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }

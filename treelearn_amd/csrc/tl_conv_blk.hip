@@ -31,7 +31,7 @@ static __device__ __forceinline__ i32x4 s_load4(const void* ptr) { i32x4 v; asm 
 #define TL_SWAIT(d) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d) : : "memory")
 
 constexpr int WS_B = 27 * 32 * 64;            // all taps of the weights
-constexpr int AFF_B = 3 * 2 * 32 * 4;         // scale / shift of up to three views
+constexpr int AFF_B = 4 * 2 * 32 * 4;         // scale / shift of up to three views + of the input (prologue)
 constexpr int STAGE_B = 192 * 64;             // positions 0..63 own rows, 64..189 halo rows, 191 the zero row
 constexpr int HCH = 8;                        // halo chunks of 16 rows (TL_BLK_HALO_MAX = 126 <= 128)
 struct RbRow { u32x4 a, b; uint32_t c; };     // one row of the local rulebook
@@ -40,7 +40,13 @@ static __device__ __forceinline__ uint32_t rb_word(const RbRow& r, int w) { retu
 // TR: the training-mode epilogue (tl_conv_args.epi_mode: TL_EPI_STATS / TL_EPI_BN_BWD; one view, residual through the shared row-vector
 // helper of tl_conv_internal.h): every lane sums its row vectors' summands over all of its wave's units in fp32, the waves' totals
 // are combined in fp64 -> one partial row per workgroup, in the format of the other kernel families
-template <int W, bool RES, int NV, bool TR = false>
+// PRO: gather-side prologue relu?(x * in_scale + in_shift) -- the BatchNorm + ReLU that sits in front of every conv of the reference
+// (blocks.py:55-70) -- applied ONCE per staged row in LDS (1.8 rows per output row; the gather kernels would have to apply it to 27
+// gathered copies, which is why their producers write a second, activated view instead: 118 MB of extra writes per level-1 tensor)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+template <int W, bool RES, int NV, bool TR = false, bool PRO = false>
 __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,6 +67,9 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
       } else {
         aff[e] = src ? src[c] : (sh ? 0.f : 1.f);
       }
+    }
+    if constexpr (PRO) {
+      for (int e = tid; e < 64; e += W * 64) aff[192 + e] = (e < 32) ? (p.in_scale ? p.in_scale[e] : 1.f) : (p.in_shift ? p.in_shift[e - 32] : 0.f);
     }
   }
   char* stage = smem + WS_B + AFF_B + wv * STAGE_B;
@@ -181,6 +190,48 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
     load_hidx(d2, hn);                                                              // unit t + 2
     load_rb(d1, rbn);                                                               // unit t + 1
 
+    if constexpr (PRO) {
+      // lane: memory piece m = lane & 3 (channels 8 m ..) of the staged positions (lane >> 2) + 16 i; slot of the piece = m ^ swizzle(pos)
+      const int nh_ = dc.z;
+      f32x2 isc[4], ish[4];                                                          // channel pairs (2 q, 2 q + 1) of the lane's piece
+      {
+        const unsigned ia = lds0 + (unsigned)(WS_B + 768 + (lane & 3) * 32);
+        const u32x4 s0_ = lds_r128(ia), s1_ = lds_r128(ia + 16), h0_ = lds_r128(ia + 128), h1_ = lds_r128(ia + 144);
+        TL_LGKM(0);
+        isc[0] = f32x2{__uint_as_float(s0_[0]), __uint_as_float(s0_[1])}; isc[1] = f32x2{__uint_as_float(s0_[2]), __uint_as_float(s0_[3])};
+        isc[2] = f32x2{__uint_as_float(s1_[0]), __uint_as_float(s1_[1])}; isc[3] = f32x2{__uint_as_float(s1_[2]), __uint_as_float(s1_[3])};
+        ish[0] = f32x2{__uint_as_float(h0_[0]), __uint_as_float(h0_[1])}; ish[1] = f32x2{__uint_as_float(h0_[2]), __uint_as_float(h0_[3])};
+        ish[2] = f32x2{__uint_as_float(h1_[0]), __uint_as_float(h1_[1])}; ish[3] = f32x2{__uint_as_float(h1_[2]), __uint_as_float(h1_[3])};
+      }
+      const int nch = (64 + nh_ + 15) >> 4;                                          // chunks of 16 staged positions (<= 12)
+      // ReLU on the rounded pair as a signed 16-bit max (rounding keeps the sign; negative halves and -0 become +0); no ReLU: max with
+      // INT16_MIN = identity
+      const s16x2 floor2 = p.in_relu ? s16x2{0, 0} : s16x2{(short)-32768, (short)-32768};
+      for (int i0 = 0; i0 < nch; i0 += 4) {
+        u32x4 dv[4]; unsigned da[4]; bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pos = (lane >> 2) + 16 * (i0 + j);
+          ok[j] = (i0 + j) < nch && pos < 64 + nh_ && (pos >= 64 || pos < nown);
+          da[j] = st_a + (unsigned)(pos * 64 + (((lane & 3) ^ ((pos >> 2) & 3)) * 16));
+          if (!ok[j]) da[j] = st_a + 191u * 64u;                                     // (reads the zero row, writes nothing)
+          dv[j] = lds_r128(da[j]);
+        }
+        TL_LGKM(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          TL_KEEP(dv[j]);
+          u32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 z = __builtin_elementwise_fma(f32x2{bf16_lo(dv[j][q]), bf16_hi(dv[j][q])}, isc[q], ish[q]);
+            o[q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16x2(z[0], z[1])), floor2));
+          }
+          if (ok[j]) asm volatile("ds_write_b128 %0, %1" ::"v"(da[j]), "v"(o) : "memory");
+        }
+      }
+      TL_LGKM(0);
+    }
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -377,17 +428,17 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
   }
 }
 
-template <int W, bool RES, int NV, bool TR = false>
+template <int W, bool RES, int NV, bool TR = false, bool PRO = false>
 int launch_blk(const ConvP& p, hipStream_t s) {
   constexpr size_t lds = (size_t)WS_B + AFF_B + (size_t)W * STAGE_B + (TR ? (size_t)W * 2 * 32 * 8 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV, TR, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
-  k_conv_blk<W, RES, NV, TR><<<256, W * 64, lds, s>>>(p);
+  k_conv_blk<W, RES, NV, TR, PRO><<<256, W * 64, lds, s>>>(p);
   if (TR && p.red_nparts) *p.red_nparts = 256;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
@@ -398,7 +449,8 @@ int launch_blk(const ConvP& p, hipStream_t s) {
 // training epilogue.  Every view 16-B aligned with a row stride that is a multiple of 8 elements; buffers below 4 GB.
 int tl_launch_conv_blk(const ConvP& p, hipStream_t s) {
   if (!p.blk_unit || !p.blk_counter || !p.blk_halo || !p.blk_lrb) return TL_ERR_UNSUPPORTED;
-  if (p.K != 27 || p.Cin != 32 || p.Cout != 32 || p.in_scale || p.in_relu || p.n_in != p.n_out) return TL_ERR_UNSUPPORTED;
+  if (p.K != 27 || p.Cin != 32 || p.Cout != 32 || p.n_in != p.n_out) return TL_ERR_UNSUPPORTED;
+  const bool pro = p.in_scale || p.in_relu;
   if (p.n_out >= (1 << 25)) return TL_ERR_UNSUPPORTED;
   auto big = [&](int64_t ld) { return (p.n_out - 1) * ld * 2 + 64 >= 0x7FFFFFFFll * 2; };
   if (big(p.in_ld) || big(p.out_ld) || (p.out2 && big(p.out2_ld)) || (p.out3 && big(p.out3_ld)) || (p.res && big(p.res_ld))) return TL_ERR_UNSUPPORTED;
@@ -407,11 +459,15 @@ int tl_launch_conv_blk(const ConvP& p, hipStream_t s) {
 #ifdef TL_F16_BUILD
     return TL_ERR_UNSUPPORTED;                                   // the training epilogues are bf16
 #else
-    if (p.out2 || p.out_scale || p.out_relu || p.out_ld % 8 || ((uintptr_t)p.out) % 16) return TL_ERR_UNSUPPORTED;
+    if (pro || p.out2 || p.out_scale || p.out_relu || p.out_ld % 8 || ((uintptr_t)p.out) % 16) return TL_ERR_UNSUPPORTED;
     return launch_blk<8, false, 1, true>(p, s);                   // (a residual goes through the shared row stage)
 #endif
   }
   const int nv = p.out3 ? 3 : p.out2 ? 2 : 1;
+  if (pro) {                                                       // prologue form: one view (what the engine's level-1 first convs need)
+    if (nv != 1) return TL_ERR_UNSUPPORTED;
+    return p.res ? launch_blk<8, true, 1, false, true>(p, s) : launch_blk<8, false, 1, false, true>(p, s);
+  }
   if (p.res) {
     switch (nv) {
       case 1: return launch_blk<8, true, 1>(p, s);

@@ -25,11 +25,10 @@ static __device__ __forceinline__ h16_f32x16 h16_mfma(const h16_u32x4& a, const 
 }
 #else
 typedef __bf16 h16_x8 __attribute__((ext_vector_type(8)));
-static __device__ __forceinline__ uint32_t h16_pack2(float lo, float hi) {        // round-to-nearest-even
-  uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-  a += 0x7FFFu + ((a >> 16) & 1u);
-  b += 0x7FFFu + ((b >> 16) & 1u);
-  return (a >> 16) | (b & 0xFFFF0000u);
+typedef __bf16 h16_x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t h16_pack2(float lo, float hi) {        // round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+  const h16_x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 static __device__ __forceinline__ float h16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 static __device__ __forceinline__ float h16_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }

@@ -97,6 +97,34 @@ class _U:
             self.bn_cat_l = (s[:C].contiguous(), h[:C].contiguous())
             self.bn_cat_r = (s[C:].contiguous(), h[C:].contiguous())
 
+    def run_l1_staged(self, x_raw, geom: TileGeometry, views):
+        """Level 1 on block-local rows with the BatchNorm + ReLU in front of every block's first conv applied AT STAGING (tl_conv_fwd's
+        gather-side prologue, served by the staged-unit kernel: once per staged row): the producers write the raw tensor only -- no
+        activated second views, no activated copy of the skip concat (5 x 118 MB of writes per 40 m tile less).  Same dataflow as `run`
+        otherwise (reference blocks.py:55-79,137-149)."""
+        lv = geom.levels[0]
+        n, C, nbr = lv.n, self.C, lv.nbr
+
+        def block(b, x, in_aff, out_views):
+            t = ops.conv_fwd(x, b.w1, nbr, n, in_scale=in_aff[0], in_shift=in_aff[1], in_relu=True, out_scale=b.bn3[0], out_shift=b.bn3[1], out_relu=True)
+            res = x if b.w1x1 is None else ops.conv_fwd(x, b.w1x1, None, n)
+            return _conv_views(t, b.w2, nbr, n, out_views, residual=res)
+
+        (x1,) = block(self.blocks[0], x_raw, self.blocks[0].bn0, [RAW()])
+        cat_raw = torch.empty((n, 2 * C), dtype=x_raw.dtype, device=x_raw.device)
+        _, xd = block(self.blocks[1], x1, self.blocks[1].bn0, [RAW(cat_raw[:, :C]), ACT(self.bn_down)])
+        nxt = geom.levels[1]
+        d_raw, d_act = _conv_views(xd, self.wd, lv.child, nxt.n, [RAW(), ACT(self.u.blocks[0].bn0)])
+        (e_act,) = self.u.run(d_raw, d_act, geom, 1, [ACT(self.bn_up)])
+        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:])], one_hot=True)
+        b = self.tail[0]                                               # 2C -> C: the two input-channel halves, each with its slice of the BatchNorm
+        part = ops.conv_fwd(cat_raw[:, :C], b.w1_halves[0], nbr, n, in_scale=self.bn_cat_l[0], in_shift=self.bn_cat_l[1], in_relu=True, split=(0, 2 * C))
+        t = ops.conv_fwd(cat_raw[:, C:], b.w1_halves[1], nbr, n, in_scale=self.bn_cat_r[0], in_shift=self.bn_cat_r[1], in_relu=True, residual=part,
+                         out_scale=b.bn3[0], out_shift=b.bn3[1], out_relu=True, split=(1, 2 * C))
+        res = ops.conv_fwd(cat_raw, b.w1x1, None, n)
+        (y,) = _conv_views(t, b.w2, nbr, n, [RAW()], residual=res)
+        return block(self.tail[1], y, self.tail[1].bn0, views)
+
     def run(self, x_raw, x_act, geom: TileGeometry, li, views):
         """`views`: what the caller needs of this UBlock's output."""
         lv = geom.levels[li]
@@ -195,18 +223,25 @@ class InferencePlan:
         vf = voxel_feats.to(self.dtype).contiguous()
         if self.preact:
             ones = all_ones and os.environ.get("TL_NO_ONES_TABLE") != "1"
+            # block-local level 1: BatchNorm + ReLU of the blocks' first convs at staging, raw tensors only (TL_BLK_PRO=0: the two-view form)
+            staged = (geom.blocked and self.unet.deeper and self.unet.C == 32 and self.unet.tail[0].w1_halves is not None
+                      and os.environ.get("TL_BLK_PRO", "1") != "0")
+            in_views = [RAW()] if staged else [RAW(), ACT(self.unet.blocks[0].bn0)]
             if geom.blocked and not ones:
                 # block-local level 1 with real input features: the input conv runs on the canonical table, its two views are
                 # carried into the block-local order (not the default configuration: the reference feeds ones)
                 if lv.nbr_ref is None:
                     raise RuntimeError("a blocked geometry needs ref_table=True when the input features are not all ones")
                 # (the voxel features were averaged through the blocked v2p map, so they arrive in the new order)
-                xs = _conv_views(vf.index_select(0, lv.nbr.o2n.long()), self.w_in, lv.nbr_ref, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)])
+                xs = _conv_views(vf.index_select(0, lv.nbr.o2n.long()), self.w_in, lv.nbr_ref, lv.n, in_views)
                 perm = lv.nbr.perm.long()
-                x_raw, x_act = (t.index_select(0, perm) for t in xs)
+                xs = [t.index_select(0, perm) for t in xs]
             else:
-                x_raw, x_act = _conv_views(vf, self.w_in, lv.nbr, lv.n, [RAW(), ACT(self.unet.blocks[0].bn0)], all_ones=ones)
-            (x,) = self.unet.run(x_raw, x_act, geom, 0, [RAW()])
+                xs = _conv_views(vf, self.w_in, lv.nbr, lv.n, in_views, all_ones=ones)
+            if staged:
+                (x,) = self.unet.run_l1_staged(xs[0], geom, [RAW()])
+            else:
+                (x,) = self.unet.run(xs[0], xs[1], geom, 0, [RAW()])
         else:
             x = ops.conv_fwd(vf, self.w_in, lv.nbr, lv.n)
             x = self.unet.run(x, geom, 0)

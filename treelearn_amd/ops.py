@@ -156,7 +156,8 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
         _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
         e1.record()
         PROFILE.append((e0, e1, dict(K=K, Cin=Cin, Cout=Cout, n_out=n_out, n_in=x.shape[0], table=blk if blk is not None else table,
-                                     residual=residual is not None, esize=x.element_size(), split=split)))
+                                     residual=residual is not None, esize=x.element_size(), split=split,
+                                     in_scale=in_scale is not None or bool(in_relu))))
         return out
     _hip.check(L.tl_conv_fwd(ctypes.byref(a), _hip.stream()), "tl_conv_fwd")
     return out
