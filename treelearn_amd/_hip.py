@@ -35,7 +35,7 @@ class ConvArgs(_c.Structure):
         ("in_all_ones", _i32), ("epi_mode", _i32), ("red_part", _vp), ("red_nparts", _c.POINTER(_i32)),
         ("bn_x", _vp), ("bn_x_ld", _i64), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_scale", _vp), ("bn_shift", _vp), ("bn_relu", _i32),
         # block-local form of a 27-tap rulebook (tl_blk_build)
-        ("blk_unit", _vp), ("blk_counter", _vp), ("blk_halo", _vp), ("blk_lrb", _vp), ("blk_pmask", _vp),
+        ("blk_unit", _vp), ("blk_counter", _vp), ("blk_halo", _vp), ("blk_lrb", _vp), ("blk_pmask", _vp), ("table_scatter", _vp),
     ]
 
 

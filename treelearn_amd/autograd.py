@@ -44,6 +44,21 @@ def _forced_mask(bn, relu):
     return RELU_MASK_SOURCE.get(bn) if (RELU_MASK_SOURCE is not None and relu) else None
 
 
+def set_stats(t, stats):
+    """Attach a conv epilogue's per-channel partial sums to its result `t` for the BatchNorm that consumes it, with the tensor's version
+    counter and address: an in-place change of the features in between (an inplace ReLU, `mul_`, a user module in a SparseSequential) makes
+    the sums stale, and get_stats() then returns None (the statistics kernel reads the tensor instead)."""
+    t._tl_stats = (stats, t._version, t.data_ptr())
+
+
+def get_stats(t):
+    rec = getattr(t, "_tl_stats", None)
+    if rec is None:
+        return None
+    stats, version, addr = rec
+    return stats if (t._version == version and t.data_ptr() == addr) else None
+
+
 def _conv_with_stats(x, w_packed, ref, residual, holder):
     """Forward conv whose epilogue also sums y and y^2 per channel when the kernel family can (ops.conv_fwd(epi="stats")); the partial
     sums go to holder["stats"] = [(parts, nparts, Cout)] for the BatchNorm that consumes the result (attached to the output tensor as
@@ -160,7 +175,7 @@ def sparse_conv(feats, weight, ref, residual=None, want_stats=False):
         holder = {} if want_stats else None
         out = _SparseConvFn.apply(feats, weight, ref, residual, holder)
         if holder:
-            out._tl_stats = holder["stats"]
+            set_stats(out, holder["stats"])
         return out
     x = feats.contiguous()
     return ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
@@ -226,13 +241,14 @@ def bn_relu_conv(x, bn, relu, weight, ref, residual=None, want_skip=False):
     """Fused training-mode BatchNorm1d(+ReLU) -> sparse conv of the feature matrix x; returns y, or (y, skip) with want_skip (skip = x
     passed through: the caller's identity path must use it, see _BNReLUTrainFn).  y carries `_tl_stats` when the conv kernel summed it."""
     holder = {}
-    out = _BNReLUConvFn.apply(x, bn.weight, bn.bias, weight, residual, bn, relu, ref, want_skip, getattr(x, "_tl_stats", None) if FUSE_BN else None, holder)
+    stats_in = get_stats(x) if FUSE_BN else None
+    out = _BNReLUConvFn.apply(x, bn.weight, bn.bias, weight, residual, bn, relu, ref, want_skip, stats_in, holder)
     y = out[0] if want_skip else out
     if "stats" in holder:
-        y._tl_stats = holder["stats"]
+        set_stats(y, holder["stats"])
     if want_skip:
-        if getattr(x, "_tl_stats", None) is not None:
-            out[1]._tl_stats = x._tl_stats
+        if stats_in is not None:
+            set_stats(out[1], stats_in)
         return y, out[1]
     return y
 
@@ -280,10 +296,10 @@ class _BNReLUTrainFn(torch.autograd.Function):
 
 def bn_relu_train(x, bn, relu=True, skip=False):
     """Training-mode BatchNorm1d `bn` (+ ReLU) of the feature matrix x on the HIP library; skip=True returns (y, x passed through)."""
-    stats_in = getattr(x, "_tl_stats", None) if FUSE_BN else None
+    stats_in = get_stats(x) if FUSE_BN else None
     out = _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn, relu, skip, stats_in)
     if skip and stats_in is not None:
-        out[1]._tl_stats = stats_in
+        set_stats(out[1], stats_in)
     return out
 
 

@@ -27,7 +27,7 @@ DEV_ONLY = ("tl_dev.hip", "tl_conv_win.hip")     # the gather micro-benchmarks; 
 
 # units compiled a SECOND time with -DTL_F16_BUILD (csrc/tl_half.h): the same kernels with IEEE-half conversions and the f16 MFMA,
 # launchers suffixed _f16 -- the float16 inference path (TL_F16)
-F16_UNITS = ("tl_conv_direct.hip", "tl_conv_blk.hip", "tl_conv_stream.hip", "tl_conv_streamq.hip", "tl_conv_small.hip", "tl_conv_bf16.hip", "tl_head.hip")
+F16_UNITS = ("tl_conv_direct.hip", "tl_conv_blk.hip", "tl_conv_up.hip", "tl_conv_stream.hip", "tl_conv_streamq.hip", "tl_conv_small.hip", "tl_conv_bf16.hip", "tl_head.hip")
 
 
 def sources(dev=False):

@@ -29,6 +29,10 @@ PRIM_MAX_MIN_SAMPLES = 128     # kMaxK of csrc/tl_hdbscan.hip: the Prim form kee
 # 1-2 % of the weights on smooth data (an edge often weighs some point's core distance: 142 of 11 999 at min_samples 50) with labels
 # identical to the Prim form; the inputs on which the two forms split a level differently had 19-100 % ties (tools/fuzz_hdbscan.py)
 TIE_FRACTION = 0.10
+# ... but only up to this many points: the Prim form is O(n^2) (50 k points: ~1 s; 400 k: minutes).  Above it the grid form's tree is kept
+# (it is a minimal tree of the same weights, put into Prim's order; labels can differ from sklearn's only where exact ties decide a split)
+# and a warning says so.
+PRIM_FALLBACK_MAX_POINTS = 50_000
 
 
 GRID_MIN_POINTS = 8192          # from here on the quadtree / Boruvka device stage replaces the two O(n^2) passes
@@ -74,7 +78,12 @@ def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False, algorithm="au
             # coordinates, tiny min_samples) the default therefore re-builds the tree in Prim's own order -- slower, sklearn's labels.
             ws_ = np.sort(gw)
             if (ws_[1:] == ws_[:-1]).sum() > TIE_FRACTION * max(len(gw), 1):
-                return hdbscan(xy, min_cluster_size, device=device, return_mst=return_mst, algorithm="prim")
+                if n <= PRIM_FALLBACK_MAX_POINTS:
+                    return hdbscan(xy, min_cluster_size, device=device, return_mst=return_mst, algorithm="prim")
+                import warnings
+                warnings.warn(f"hdbscan: {n} points with more than {TIE_FRACTION:.0%} exactly tied tree weights (quantised or duplicated "
+                              f"coordinates?); above {PRIM_FALLBACK_MAX_POINTS} points the quadtree form's tree is kept -- labels may differ "
+                              f"from the O(n^2) form's where ties decide a split (algorithm='prim' forces it)", RuntimeWarning, stacklevel=2)
         hs, hd, hw = np.empty_like(gs), np.empty_like(gd), np.empty_like(gw)       # the tree in Prim's order / orientation (host)
         _hip.check(L.tl_hdbscan_prim_order_host(gs.ctypes.data, gd.ctypes.data, gw.ctypes.data, n, hs.ctypes.data, hd.ctypes.data, hw.ctypes.data),
                    "tl_hdbscan_prim_order_host")

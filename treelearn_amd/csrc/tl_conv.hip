@@ -341,6 +341,7 @@ static int g_streamq = 1;                         // ... and its quad-gather for
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
 static int g_direct_oh = 1;                       // ... and its gather-once form for the level-1 inverse conv
 static int g_blk = 1;                             // use the staged-unit kernel when the caller passes the block-local rulebook form
+static int g_up = 1;                              // use the coarse-stationary inverse conv when the caller passes the scatter form of the table
 #ifdef TL_DEV                                     // the window kernel lives in the developer build only (python -m treelearn_amd.build --dev)
 static int g_win = 0;                             // window kernel (opt-in, TL_CONV_WIN=1: measured at parity with the gather kernels): 1 = shapes with >= 64 channels, 2 = all, 0 = off
 extern int g_win_rows, g_win_ct;                  // tl_conv_win.hip
@@ -355,6 +356,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "bf16_units")) { g_bf16_units = (int)value; return TL_OK; }
   if (!strcmp(key, "direct")) { g_direct = (int)value; return TL_OK; }
   if (!strcmp(key, "blk")) { g_blk = (int)value; return TL_OK; }
+  if (!strcmp(key, "up")) { g_up = (int)value; return TL_OK; }
   if (!strcmp(key, "direct_oh")) { g_direct_oh = (int)value; return TL_OK; }
 #ifdef TL_DEV
   if (!strcmp(key, "win")) { g_win = (int)value; return TL_OK; }
@@ -397,6 +399,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const auto L_small = f16 ? tl_launch_conv_small_f16 : tl_launch_conv_small;
   const auto L_tinycin = f16 ? tl_launch_conv_tinycin_f16 : tl_launch_conv_tinycin;
   const auto L_blk = f16 ? tl_launch_conv_blk_f16 : tl_launch_conv_blk;
+  const auto L_up = f16 ? tl_launch_conv_up_f16 : tl_launch_conv_up;
   if (f16 && a->epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;       // the training epilogues take TL_F32 / TL_BF16
   ConvP p;
   p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
@@ -437,6 +440,11 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (!a->table && a->K != 1) return TL_ERR_UNSUPPORTED;       // block-local rows without a shape the staged-unit kernel serves
+  if (a->table_scatter && p.one_hot && g_up && !train && dt == TL_BF16 && vec_ok && out_vec &&
+      (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
+    const int rc = L_up(p, a->table_scatter, s);          // inverse conv walking the coarse rows (levels 1-4)
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
   if (dt == TL_BF16 && a->Cin == 4 && a->Cout == 32 && g_direct && out_vec && ((uintptr_t)a->in) % 8 == 0 && ((uintptr_t)a->weight) % 16 == 0 &&
       (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0))) {
     const int rc = L_direct(p, TL_BF16, s);

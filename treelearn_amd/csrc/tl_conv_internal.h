@@ -14,6 +14,7 @@
 #define tl_launch_conv_tinycin tl_launch_conv_tinycin_f16
 #define tl_launch_conv_bf16 tl_launch_conv_bf16_f16
 #define tl_launch_conv_blk tl_launch_conv_blk_f16
+#define tl_launch_conv_up tl_launch_conv_up_f16
 #define g_small_mode g_small_mode_f16
 #endif
 
@@ -305,6 +306,9 @@ int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   
 int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s);   // whole weight tensor resident in LDS, per-wave tiles
 int tl_launch_conv_ones27(const ConvP& p, hipStream_t s);               // every input element is 1: presence-mask table, no gather
 
+// tl_conv_up.hip
+int tl_launch_conv_up(const ConvP& p, const int32_t* child, hipStream_t s);   // 16-bit inverse conv, coarse-stationary scatter form
+
 // tl_conv_blk.hip
 int tl_launch_conv_blk(const ConvP& p, hipStream_t s);                  // 16-bit, 27 taps, 32 -> 32: rows in block-local order, staged units
 
@@ -333,6 +337,7 @@ int tl_launch_conv_small_f16(const ConvP& p, int dtype, hipStream_t s);
 int tl_launch_conv_tinycin_f16(const ConvP& p, int dtype, hipStream_t s);
 int tl_launch_conv_bf16_f16(const ConvP& p, int depth, int units, hipStream_t s);
 int tl_launch_conv_blk_f16(const ConvP& p, hipStream_t s);
+int tl_launch_conv_up_f16(const ConvP& p, const int32_t* child, hipStream_t s);
 #endif
 
 // tl_linear_small.hip

@@ -42,13 +42,13 @@ RAW = lambda buf=None: View(buf=buf)                                   # noqa: E
 ACT = lambda aff, buf=None: View(aff[0], aff[1], True, buf)            # noqa: E731
 
 
-def _conv_views(x, w, table, n, views, residual=None, one_hot=False, all_ones=False):
+def _conv_views(x, w, table, n, views, residual=None, one_hot=False, all_ones=False, scatter=None):
     """Run one conv producing up to three views; returns the list of result tensors (same order)."""
     outs = [v.buf if v.buf is not None else torch.empty((n, w.shape[1]), dtype=x.dtype, device=x.device) for v in views]
     v0 = views[0]
     extra = [(o, v.scale, v.shift, v.relu) for o, v in zip(outs[1:], views[1:])]
     ops.conv_fwd(x, w, table, n, out=outs[0], residual=residual, out_scale=v0.scale, out_shift=v0.shift, out_relu=v0.relu,
-                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None, one_hot=one_hot, all_ones=all_ones)
+                 out2=extra[0] if len(extra) > 0 else None, out3=extra[1] if len(extra) > 1 else None, one_hot=one_hot, all_ones=all_ones, scatter=scatter)
     return outs
 
 
@@ -116,7 +116,7 @@ class _U:
         nxt = geom.levels[1]
         d_raw, d_act = _conv_views(xd, self.wd, lv.child, nxt.n, [RAW(), ACT(self.u.blocks[0].bn0)])
         (e_act,) = self.u.run(d_raw, d_act, geom, 1, [ACT(self.bn_up)])
-        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:])], one_hot=True)
+        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:])], one_hot=True, scatter=lv.child)
         b = self.tail[0]                                               # 2C -> C: the two input-channel halves, each with its slice of the BatchNorm
         part = ops.conv_fwd(cat_raw[:, :C], b.w1_halves[0], nbr, n, in_scale=self.bn_cat_l[0], in_shift=self.bn_cat_l[1], in_relu=True, split=(0, 2 * C))
         t = ops.conv_fwd(cat_raw[:, C:], b.w1_halves[1], nbr, n, in_scale=self.bn_cat_r[0], in_shift=self.bn_cat_r[1], in_relu=True, residual=part,
@@ -141,7 +141,7 @@ class _U:
         nxt = geom.levels[li + 1]
         d_raw, d_act = _conv_views(xd, self.wd, lv.child, nxt.n, [RAW(), ACT(self.u.blocks[0].bn0)])
         (e_act,) = self.u.run(d_raw, d_act, geom, li + 1, [ACT(self.bn_up)])
-        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:]), ACT(self.bn_cat_r, cat_act[:, C:])], one_hot=True)
+        _conv_views(e_act, self.wu, lv.inv, n, [RAW(cat_raw[:, C:]), ACT(self.bn_cat_r, cat_act[:, C:])], one_hot=True, scatter=lv.child)
         y_raw, y_act = self.tail[0].run(cat_raw, cat_act, lv.nbr, n, [RAW(), ACT(self.tail[1].bn0)])
         return self.tail[1].run(y_raw, y_act, lv.nbr, n, views)
 

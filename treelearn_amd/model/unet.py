@@ -140,9 +140,10 @@ class UBlock(nn.Module):
             identity = skip if skip is not None else output.features
             dec = self.deconv(self.u(down))
             cat = torch.cat((identity, dec.features), dim=1)
-            sa, sb = getattr(identity, "_tl_stats", None), getattr(dec.features, "_tl_stats", None)
+            from ..autograd import get_stats, set_stats
+            sa, sb = get_stats(identity), get_stats(dec.features)
             if sa is not None and sb is not None:              # per-channel statistics of a concat = those of its halves
-                cat._tl_stats = list(sa) + list(sb)
+                set_stats(cat, list(sa) + list(sb))
             output = output.replace_feature(cat)
             output = self.blocks_tail(output)
         return output

@@ -66,7 +66,7 @@ def _check_table(table, K, n_out, device):
 
 def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: torch.Tensor = None,
              in_scale=None, in_shift=None, in_relu=False, residual=None, out_scale=None, out_shift=None, out_relu=False,
-             out2=None, out3=None, one_hot=False, epi=None, all_ones=False, split=None):
+             out2=None, out3=None, one_hot=False, epi=None, all_ones=False, split=None, scatter=None):
     """out[o] = epi(sum_k W[k] . pro(x[table[k][o]])); x / out / residual may be column views of wider
     row-major buffers (their stride(0) is the leading dimension) -- that is how the skip concat is fused.
 
@@ -76,7 +76,8 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     kernel family that serves the shape has no such epilogue (nothing was launched: the caller runs the separate passes).
 
     `table` may be a geometry.BlockedRulebook (K = 27): x / out / residual are then in the block-local row order.  `split` = (part, Cin of
-    the logical conv) marks a launch as one input-channel half of a wider conv (bench.py's per-launch accounting)."""
+    the logical conv) marks a launch as one input-channel half of a wider conv (bench.py's per-launch accounting).  `scatter` (with one_hot):
+    the table's scatter form i32[K][n_in] (tl_conv_args.table_scatter) -- the inverse conv then walks its input rows."""
     L = _hip.lib()
     K, Cout, Cin = w_packed.shape
     if x.stride(1) != 1 or x.shape[1] != Cin:
@@ -103,6 +104,10 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
     a.table = table.data_ptr() if table is not None else None
     a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
     a.table_one_hot = int(bool(one_hot))          # inverse conv: one valid entry per output row
+    if scatter is not None:                       # ... and its scatter form (the stride-2 conv's rulebook, i32[K][n_in])
+        if not one_hot or scatter.dtype != torch.int32 or tuple(scatter.shape) != (K, x.shape[0]) or not scatter.is_contiguous() or scatter.device != x.device:
+            raise ValueError("scatter: the one-hot table's transpose, i32[K][n_in] on the input's device")
+        a.table_scatter = scatter.data_ptr()
     a.in_all_ones = int(bool(all_ones))           # the caller guarantees x == 1 everywhere (default reference flags): presence-mask table, no gather
     a.table_compact = _hip.ptr(getattr(table, "_tl_compact", None)) if (table is not None and os.environ.get("TL_NO_COMPACT") != "1") else None
     a.n_out = n_out; a.n_in = x.shape[0]
