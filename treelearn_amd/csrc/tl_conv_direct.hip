@@ -511,6 +511,13 @@ int dispatch(const ConvP& p, hipStream_t s) {
     // form took 0.171 ms for 0.38 GB of traffic: eight barrier steps per 256 rows)
     if (p.one_hot && nb == 1 && un == 2) return launch<true, 8, 1, 2, G, 16, 0, false, false, true>(p, s);
   }
+  if constexpr (BF16 && K == 1) {
+    // the 1x1 convs of the decoder blocks (2C -> C on the skip concat) of levels 2-4: pure streaming, weights resident (level 2: 0.108 ms
+    // on the tile kernel for 424 MB = 3.9 TB/s; the level-1 shape runs at 5.1 TB/s here)
+    if (nb == 2 && un == 4) return launch<true, 1, 2, 4, 1, 16>(p, s);
+    if (nb == 3 && un == 6) return launch<true, 1, 3, 6, 1, 8>(p, s);
+    if (nb == 4 && un == 8) return launch<true, 1, 4, 8, 1, 8>(p, s);
+  }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \
   if (nb == NB_ && un == UN_) {                                                                                      \

@@ -6,22 +6,27 @@
 // COARSE rows: their features are read once, coalesced, straight into A fragments; for each tap the 32 x Cout product is formed and its rows
 // are scattered to the children that exist (tl_conv_args.table_scatter = the stride-2 conv's own rulebook, i32[K][n_in]) -- each fine row is
 // written exactly once, whole rows per view.  MFMA work: n_coarse x K row-taps instead of n_fine x K (4.3 x less at level 2 of config 2),
-// no gathers.  Weights: fragment-order copy (tl_pack_weight_frag), resident in LDS when K x Cout x Cin fits, else read from L2 per tile
-// (those levels are small).  Results are bit-identical to the gather forms: one product per output element, same k order.
+// no gathers.  Weights: the fragment-order copy (tl_pack_weight_frag), resident in LDS.  Results are bit-identical to the gather forms: one
+// product per output element, same k order.
+//
+// Measured on the config-2 tile (inside the forward, us): 96 -> 64 (level 2 <- 3, two 128-B views) 138 -> 102; 64 -> 32 (level 1 <- 2, one
+// 64-B view) 78 -> 117 -- scattered 64-B row writes cost more than the gather form's parent fetches, which hit L2; with the weights read
+// from L2 per tile (they do not fit the LDS) 128 -> 96 58 -> 154 and 160 -> 128 46 -> 214.  So: one shape, the one with wide rows and two
+// views; the others stay on the gather forms.
 #include "tl_conv_internal.h"
 #include <atomic>
 
 namespace {
 
-template <int NBI, int NBO, bool WLDS, int WAVES>
+template <int NBI, int NBO, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_up(ConvP p, const int32_t* __restrict__ child, int ntiles) {
   constexpr int K = 8, KS = 2 * NBI;                 // 16-wide contraction steps per tap
   constexpr int EP = 36;                             // epilogue tile [32][36] fp32 per wave: one 32-column block at a time
-  constexpr int WB = WLDS ? K * NBO * NBI * 2 * 1024 : 0;
+  constexpr int WB = K * NBO * NBI * 2 * 1024;      // the whole weight tensor, fragment order
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fi = lane & 31, fh = lane >> 5;
-  if constexpr (WLDS) {
+  {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.w_frag);
     u32x4* dst = reinterpret_cast<u32x4*>(smem);
     for (int e = tid; e < WB / 16; e += WAVES * 64) dst[e] = src[e];
@@ -31,7 +36,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_up(ConvP p, const int32_t* 
   const unsigned in_ldb = (unsigned)(p.in_ld * 2);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)((p.n_in - 1) * (int64_t)in_ldb + NBI * 64), 0x00020000);
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(child), 0, (int)((int64_t)K * p.n_in * 4), 0x00020000);
-  const u32x4* wf = reinterpret_cast<const u32x4*>(p.w_frag);
 
   const int nw = (int)gridDim.x * WAVES;
   int t = (int)blockIdx.x * WAVES + wv;
@@ -69,10 +73,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_up(ConvP p, const int32_t* 
         for (int s_ = 0; s_ < KS; ++s_) {
           // fragment order: vector ((((k * NBO + nb) * NBI + ch) * 2 + j) * 64 + lane), ch = s_ / 2, j = s_ & 1
           const int v = (((k * NBO + nb) * NBI + (s_ >> 1)) * 2 + (s_ & 1)) * 64 + lane;
-          u32x4 B;
-          if constexpr (WLDS) B = *reinterpret_cast<const u32x4*>(smem + (size_t)v * 16);
-          else B = wf[v];
-          acc = h16_mfma(A[s_], B, acc);
+          acc = h16_mfma(A[s_], *reinterpret_cast<const u32x4*>(smem + (size_t)v * 16), acc);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP + fi] = acc[r];
@@ -101,12 +102,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_up(ConvP p, const int32_t* 
   }
 }
 
-template <int NBI, int NBO, bool WLDS, int WAVES>
+template <int NBI, int NBO, int WAVES>
 int launch_up(const ConvP& p, const int32_t* child, hipStream_t s) {
-  const size_t lds = (WLDS ? (size_t)8 * NBO * NBI * 2 * 1024 : 0) + (size_t)WAVES * 32 * 36 * 4;
+  const size_t lds = (size_t)8 * NBO * NBI * 2 * 1024 + (size_t)WAVES * 32 * 36 * 4;
+  static_assert(8 * NBO * NBI * 2 * 1024 + WAVES * 32 * 36 * 4 <= 160 * 1024, "weights + epilogue tiles must fit the LDS");
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_up<NBI, NBO, WLDS, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_up<NBI, NBO, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return TL_ERR_LAUNCH;
     attr_set = true;
   }
@@ -115,7 +117,7 @@ int launch_up(const ConvP& p, const int32_t* child, hipStream_t s) {
   int grid = 256 * (per_cu > 4 ? 4 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_up<NBI, NBO, WLDS, WAVES><<<grid, WAVES * 64, lds, s>>>(p, child, ntiles);
+  k_conv_up<NBI, NBO, WAVES><<<grid, WAVES * 64, lds, s>>>(p, child, ntiles);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
@@ -128,11 +130,6 @@ int tl_launch_conv_up(const ConvP& p, const int32_t* child, hipStream_t s) {
   auto big = [&](int64_t rows, int64_t ld) { return (rows - 1) * ld * 2 + 512 >= 0x7FFFFFFFll; };
   if (big(p.n_in, p.in_ld) || big(p.n_out, p.out_ld) || (p.out2 && big(p.n_out, p.out2_ld)) || (p.out3 && big(p.n_out, p.out3_ld)) || (int64_t)8 * p.n_in * 4 >= 0x7FFFFFFFll)
     return TL_ERR_UNSUPPORTED;
-  switch (p.Cin * 1000 + p.Cout) {
-    case 64032: return launch_up<2, 1, true, 8>(p, child, s);      // 32 KB of weights resident
-    case 96064: return launch_up<3, 2, true, 8>(p, child, s);      // 96 KB
-    case 128096: return launch_up<4, 3, false, 8>(p, child, s);    // 192 KB: read per tile (1 200 tiles at level 3 of config 2)
-    case 160128: return launch_up<5, 4, false, 8>(p, child, s);
-  }
+  if (p.Cin == 96 && p.Cout == 64) return launch_up<3, 2, 8>(p, child, s);      // 96 KB of weights resident
   return TL_ERR_UNSUPPORTED;
 }
