@@ -238,15 +238,16 @@ def test_forward_blocked_vs_canonical_order(dtype, use_feats, monkeypatch):
         assert float((a[k] - b[k]).abs().mean() / b[k].abs().mean()) < 2e-3, k
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_forward_prologue_at_staging_vs_fp32(dtype, monkeypatch):
+@pytest.mark.parametrize("dtype,use_feats,seeds", [(torch.bfloat16, False, [5]), (torch.float16, False, [5]), (torch.bfloat16, True, [5]),
+                                                   (torch.bfloat16, False, [6, 7])])
+def test_forward_prologue_at_staging_vs_fp32(dtype, use_feats, seeds, monkeypatch):
     """The default level-1 form stores each conv result once (rounded to 16 bits) and applies BatchNorm + ReLU when the consumer stages the
     row -- the reference's own order of operations (conv output tensor, then BatchNorm1d + ReLU on it, tree_learn/model/blocks.py:57-70) --
     where the two-view form rounds the activated value from the fp32 accumulator.  Neither is `the' 16-bit result, so both are held
     against the fp32 forward: the staged form is no further from it than the canonical-order 16-bit forward (factor 1.25)."""
     from treelearn_amd import ops
-    batch = _batch(16.0, [5])
-    m = _model(torch.bfloat16, False, settle_on=batch)
+    batch = _batch(16.0 if len(seeds) == 1 else 12.0, seeds)           # (the last case: a batch of two tiles)
+    m = _model(torch.bfloat16, use_feats, settle_on=batch)
     m.compute_dtype = torch.float32
     ref = _fwd(m, batch, False)
     m.compute_dtype = dtype
