@@ -49,8 +49,15 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   for (int rb = 0; rb < RB; ++rb) {
     const int64_t row = r0 + rb * 32 + fi;
     const bool rvalid = row < p.n_out;
+    if (K == 27 && p.ctab) {                                 // column form of the rulebook: 40 B per row instead of 108
+      int t27[27];
+      decode_ctab(p.ctab, p.n_out, row, rvalid, t27);
 #pragma unroll
-    for (int k = 0; k < K; ++k) idx[k][rb] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+      for (int k = 0; k < K; ++k) idx[k][rb] = t27[k < 27 ? k : 0];
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) idx[k][rb] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+    }
   }
 
   const int in_ld_b = (int)(p.in_ld * EB);

@@ -90,10 +90,17 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
     const int64_t row = r0 + rb * 32 + fi;
     const bool rvalid = row < p.n_out;
     int v[(K + 1) / 2];
+    if (K == 27 && p.ctab) {                                 // column form of the rulebook: 40 B per row instead of 108
+      int t27[27];
+      decode_ctab(p.ctab, p.n_out, row, rvalid, t27);
 #pragma unroll
-    for (int t = 0; t < (K + 1) / 2; ++t) {
-      const int k = min(2 * t + fh, K - 1);
-      v[t] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+      for (int t = 0; t < (K + 1) / 2; ++t) v[t] = fh ? t27[min(2 * t + 1, 26)] : t27[min(2 * t, 26)];
+    } else {
+#pragma unroll
+      for (int t = 0; t < (K + 1) / 2; ++t) {
+        const int k = min(2 * t + fh, K - 1);
+        v[t] = rvalid ? (p.table ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
+      }
     }
 #pragma unroll
     for (int t = 0; t < (K + 1) / 2; ++t) {

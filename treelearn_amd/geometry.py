@@ -16,6 +16,7 @@ import torch
 from . import _hip
 
 
+COMPACT_MIN_ROWS = 65536       # levels from this size on also get the column form of their rulebook (40 instead of 108 B per voxel)
 BLK_MIN_ROWS = 16384        # below this the level-1 convs run on the small-level kernel anyway (tl_conv_fwd's small_rows)
 BLK_MAX_ROWS = (1 << 25) - 64
 BLK_HALO_MAX = 126
@@ -168,9 +169,9 @@ def _build_per_level(L, st, dev, pcoords, N, batch_size, extent, shapes, num_lev
         lv.coords = torch.empty((lv.n, 4), dtype=torch.int32, device=dev)
         _hip.check(L.tl_expand_coords(_hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims), _hip.ptr(lv.coords), st), "tl_expand_coords")
         lv.nbr = torch.empty((27, lv.n), dtype=torch.int32, device=dev)
-        # level 1 also gets the column form of its rulebook (40 instead of 108 B/voxel) for the kernels that read it; it rides on
+        # big levels also get the column form of their rulebook (40 instead of 108 B/voxel) for the kernels that read it; it rides on
         # the table tensor as an attribute
-        ct = torch.empty((10, lv.n), dtype=torch.int32, device=dev) if (lv.n >= 65536 and (li == 0 or _hip.WIN_KERNEL)) else None
+        ct = torch.empty((10, lv.n), dtype=torch.int32, device=dev) if lv.n >= COMPACT_MIN_ROWS else None
         _hip.check(L.tl_rulebook_subm(_hip.ptr(lv.coords), lv.n, _hip.ptr(lv.bitmap), _hip.ptr(lv.prefix), _hip.dims4(lv.dims),
                                       _hip.ptr(lv.nbr), _hip.ptr(ct), st), "tl_rulebook_subm")
         if ct is not None:
@@ -255,7 +256,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     # 108 B/voxel); it rides on the table tensor as an attribute
     n1 = levels[0].n
     blocked = bool(blocked) and (BLK_MIN_ROWS if blk_min_rows is None else blk_min_rows) <= n1 <= BLK_MAX_ROWS
-    want_ct = lambda lv: lv.n >= 65536 and (lv is levels[0] or _hip.WIN_KERNEL)     # noqa: E731
+    want_ct = lambda lv: lv.n >= COMPACT_MIN_ROWS     # noqa: E731
     al = lambda w: (w + 63) & ~63                           # noqa: E731
     cur = 0
     def take(words):
