@@ -948,6 +948,36 @@ def test_compact_rulebook_equals_table():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_column_form_rulebook_in_the_mid_level_gather_kernels(dtype):
+    """Levels 2 and 3 of a real tile (>= 65 536 rows: the geometry attaches the column form there too): the stream-q / stream kernels fed
+    with the 40-B column form must give the table-fed result bit for bit -- 64 -> 64, 128 -> 64 (two channel slices), 96 -> 96, residual
+    and a second view; fp32 (the stream kernel's exact mode) as well."""
+    from treelearn_amd import ops
+    from treelearn_amd.geometry import COMPACT_MIN_ROWS, build_geometry
+    from treelearn_amd.synth import make_tile
+    t = make_tile(extent=30.0, voxel=0.1, n_trees=30, fill=0.10, seed=3)
+    pts = torch.from_numpy(t["points"]).cuda(); bid = torch.zeros(len(pts), dtype=torch.int64, device="cuda")
+    g = build_geometry(pts, bid, 1, 0.1, 7, [500, 500, 1000])
+    served = 0
+    for li, shapes in ((1, [(64, 64), (128, 64)]), (2, [(96, 96)])):
+        lv = g.levels[li]
+        assert lv.n >= COMPACT_MIN_ROWS and getattr(lv.nbr, "_tl_compact", None) is not None, (li, lv.n)
+        plain = lv.nbr.clone()                                   # the same table without the attached column form
+        for cin, cout in shapes:
+            x = torch.randn(lv.n, cin, device="cuda").to(dtype)
+            w = ops.pack_weight(torch.randn(cout, 3, 3, 3, cin, device="cuda") * 0.05, dtype)
+            res = torch.randn(lv.n, cout, device="cuda").to(dtype)
+            sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+            outs = []
+            for tab in (lv.nbr, plain):
+                o2 = torch.empty(lv.n, cout, device="cuda", dtype=dtype)
+                outs.append((ops.conv_fwd(x, w, tab, lv.n, residual=res, out2=(o2, sc, sh, True)), o2))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (li, cin, cout)
+            served += 1
+    assert served == 3
+
+
 def test_input_conv_of_all_ones_by_presence_mask_table():
     """tl_conv_args.in_all_ones (the reference's default use_feats = False, use_coords = False feeds ones, tree_learn.py:129-167): the
     27-entry table indexed by the rulebook's presence mask equals the gather kernel on an all-ones input (fp32 sums in another order,
