@@ -541,7 +541,7 @@ def main():
             # the north-star's "HBM bandwidth on the rulebook gather": PMC bytes of the conv kernels / their measured time
             roof["traffic_gbs"] = roof["traffic"] / (tot_ms * 1e-3)
             roof["traffic_frac_of_peak"] = roof["traffic_gbs"] / PEAK_HBM_GBS
-        roof.update(kernel="tl_conv_fwd family (k_conv_streamq / k_conv_stream / k_conv_blk / k_conv_direct / k_conv_small / k_conv_ones27)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
+        roof.update(kernel="tl_conv_fwd family (k_conv_streamq / k_conv_stream / k_conv_blk / k_conv_direct / k_conv_up / k_conv_small / k_conv_ones27)", launches_per_step=per, conv_ms_per_step=tot_ms, avg_launch_ms=avg_ms,
                     algorithmic_gflop_per_step=flops / 1e9, algorithmic_gb_per_step=byts / 1e9)
 
     if rank == 0:
