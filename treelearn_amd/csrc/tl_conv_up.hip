@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_up(ConvP p, const int32_t* 
         for (int e0 = 0; e0 < 2; ++e0) {
           const int rr = (lane >> 2) + 16 * e0, cvv = lane & 3;
           const int orow = ch[k][e0];
-          if (orow >= 0) {
+          if (orow >= 0 && orow < (int)p.n_out) {           // (a child index outside the output is ignored, never written)
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * EP + cvv * 8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             epi_views8<true>(p, (int64_t)orow, nb * 32 + cvv * 8, v);
