@@ -39,9 +39,11 @@ enum {
 enum { TL_F32 = 0, TL_BF16 = 1, TL_F16 = 2 };
 
 int tl_version(void);
-/* Developer tuning knobs, process-wide ("win" / "direct" / "stream" / "streamq": enable a conv kernel family; "win_rows": window
- * rows of the window kernel; "win_min_rows" / "small_rows": row thresholds; "bf16_depth": register prefetch depth 1..4).  Not
- * needed for correct results; the parity tests use them to force every family over the same data. */
+/* Developer tuning knobs, process-wide ("win" / "direct" / "stream" / "streamq" / "blk" / "up" / "direct_oh": enable a conv kernel
+ * family or form -- "blk" the staged-unit kernel of the block-local level, "up" the scatter form of the inverse conv, "direct_oh" the
+ * gather-once form of the level-1 inverse conv; "win_rows": window rows of the window kernel; "win_min_rows" / "small_rows": row
+ * thresholds; "small_mode": variant of the small-level kernel; "bf16_depth": register prefetch depth 1..4).  Not needed for correct
+ * results; the parity tests use them to force every family over the same data.  Change them only while no launch is in flight. */
 int tl_set_tuning(const char* key, int64_t value);
 const char* tl_error_string(int code);
 
