@@ -43,7 +43,8 @@ int tl_version(void);
  * family or form -- "blk" the staged-unit kernel of the block-local level, "up" the scatter form of the inverse conv, "direct_oh" the
  * gather-once form of the level-1 inverse conv; "win_rows": window rows of the window kernel; "win_min_rows" / "small_rows": row
  * thresholds; "small_mode": variant of the small-level kernel; "bf16_depth": register prefetch depth 1..4).  Not needed for correct
- * results; the parity tests use them to force every family over the same data.  Change them only while no launch is in flight. */
+ * results; the parity tests use them to force every family over the same data.  They are read on the host when a launch is
+ * dispatched (launches already enqueued are unaffected); do not change them while another host thread is inside the library. */
 int tl_set_tuning(const char* key, int64_t value);
 const char* tl_error_string(int code);
 
