@@ -94,8 +94,24 @@ def main():
         assert rc == 0, rc
         return out
 
+    lib2 = None
+    if os.path.exists(os.path.join(HERE, "libproto_l2_v2.so")):          # conv_l2_v2.hip: staging / descriptors / epilogue overlapped with the taps
+        lib2 = ctypes.CDLL(os.path.join(HERE, "libproto_l2_v2.so"))
+        lib2.proto_l2v2_conv.restype = i32
+        lib2.proto_l2v2_conv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    out2 = torch.empty_like(x_new)
+
+    def proto2():
+        rc = lib2.proto_l2v2_conv(x_new.data_ptr(), w._tl_frag.data_ptr(), out2.data_ptr(), halo_t.data_ptr(), nhalo_t.data_ptr(), lrb_t.data_ptr(), n, units, _hip.stream())
+        assert rc == 0, rc
+        return out2
+
     y = ops.conv_fwd(x, w, lv.nbr, n)
     o = proto(False).clone()
+    if lib2 is not None:
+        o2v = proto2().clone(); torch.cuda.synchronize()
+        print("v2 (overlapped): equal to v1: %s (max |diff| to the gather kernel %.3g, rows differing from v1: %d)" % (
+            torch.equal(o2v, o), float((o2v.float() - y.index_select(0, perm_t).float()).abs().max()), int((o2v != o).any(1).sum())), flush=True)
     d = (o.float() - y.index_select(0, perm_t).float()).abs().max()
     print("plain: equal to the gather kernel: %s (max |diff| %.3g, max |y| %.3g)" % (torch.equal(o, y.index_select(0, perm_t)), float(d), float(y.float().abs().max())), flush=True)
     act = ops.affine_relu(x, sc, sh, True)
@@ -110,6 +126,8 @@ def main():
         res["gather kernel, two views"].append(timeit(lambda: ops.conv_fwd(x, w, lv.nbr, n, out2=(o2, sc, sh, True))))
         res["staged prototype"].append(timeit(lambda: proto(False)))
         res["staged prototype + prologue"].append(timeit(lambda: proto(True)))
+        if lib2 is not None:
+            res.setdefault("staged prototype v2 (overlapped)", []).append(timeit(proto2))
     for mode, name in ((1, "no staging"), (2, "one tap instead of 27"), (4, "no output stores"), (3, "no staging, one tap"), (7, "barriers and LDS transposition only")):
         print("ablation %-40s %.3f ms" % (name, timeit(lambda: proto(False, mode))), flush=True)
     for k, v in res.items():
