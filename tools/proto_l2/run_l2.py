@@ -99,6 +99,18 @@ def main():
         lib2 = ctypes.CDLL(os.path.join(HERE, "libproto_l2_v2.so"))
         lib2.proto_l2v2_conv.restype = i32
         lib2.proto_l2v2_conv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    lib3 = None
+    if os.path.exists(os.path.join(HERE, "libproto_l2_v3.so")):          # conv_l2_v3.hip: loader waves fill the other half-row stage
+        lib3 = ctypes.CDLL(os.path.join(HERE, "libproto_l2_v3.so"))
+        lib3.proto_l2v3_conv.restype = i32
+        lib3.proto_l2v3_conv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    out3 = torch.empty_like(x_new)
+
+    def proto3():
+        rc = lib3.proto_l2v3_conv(x_new.data_ptr(), w._tl_frag.data_ptr(), out3.data_ptr(), halo_t.data_ptr(), nhalo_t.data_ptr(), lrb_t.data_ptr(), n, units, _hip.stream())
+        assert rc == 0, rc
+        return out3
+
     out2 = torch.empty_like(x_new)
 
     def proto2():
@@ -114,6 +126,10 @@ def main():
             torch.equal(o2v, o), float((o2v.float() - y.index_select(0, perm_t).float()).abs().max()), int((o2v != o).any(1).sum())), flush=True)
     d = (o.float() - y.index_select(0, perm_t).float()).abs().max()
     print("plain: equal to the gather kernel: %s (max |diff| %.3g, max |y| %.3g)" % (torch.equal(o, y.index_select(0, perm_t)), float(d), float(y.float().abs().max())), flush=True)
+    if lib3 is not None:
+        o3v = proto3().clone(); torch.cuda.synchronize()
+        print("v3 (loader waves): max |diff| to the gather kernel %.3g, rows differing from v2: %s" % (
+            float((o3v.float() - y.index_select(0, perm_t).float()).abs().max()), int((o3v != o2v).any(1).sum()) if lib2 is not None else "-"), flush=True)
     act = ops.affine_relu(x, sc, sh, True)
     ya = ops.conv_fwd(act, w, lv.nbr, n)
     oa = proto(True).clone()
@@ -128,6 +144,8 @@ def main():
         res["staged prototype + prologue"].append(timeit(lambda: proto(True)))
         if lib2 is not None:
             res.setdefault("staged prototype v2 (overlapped)", []).append(timeit(proto2))
+        if lib3 is not None:
+            res.setdefault("staged prototype v3 (loader waves)", []).append(timeit(proto3))
     for mode, name in ((1, "no staging"), (2, "one tap instead of 27"), (4, "no output stores"), (3, "no staging, one tap"), (7, "barriers and LDS transposition only")):
         print("ablation %-40s %.3f ms" % (name, timeit(lambda: proto(False, mode))), flush=True)
     for k, v in res.items():
