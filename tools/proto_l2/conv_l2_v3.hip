@@ -4,7 +4,11 @@
 // the HBM round trips of the DMA pieces.  Here a workgroup has 4 compute waves (one per SIMD, 96 rows x 64 output channels each, as in v1)
 // and 4 loader waves (one per SIMD beside them, a handful of registers): the loaders fill the OTHER half-row stage (and fetch the next
 // unit's halo row ids) while the compute waves run the 27 taps of the current phase; two workgroup barriers per unit hand the stages over.
-// Compute waves only ever wait for their own weight fragments (two taps ahead) and, once per unit, their rulebook rows.
+// Compute waves only ever wait for their own weight fragments (two taps ahead) and, once per unit, their rulebook rows; their accumulator
+// tiles are formed transposed (weights as the MFMA's row operand) so the epilogue stores 8-B pieces straight from registers.
+//
+// RESULT (profiles/r4_final/proto_l2.txt): correct (bit-identical to v2), 0.30-0.31 ms against 0.26-0.28 for the gather kernel with one view;
+// 0.20-0.21 with neither DMAs nor stores, 0.24-0.26 with one of them: the bytes cost their time although nothing waits for them.
 //
 //   hipcc -std=c++20 --offload-arch=gfx950 -O3 -shared -fPIC tools/proto_l2/conv_l2_v3.hip -o tools/proto_l2/libproto_l2_v3.so
 #include <hip/hip_runtime.h>
@@ -29,7 +33,7 @@ constexpr int NQ = POS / 16 / LW;                        // DMA instructions per
 struct P {
   const uint16_t* x; const uint16_t* wfrag; uint16_t* out;
   const int32_t* halo; const int32_t* nhalo; const uint32_t* lrb;
-  int64_t n; int units;
+  int64_t n; int units; int mode;      // mode (timing ablations): 1 the loaders issue no DMA, 4 no output stores
 };
 
 __device__ __forceinline__ u32x4 lds_r128(unsigned a) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); return v; }
@@ -64,7 +68,7 @@ __global__ void __launch_bounds__(NT) k_conv_l2v3(P p) {
         const int64_t r = pos < U ? (int64_t)u * U + pos : (int64_t)hr[i];
         const bool ok = u < p.units && pos < POS - 1 && r >= 0 && r < p.n && (pos < U || hr[i] >= 0);
         const unsigned off = ok ? (unsigned)r * 128u + (unsigned)(h * 64) + (unsigned)((((lane & 3) ^ ((pos >> 1) & 3))) * 16) : 0xFFFFFFFFu;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + h * SB + (lw + LW * i) * 1024), 16, (int)off, 0, 0, 0);
+        if (!(p.mode & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + h * SB + (lw + LW * i) * 1024), 16, (int)off, 0, 0, 0);
       }
     };
     int hrow[NQ], hrown[NQ];
@@ -167,32 +171,27 @@ __global__ void __launch_bounds__(NT) k_conv_l2v3(P p) {
           for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-              acc[t][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a_][t][j]), __builtin_bit_cast(bf16x8, B[b_][nb][j]), acc[t][nb], 0, 0, 0);
+              acc[t][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, B[b_][nb][j]), __builtin_bit_cast(bf16x8, A[a_][t][j]), acc[t][nb], 0, 0, 0);   // (weights as the row operand: the tile comes out transposed)
       }
       if (h == 1) {
         load_rb(un);                                                     // the next unit's rulebook rows, under the epilogue
+        // the accumulator tiles are TRANSPOSED (output channels down the tile, rows across the lanes): lane (fi, fh) holds, for ITS row, the
+        // channels 8 q + 4 fh .. + 4 of the block (q = 0..3) -- four consecutive channels per register quad, stored straight from registers
+        // as 8-B pieces; no LDS transposition, no wave barriers
         const int64_t row0 = (int64_t)u * U;
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MT; ++t) {
+          const int64_t r = row0 + wv * (32 * MT) + t * 32 + fi;
+          if (r < p.n && !(p.mode & 4)) {
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * fh) * 36 + fi] = acc[t][nb][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e0 = 0; e0 < 2; ++e0) {
-              const int rr = (lane >> 2) + 16 * e0, cv = lane & 3;
-              const int64_t r = row0 + wv * (32 * MT) + t * 32 + rr;
-              if (r < p.n) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + rr * 36 + cv * 8), v1 = *reinterpret_cast<const f32x4*>(ew + rr * 36 + cv * 8 + 4);
-                const u32x4 o = {pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
-                *reinterpret_cast<u32x4*>(p.out + r * 64 + nb * 32 + cv * 8) = o;
+              for (int q = 0; q < 4; ++q) {
+                const uint2 o = make_uint2(pack2(acc[t][nb][4 * q], acc[t][nb][4 * q + 1]), pack2(acc[t][nb][4 * q + 2], acc[t][nb][4 * q + 3]));
+                *reinterpret_cast<uint2*>(p.out + r * 64 + nb * 32 + 8 * q + 4 * fh) = o;
               }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
           }
+        }
       }
       __syncthreads();                                                   // stage h is free for the loaders; the other stage is complete
     }
@@ -202,8 +201,8 @@ __global__ void __launch_bounds__(NT) k_conv_l2v3(P p) {
 }  // namespace
 
 extern "C" int proto_l2v3_conv(const void* x, const void* wfrag, void* out, const int32_t* halo, const int32_t* nhalo, const uint32_t* lrb,
-                               int64_t n, int units, void* stream) {
-  P p{(const uint16_t*)x, (const uint16_t*)wfrag, (uint16_t*)out, halo, nhalo, lrb, n, units};
+                               int64_t n, int units, void* stream, int mode) {
+  P p{(const uint16_t*)x, (const uint16_t*)wfrag, (uint16_t*)out, halo, nhalo, lrb, n, units, mode};
   const int lds = 2 * SB + CW * 32 * 36 * 4;
   static bool attr = false;
   if (!attr) {

@@ -103,11 +103,11 @@ def main():
     if os.path.exists(os.path.join(HERE, "libproto_l2_v3.so")):          # conv_l2_v3.hip: loader waves fill the other half-row stage
         lib3 = ctypes.CDLL(os.path.join(HERE, "libproto_l2_v3.so"))
         lib3.proto_l2v3_conv.restype = i32
-        lib3.proto_l2v3_conv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+        lib3.proto_l2v3_conv.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp, i32]
     out3 = torch.empty_like(x_new)
 
-    def proto3():
-        rc = lib3.proto_l2v3_conv(x_new.data_ptr(), w._tl_frag.data_ptr(), out3.data_ptr(), halo_t.data_ptr(), nhalo_t.data_ptr(), lrb_t.data_ptr(), n, units, _hip.stream())
+    def proto3(mode=0):
+        rc = lib3.proto_l2v3_conv(x_new.data_ptr(), w._tl_frag.data_ptr(), out3.data_ptr(), halo_t.data_ptr(), nhalo_t.data_ptr(), lrb_t.data_ptr(), n, units, _hip.stream(), mode)
         assert rc == 0, rc
         return out3
 
@@ -148,6 +148,9 @@ def main():
             res.setdefault("staged prototype v3 (loader waves)", []).append(timeit(proto3))
     for mode, name in ((1, "no staging"), (2, "one tap instead of 27"), (4, "no output stores"), (3, "no staging, one tap"), (7, "barriers and LDS transposition only")):
         print("ablation %-40s %.3f ms" % (name, timeit(lambda: proto(False, mode))), flush=True)
+    if lib3 is not None:
+        for mode, name in ((1, "v3, loaders issue no DMA"), (4, "v3, no output stores"), (5, "v3, neither")):
+            print("ablation %-40s %.3f ms" % (name, timeit(lambda: proto3(mode))), flush=True)
     for k, v in res.items():
         v = sorted(v[1:])
         print("%-32s median %.3f ms (min %.3f max %.3f)" % (k, v[len(v) // 2], v[0], v[-1]), flush=True)
