@@ -485,6 +485,80 @@ int tl_knn_vote_grid(const float* ref_sorted_xyz, const int64_t* ref_sorted_labe
                      const float* q_xyz, int64_t nq, int k, int64_t* out_label, tl_stream_t stream);
 
 
+/* ------------------------------------------------------------------ the whole eval-mode forward behind ONE call
+ * Replaces, per batch of tiles, the body of `model(batch, return_loss=False)` of the reference's tile loop
+ * (tree_learn/util/pipeline.py:86 -> tree_learn/model/tree_learn.py:75-103: voxelize :129-167, input conv :90, UBlock recursion
+ * blocks.py:137-149, output_layer :93, forward_head :97-103) in the reference's DEFAULT configuration (use_feats = use_coords =
+ * False: all-ones voxel features, configs/_modular/model.yaml:5-6).  tl_forward enqueues everything the per-operator entry points
+ * above would be called for -- tl_voxel_point_coords, tl_pyramid_build, tl_blk_build, tl_rulebooks_build, every tl_conv_fwd of the
+ * U-Net in the pre-activated dataflow (BatchNorm + ReLU folded into producer epilogues / the staging prologue, residual adds and the
+ * skip concat as views) and tl_head_mlp -- from C, so that the host cost of a forward no longer depends on the caller's interpreter.
+ * It SYNCHRONISES `stream` twice (grid extent, level counts: two 16-B read-backs, as the per-operator path does).
+ *
+ * The network is described by plain structs of DEVICE pointers the caller keeps alive (weights in the tl_pack_weight layout, `frag` =
+ * the tl_pack_weight_frag copy or NULL, eval-mode BatchNorms as scale / shift); nothing is copied.  All device memory of one forward
+ * -- geometry and activations -- comes out of ONE caller-provided arena; if it is too small the call returns TL_ERR_ARENA with
+ * args->needed_bytes set and nothing useful enqueued (call again with a larger arena).  Outputs are caller-provided and never alias
+ * the arena, so the arena may serve the next forward on the same stream at once. */
+#define TL_MAX_LEVELS 8
+#define TL_ERR_ARENA (-4)        /* arena too small: args->needed_bytes */
+#define TL_ERR_REACH_ZERO (-5)   /* a level's spatial shape or voxel set collapsed (spconv's "reach zero!!!", util/pipeline.py:91-97) */
+#define TL_ERR_EXTENT (-6)       /* the tile's voxel extent exceeds spatial_shape, a batch id is out of range, or a voxel coordinate leaves [0, 65536) */
+typedef struct tl_affine { const float* scale; const float* shift; } tl_affine;
+typedef struct tl_weight { const void* w; const void* frag; int32_t K, Cout, Cin, reserved; } tl_weight;
+typedef struct tl_res_desc {      /* ResidualBlock, blocks.py:42-79 */
+  tl_affine bn0; tl_weight w1; tl_affine bn3; tl_weight w2;
+  tl_weight w1x1;                 /* i_branch: w == NULL = Identity (blocks.py:48-52) */
+  tl_weight w1_half[2];           /* w1 split into its two input-channel halves (2C -> C decoder block on block-local rows), w == NULL = absent */
+} tl_res_desc;
+typedef struct tl_ublock_desc {   /* UBlock, blocks.py:81-149 (block_reps = 2, tree_learn.py:41) */
+  int32_t C; int32_t deeper;
+  tl_res_desc blocks[2];
+  tl_affine bn_down; tl_weight wd;      /* BN, ReLU, SparseConv3d k2 s2 (blocks.py:102-110) */
+  tl_affine bn_up; tl_weight wu;        /* BN, ReLU, SparseInverseConv3d k2 (blocks.py:116-123) */
+  tl_res_desc tail[2];
+  tl_affine bn_cat_l, bn_cat_r;         /* tail[0].bn0 split over the two halves of the skip concat (blocks.py:146) */
+} tl_ublock_desc;
+typedef struct tl_net_desc {
+  int32_t dtype;                  /* TL_F32 | TL_BF16 | TL_F16 */
+  int32_t num_levels;             /* 2 .. TL_MAX_LEVELS */
+  float voxel_size;
+  int32_t has_shape; int32_t spatial_shape[3];   /* tree_learn.py:86-87 override; has_shape = 0: the tile's own extent (:165) */
+  int32_t blocked;                /* != 0: level 1 may run in the block-local order (16-bit, C = 32) */
+  int32_t in_channels;            /* dim_coord + dim_feat of the all-ones input (tree_learn.py:38) */
+  tl_weight w_in;                 /* input conv, tree_learn.py:37-39 */
+  tl_ublock_desc u[TL_MAX_LEVELS];
+  tl_affine out_bn;               /* output_layer, tree_learn.py:42 */
+  const float* head_w1; const float* head_b1; const float* head_w2; const float* head_b2;   /* as tl_head_mlp takes them */
+} tl_net_desc;
+typedef struct tl_launch_rec {    /* one conv launch of a profiled forward */
+  int32_t level, kind;            /* kind: 0 = SubM (27 taps), 1 = stride-2, 2 = inverse, 3 = 1x1, 4 = input conv */
+  int32_t K, Cin, Cout, residual, esize, split_part, split_cin, in_prologue;
+  int64_t n_out, n_in;
+  float ms;
+} tl_launch_rec;
+typedef struct tl_forward_args {
+  const float* xyz; const int64_t* batch_ids; int64_t N; int32_t B; int32_t reserved;
+  void* arena; int64_t arena_bytes;
+  float* backbone;                /* f32[N, C] or NULL */
+  float* logits; float* offsets;  /* f32[N, 2], f32[N, 3] */
+  tl_stream_t side_stream;        /* optional: the block-local unit builder runs there beside the other levels' rulebook kernels */
+  int64_t needed_bytes;           /* out */
+  int64_t level_n[TL_MAX_LEVELS]; /* out: active voxels per level */
+  int32_t blocked_used;           /* out */
+  int32_t launches;               /* out: tl_conv_fwd launches enqueued */
+} tl_forward_args;
+typedef struct tl_exec tl_exec;   /* host-side context of a caller thread / stream: pinned read-back words, two events, profile storage */
+tl_exec* tl_exec_create(void);
+void tl_exec_destroy(tl_exec* ex);
+int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* args, tl_stream_t stream);
+/* Live per-launch timing of the NEXT tl_forward calls on this context (HIP events on the launch stream around every conv launch;
+ * enable = 0 stops).  tl_exec_profile_read waits for the last profiled forward and returns its launches (<= cap; return value = their
+ * number, negative = error). */
+int tl_exec_profile(tl_exec* ex, int enable);
+int tl_exec_profile_read(tl_exec* ex, tl_launch_rec* recs, int cap);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+"""tl_forward (the C-side forward executor, csrc/tl_exec.hip) against the Python-driven engine (model/engine.py): the same launches with
+the same arguments, so every output must be BIT-identical -- and, through the engine's own tests, equal to the oracle.  The reference
+call this replaces: `model(batch, return_loss=False)` in the tile loop (tree_learn/util/pipeline.py:86)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dtype, channels=32, num_blocks=7, spatial_shape=(500, 500, 1000), voxel=0.1, seed=7):
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import random_state_dict
+    m = TreeLearn(channels=channels, num_blocks=num_blocks, use_feats=False, use_coords=False, spatial_shape=list(spatial_shape) if spatial_shape else None,
+                  voxel_size=voxel, compute_dtype=dtype)
+    m.load_state_dict(random_state_dict(seed, channels=channels, num_blocks=num_blocks), strict=True)
+    return m.cuda().eval()
+
+
+def _batch(tiles):
+    from treelearn_amd.synth import make_batch
+    b = make_batch(tiles)
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def _both(model, gb):
+    """(executor outputs, Python-engine outputs, executor) of the same forward."""
+    with torch.no_grad():
+        ex = model._executor(model.active_dtype(False))
+        assert ex is not None, "this configuration must be served by tl_forward"
+        out_c = model(gb, return_loss=False)
+        os.environ["TL_EXEC"] = "0"
+        try:
+            assert model._executor(model.active_dtype(False)) is None
+            out_p = model(gb, return_loss=False)
+        finally:
+            del os.environ["TL_EXEC"]
+    torch.cuda.synchronize()
+    return out_c, out_p, ex
+
+
+def _assert_equal(out_c, out_p):
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert out_c[k].shape == out_p[k].shape and out_c[k].dtype == out_p[k].dtype, k
+        a, b = out_c[k], out_p[k]                       # (float16 on random-init weights overflows in places: inf / nan must agree too)
+        same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same.all()), f"{k}: executor and Python-driven engine differ in {int((~same).sum())} elements"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_exec_equals_engine_on_a_blocked_tile(dtype):
+    """A 16 m tile (0.29 M voxels: level 1 in the block-local order for the 16-bit types, canonical in fp32)."""
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=16.0, voxel=0.1, n_trees=10, fill=0.1, seed=3)])
+    m = _model(dtype)
+    out_c, out_p, ex = _both(m, gb)
+    _assert_equal(out_c, out_p)
+    assert ex.last["blocked"] == (dtype != torch.float32)
+    assert ex.last["launches"] == 72 if ex.last["blocked"] else ex.last["launches"] == 71
+    assert dtype == torch.float16 or all(bool(torch.isfinite(out_c[k]).all()) for k in out_c)
+
+
+def test_exec_equals_engine_small_tile_and_batch_of_two():
+    """Below BLK_MIN_ROWS the 16-bit forward stays canonical; a batch of two tiles; spatial_shape = None (the tile's own extent)."""
+    from treelearn_amd.synth import make_tile
+    tiles = [make_tile(extent=6.0, voxel=0.1, n_trees=2, fill=0.1, seed=s) for s in (1, 2)]
+    for shape in ((500, 500, 1000), None):
+        m = _model(torch.bfloat16, num_blocks=5, spatial_shape=shape)
+        for gb in (_batch(tiles[:1]), _batch(tiles)):
+            out_c, out_p, ex = _both(m, gb)
+            _assert_equal(out_c, out_p)
+            assert ex.last["blocked"] == (ex.last["level_n"][0] >= 16384)
+
+
+def test_exec_other_widths_and_depths():
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=10.0, voxel=0.1, n_trees=4, fill=0.1, seed=5)])
+    for ch, nb in ((16, 3), (64, 2), (32, 4)):
+        m = _model(torch.bfloat16, channels=ch, num_blocks=nb)
+        out_c, out_p, _ = _both(m, gb)
+        _assert_equal(out_c, out_p)
+
+
+def test_exec_without_backbone_and_repeated_calls_reuse_the_arena():
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=9)])
+    m = _model(torch.bfloat16)
+    out_c, out_p, ex = _both(m, gb)
+    _assert_equal(out_c, out_p)
+    arena = next(iter(ex._ctx.values()))[1]
+    ptr0, size0 = arena.data_ptr(), arena.numel()
+    assert ex.last["arena_bytes"] <= size0
+    m.return_backbone_feats = False
+    with torch.no_grad():
+        o2 = m(gb, return_loss=False)
+    assert o2["backbone_feats"] is None and torch.equal(o2["offset_predictions"], out_c["offset_predictions"])
+    arena = next(iter(ex._ctx.values()))[1]
+    assert (arena.data_ptr(), arena.numel()) == (ptr0, size0)
+    # a larger tile grows the arena, results stay right
+    gb2 = _batch([make_tile(extent=20.0, voxel=0.1, n_trees=14, fill=0.1, seed=11)])
+    m.return_backbone_feats = True
+    out_c2, out_p2, _ = _both(m, gb2)
+    _assert_equal(out_c2, out_p2)
+    out_c3, _, _ = _both(m, gb)                      # ... and the small tile still gives what it gave
+    _assert_equal(out_c3, out_c)
+
+
+def test_exec_on_side_streams_in_flight():
+    """Four forwards in flight on four streams (what the tile loop and bench.py do): every stream has its own context and arena."""
+    from treelearn_amd.synth import make_tile
+    gbs = [_batch([make_tile(extent=12.0, voxel=0.1, n_trees=5, fill=0.1, seed=20 + i)]) for i in range(4)]
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        ref = [m(g, return_loss=False) for g in gbs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        outs = [None] * 8
+        for i in range(8):
+            with torch.cuda.stream(streams[i % 4]):
+                outs[i] = m(gbs[i % 4], return_loss=False)
+        torch.cuda.synchronize()
+    for i in range(8):
+        _assert_equal(outs[i], ref[i % 4])
+    assert len(m._plan._exec._ctx) == 5
+
+
+def test_exec_raises_reach_zero_like_the_engine():
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=3.0, voxel=0.1, n_trees=1, fill=0.1, seed=0)])
+    m = _model(torch.bfloat16, spatial_shape=None)
+    with pytest.raises(ValueError, match="reach zero!!!"), torch.no_grad():
+        m(gb, return_loss=False)
+    m2 = _model(torch.bfloat16, spatial_shape=(16, 16, 16))
+    with pytest.raises(ValueError, match="exceeds spatial_shape"), torch.no_grad():
+        m2(gb, return_loss=False)
+
+
+def test_exec_profile_records_every_launch():
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=16.0, voxel=0.1, n_trees=10, fill=0.1, seed=3)])
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        m(gb, return_loss=False)
+        ex = m._plan._exec
+        ex.profile(True)
+        m(gb, return_loss=False)
+        recs = ex.profile_read()
+        ex.profile(False)
+    assert len(recs) == ex.last["launches"] == 72
+    assert all(r["ms"] > 0 for r in recs)
+    assert sum(r["kind"] == "subm" for r in recs) == 52 + 1 and sum(r["kind"] == "input" for r in recs) == 1     # 53 SubM convs: the input conv + 52, the level-1 64 -> 32 one as two launches
+    assert sum(r["kind"] == "down" for r in recs) == 6 and sum(r["kind"] == "inverse" for r in recs) == 6 and sum(r["kind"] == "1x1" for r in recs) == 6
+    # the same launches the Python-driven engine reports to bench.py
+    from treelearn_amd import ops
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            m(gb, return_loss=False)
+        torch.cuda.synchronize()
+        py = [meta for _, _, meta in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert [(r["K"], r["Cin"], r["Cout"], r["n_out"], r["n_in"], r["residual"], r["split"]) for r in recs] == \
+           [(p["K"], p["Cin"], p["Cout"], p["n_out"], p["n_in"], p["residual"], p["split"]) for p in py]
+
+
+def test_exec_config2_full_tile():
+    """The headline tile (1.89 M points): bit-identical to the Python-driven engine, which tests/test_gpu_configs.py holds against the oracle."""
+    from treelearn_amd.synth import CONFIGS, make_tile
+    gb = _batch([make_tile(**CONFIGS["config2"], seed=0)])
+    m = _model(torch.bfloat16)
+    out_c, out_p, ex = _both(m, gb)
+    _assert_equal(out_c, out_p)
+    assert ex.last["blocked"] and ex.last["level_n"][0] > 1_800_000

@@ -58,6 +58,44 @@ class HdbGrid(_c.Structure):               # TlHdbGrid
     _fields_ = [("lo", _c.c_double * 2), ("h", _c.c_double), ("levels", _c.c_int32), ("reserved", _c.c_int32)]
 
 
+TL_MAX_LEVELS = 8
+TL_ERR_ARENA, TL_ERR_REACH_ZERO, TL_ERR_EXTENT = -4, -5, -6
+
+
+class Affine(_c.Structure):                # tl_affine
+    _fields_ = [("scale", _vp), ("shift", _vp)]
+
+
+class Weight(_c.Structure):                # tl_weight
+    _fields_ = [("w", _vp), ("frag", _vp), ("K", _i32), ("Cout", _i32), ("Cin", _i32), ("reserved", _i32)]
+
+
+class ResDesc(_c.Structure):               # tl_res_desc
+    _fields_ = [("bn0", Affine), ("w1", Weight), ("bn3", Affine), ("w2", Weight), ("w1x1", Weight), ("w1_half", Weight * 2)]
+
+
+class UBlockDesc(_c.Structure):            # tl_ublock_desc
+    _fields_ = [("C", _i32), ("deeper", _i32), ("blocks", ResDesc * 2), ("bn_down", Affine), ("wd", Weight), ("bn_up", Affine), ("wu", Weight),
+                ("tail", ResDesc * 2), ("bn_cat_l", Affine), ("bn_cat_r", Affine)]
+
+
+class NetDesc(_c.Structure):               # tl_net_desc
+    _fields_ = [("dtype", _i32), ("num_levels", _i32), ("voxel_size", _f32), ("has_shape", _i32), ("spatial_shape", _i32 * 3), ("blocked", _i32),
+                ("in_channels", _i32), ("w_in", Weight), ("u", UBlockDesc * TL_MAX_LEVELS), ("out_bn", Affine),
+                ("head_w1", _vp), ("head_b1", _vp), ("head_w2", _vp), ("head_b2", _vp)]
+
+
+class LaunchRec(_c.Structure):             # tl_launch_rec
+    _fields_ = [("level", _i32), ("kind", _i32), ("K", _i32), ("Cin", _i32), ("Cout", _i32), ("residual", _i32), ("esize", _i32), ("split_part", _i32),
+                ("split_cin", _i32), ("in_prologue", _i32), ("n_out", _i64), ("n_in", _i64), ("ms", _f32)]
+
+
+class ForwardArgs(_c.Structure):           # tl_forward_args
+    _fields_ = [("xyz", _vp), ("batch_ids", _vp), ("N", _i64), ("B", _i32), ("reserved", _i32), ("arena", _vp), ("arena_bytes", _i64),
+                ("backbone", _vp), ("logits", _vp), ("offsets", _vp), ("side_stream", _vp), ("needed_bytes", _i64),
+                ("level_n", _i64 * TL_MAX_LEVELS), ("blocked_used", _i32), ("launches", _i32)]
+
+
 _I4 = _i32 * 4
 _I3 = _i32 * 3
 
@@ -84,6 +122,11 @@ PROTOTYPES = {
     "tl_blk_build": (_i32, [_vp, _vp, _I4, _i64, _c.POINTER(Blk), _vp, _i32, _vp]),
     "tl_conv_fwd": (_i32, [_c.POINTER(ConvArgs), _vp]),
     "tl_conv_red_parts": (_i64, [_i64]),
+    "tl_exec_create": (_vp, []),
+    "tl_exec_destroy": (None, [_vp]),
+    "tl_forward": (_i32, [_vp, _c.POINTER(NetDesc), _c.POINTER(ForwardArgs), _vp]),
+    "tl_exec_profile": (_i32, [_vp, _i32]),
+    "tl_exec_profile_read": (_i32, [_vp, _c.POINTER(LaunchRec), _i32]),
     "tl_bn_train_finish": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_bn_train_bwd_from_parts": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -20,6 +20,13 @@ COMPACT_MIN_ROWS = 65536       # levels from this size on also get the column fo
 BLK_MIN_ROWS = 16384        # below this the level-1 convs run on the small-level kernel anyway (tl_conv_fwd's small_rows)
 BLK_MAX_ROWS = (1 << 25) - 64
 BLK_HALO_MAX = 126
+TRACE = None                # developer: a list -> build_geometry appends (phase, time.perf_counter()) marks (tools/dev_fwd_host.py)
+
+
+def _mark(name):
+    if TRACE is not None:
+        import time
+        TRACE.append((name, time.perf_counter()))
 
 
 class BlockedRulebook:
@@ -213,7 +220,9 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     ws_mm = torch.empty(batch_size * 6, dtype=torch.int32, device=dev)
     _hip.check(L.tl_voxel_point_coords(_hip.ptr(coords), _hip.ptr(batch_ids), N, batch_size, float(voxel_size),
                                        _hip.ptr(ws_mm), _hip.ptr(pcoords), _hip.ptr(maxc), st), "tl_voxel_point_coords")
+    _mark("enqueue point coords")
     mx = maxc.tolist()                                     # host sync #1
+    _mark("host sync #1 (extent) returned")
     if mx[3]:
         raise ValueError("voxelize: batch id out of range or voxel coordinate outside [0, 65536)")
     extent = (mx[0] + 1, mx[1] + 1, mx[2] + 1)
@@ -238,7 +247,9 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
     p0 = pyr.data_ptr()
     _hip.check(L.tl_pyramid_build(_hip.ptr(pcoords), N, _hip.dims4(dims[0]), _hip.dims3(shapes[0]), num_levels,
                                   p0, p0 + 8 * tw, p0 + 12 * tw, p0 + 12 * tw + 32, st), "tl_pyramid_build")
+    _mark("enqueue pyramid")
     ns = pyr[3 * tw:3 * tw + num_levels].tolist()          # host sync #2
+    _mark("host sync #2 (level counts) returned")
     bm_all = pyr[:2 * tw].view(torch.int64)
     pf_all = pyr[2 * tw:3 * tw]
     levels = []
@@ -317,6 +328,7 @@ def build_geometry(coords: torch.Tensor, batch_ids: torch.Tensor, batch_size: in
         # (no record_stream: the main stream waits for the side stream right here, before anything that could free or re-use the buffers
         # is enqueued on it; recording would make the caching allocator hold every geometry block until an event query, i.e. allocate anew)
         main.wait_stream(side)
+    _mark("layout + enqueue blk / rulebooks")
     v2p = back[o_v2p:o_v2p + 2 * N].view(torch.int64)
     for li, lv in enumerate(levels):
         y = lay[li]

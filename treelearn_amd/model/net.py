@@ -99,7 +99,28 @@ class TreeLearn(nn.Module):
         return super()._apply(fn, *a, **k)
 
     # ------------------------------------------------------------------ forward
+    def _executor(self, dtype):
+        """The C-side forward executor of the current plan (model/executor.py), or None when this configuration stays on the
+        Python-driven engine."""
+        from .executor import Executor
+        if self._plan is None or self._plan.dtype != dtype:
+            self._plan = InferencePlan(self, dtype)
+        ex = getattr(self._plan, "_exec", False)
+        if ex is False:
+            ex = self._plan._exec = Executor(self._plan, self) if Executor.supported(self._plan, self) else None
+        return ex if (ex is not None and Executor.env_default()) else None
+
     def forward(self, batch, return_loss):
+        if not return_loss and not (self.training or torch.is_grad_enabled()) and torch.is_tensor(batch['coords']):
+            # eval forward in the reference's default configuration: ONE call into the library per tile (tl_forward) -- geometry, the 72
+            # conv launches and the heads are enqueued from C; the module-by-module path below issues the same launches from Python
+            ex = self._executor(self.active_dtype(False))
+            if ex is not None:
+                mv = lambda t: t if t.is_cuda else t.cuda(non_blocking=True)                         # noqa: E731
+                coords = mv(batch['coords']).float().contiguous()
+                bids = mv(batch['batch_ids']).long().contiguous()
+                bb, logits, offsets = ex.forward(coords, bids, int(batch['batch_size']), want_backbone=self.return_backbone_feats)
+                return dict(backbone_feats=bb, semantic_prediction_logits=logits, offset_predictions=offsets)
         # only the tensors the backbone reads cross PCIe here (the reference's cuda_cast also ships every label /
         # mask / centre tensor of the batch, ~80 MB per tile that inference never touches; util/train.py:28-43)
         backbone_output, v2p_map = self.forward_backbone(coords=batch['coords'], input_feats=batch['input_feats'],
