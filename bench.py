@@ -37,13 +37,15 @@ PEAK_HBM_GBS = 8000.0
 def conv_work(meta):
     """Algorithmic work of one conv launch (SURVEY.md §8d): flops = 2*pairs*Cin*Cout;
     compulsory bytes = (N_in*Cin + N_out*Cout [+ N_out*Cout residual]) * e + 8*pairs."""
-    t = meta["table"]
-    if t is None:
+    t = meta.get("table")
+    if "pairs" in meta:                                      # launch records of the C-side executor: pairs counted per (level, kind) beforehand
+        pairs = meta["pairs"]
+    elif t is None:
         pairs = meta["n_out"]
     elif hasattr(t, "count_pairs"):                          # block-local form of a rulebook (geometry.BlockedRulebook)
-        pairs = _PAIRS.get(id(t))
+        pairs = getattr(t, "_bench_pairs", None)              # cached ON the object (an id()-keyed cache would outlive the rulebook)
         if pairs is None:
-            pairs = _PAIRS[id(t)] = t.count_pairs()
+            pairs = t._bench_pairs = t.count_pairs()
     else:
         pairs = int((t >= 0).sum())
     e = meta["esize"]
@@ -59,7 +61,49 @@ def conv_work(meta):
     return flops, byts, pairs
 
 
-_PAIRS = {}
+def conv_event_pass(model, gbatch, reps):
+    """Live per-launch timing of the conv launches of `reps` lone forwards of `model` on `gbatch`, HIP events on the launch stream around
+    every launch.  The product path is measured: when the forward runs through the C-side executor (tl_forward) its own event recorder
+    is switched on (tl_exec_profile) and the rulebook pair counts of the same tile come from one separately built geometry; a
+    configuration that stays on the Python-driven engine is timed through ops.PROFILE.  Returns [[(ms, meta), ...] per forward]."""
+    from treelearn_amd import ops
+
+    def step():
+        with torch.no_grad():
+            return model(gbatch, return_loss=False)
+    step(); torch.cuda.synchronize()
+    ex = model._executor(model.active_dtype(False)) if hasattr(model, "_executor") else None
+    out = []
+    if ex is not None:
+        with torch.no_grad():
+            _, geom = model._voxelize(gbatch["coords"].float(), gbatch["input_feats"].float(), gbatch["batch_ids"].long(), gbatch["batch_size"])
+        pairs = {}
+        for li, lv in enumerate(geom.levels):
+            pairs[(li, "subm")] = int((lv.nbr >= 0).sum())
+            if lv.child is not None:
+                pairs[(li, "down")] = pairs[(li, "inverse")] = int((lv.child >= 0).sum())
+        pairs[(0, "input")] = pairs[(0, "subm")]
+        del geom
+        ex.profile(True)
+        try:
+            step(); torch.cuda.synchronize()
+            for _ in range(reps):
+                step()
+                recs = ex.profile_read()
+                for r in recs:
+                    r["pairs"] = r["n_out"] if r["kind"] == "1x1" else pairs[(r["level"], r["kind"])]
+                out.append([(r["ms"], r) for r in recs])
+        finally:
+            ex.profile(False)
+        return out
+    for _ in range(reps):
+        ops.PROFILE = []
+        try:
+            step(); torch.cuda.synchronize()
+            out.append([(e0.elapsed_time(e1), m) for e0, e1, m in ops.PROFILE])
+        finally:
+            ops.PROFILE = None
+    return out
 
 
 def host_cores():
@@ -239,12 +283,8 @@ def training_step_bench(args, rank, world, dist):
     if rank != 0:
         return None
     # algorithmic conv flops of one step: forward + dgrad + wgrad = 3 x (2 * pairs * Cin * Cout) over the 71 conv launches
-    ops.PROFILE = []
     model.eval()
-    with torch.no_grad():
-        model(gb, return_loss=False)
-    torch.cuda.synchronize()
-    fl = sum(conv_work(m)[0] for _, _, m in ops.PROFILE); ops.PROFILE = None
+    fl = sum(conv_work(m)[0] for _, m in conv_event_pass(model, gb, 1)[0])
     model.train()
     sec = dt / args.steps
     peak = PEAK_MFMA_F32_TFLOPS if args.dtype == "fp32" else PEAK_MFMA_BF16_TFLOPS
@@ -307,13 +347,12 @@ def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
     run(max(nfl, 1)); torch.cuda.synchronize()
     run(max(warmup, 1)); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(steps); torch.cuda.synchronize(); sec = (time.perf_counter() - t0) / steps
-    ops.PROFILE = []; step(); torch.cuda.synchronize(); ops.PROFILE = []
+    recs = conv_event_pass(model, gb, 1)[0]
     last = step(); torch.cuda.synchronize()
-    recs = ops.PROFILE; ops.PROFILE = None
     nonfinite = sum(int((~torch.isfinite(last[k])).sum()) for k in ("semantic_prediction_logits", "offset_predictions"))
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+    ms = sum(t for t, _ in recs)
     fl = by = 0.0
-    for _, _, m in recs:
+    for _, m in recs:
         f, b, _ = conv_work(m); fl += f; by += b
     ach = by / (ms * 1e-3) / 1e9
     out = dict(value=n_pts / sec / 1e6, unit="Mpoints/s", ms_per_step=sec * 1e3, steps=steps, warmup=warmup, dtype=dtype_name, tiles_in_flight=nfl,
@@ -323,6 +362,8 @@ def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
                roofline=dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, launches_per_step=len(recs),
                              conv_ms_per_step=ms, algorithmic_gb_per_step=by / 1e9, mfma_tflops=fl / (ms * 1e-3) / 1e12))
     del model, gb
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     return out
 
@@ -494,18 +535,12 @@ def main():
     # live per-kernel timing of the conv launches (separate pass: event pairs perturb the pipeline)
     roof = None
     if rank == 0:
-        ops.PROFILE = []
-        step(); torch.cuda.synchronize()
-        ops.PROFILE = []
         reps = 3
-        for _ in range(reps):
-            step()
-        torch.cuda.synchronize()
-        recs = ops.PROFILE; ops.PROFILE = None
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / reps
-        per = len(recs) // reps
+        passes = conv_event_pass(model, gbatch, reps)
+        per = len(passes[0])
+        tot_ms = sum(t for ps in passes for t, _ in ps) / reps
         flops = byts = 0.0
-        for _, _, m in recs[:per]:
+        for _, m in passes[0]:
             f, b, _ = conv_work(m); flops += f; byts += b
         avg_ms = tot_ms / per
         if args.layer_table:
@@ -516,8 +551,8 @@ def main():
                 f.write("#  i   K  Cin->Cout     rows  pairs/row      ms  TFLOP/s(present)  dense-equiv %of 2.5PF  compulsory GB  GB/s  t_mfma@2.5PF  t_hbm@8TB/s (ms)\n")
                 lo = 0.0
                 for i in range(per):
-                    m = recs[i][2]
-                    ms = sum(recs[i + r * per][0].elapsed_time(recs[i + r * per][1]) for r in range(reps)) / reps
+                    m = passes[0][i][1]
+                    ms = sum(passes[r][i][0] for r in range(reps)) / reps
                     fl, by, pairs = conv_work(m)
                     dense = 2.0 * ((m["n_out"] + 31) // 32 * 32) * m["K"] * m["Cin"] * m["Cout"]
                     t_m, t_h = dense / (PEAK_MFMA_BF16_TFLOPS * 1e12) * 1e3, by / (PEAK_HBM_GBS * 1e9) * 1e3
@@ -562,16 +597,21 @@ def main():
             res["one_tile_at_a_time"] = dict(value=n_pts / d1 / 1e6, unit="Mpoints/s", ms_per_step=d1 * 1e3)
         # SURVEY.md 8d's latency definition next to the throughput `value`: wall time of ONE model(batch, return_loss=False), device-resident
         # input to device-resident outputs, strictly sequential (a device synchronisation after every forward), median of 24
-        lat = []
+        lat, enq = [], []
         with torch.no_grad():
             for _ in range(3): step()
             torch.cuda.synchronize()
             for _ in range(24):
-                t1 = time.perf_counter(); step(); torch.cuda.synchronize(); lat.append((time.perf_counter() - t1) * 1e3)
-        lat.sort()
+                t1 = time.perf_counter(); step(); t2 = time.perf_counter(); torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3); enq.append((t2 - t1) * 1e3)
+        lat.sort(); enq.sort()
         res["latency_ms_median"] = 0.5 * (lat[11] + lat[12])
+        ex = model._executor(model.active_dtype(False))
         res["latency"] = dict(median_ms=res["latency_ms_median"], min_ms=lat[0], max_ms=lat[-1], forwards=24,
-                              definition="one model(batch, return_loss=False) on device-resident input, torch.cuda.synchronize() after each (SURVEY.md 8d)")
+                              host_enqueue_ms_median=0.5 * (enq[11] + enq[12]),
+                              launch_path="tl_forward: one C-ABI call per tile enqueues geometry + convs + heads" if ex is not None else "Python-driven engine: one ctypes call per launch",
+                              definition="one model(batch, return_loss=False) on device-resident input, torch.cuda.synchronize() after each (SURVEY.md 8d); "
+                                         "host_enqueue = time until the call returns (includes the two geometry read-backs)")
         if world == 1 and args.dtype in ("bf16", "fp16") and not args.no_fp32_mode:
             # the fp32 parity mode (the precision the 1e-3 parity gate is checked in), same tile, for reference
             m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype=torch.float32)

@@ -422,3 +422,22 @@ def test_inverse_conv_scatter_form_equals_gather_form(dtype):
                 assert float(outs[1][0].float().abs().max()) > 0.1
                 served += 1
     assert served == 16
+
+
+def test_no_ones_table_knob_with_a_blocked_geometry(monkeypatch):
+    """TL_NO_ONES_TABLE=1 is documented as a knob that leaves the output unchanged: with the default flags (all-ones input, block-local
+    level 1, no canonical table built) the forward must run and give the same result (advisor, round 4)."""
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    b = make_batch([make_tile(extent=14.0, voxel=0.1, n_trees=8, fill=0.1, seed=4)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
+    m.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); m = m.cuda().eval()
+    with torch.no_grad():
+        ref = m(gb, return_loss=False)
+        monkeypatch.setenv("TL_NO_ONES_TABLE", "1")
+        out = m(gb, return_loss=False)                      # (the knob also keeps the forward on the Python-driven engine)
+        bb, v2p = m.forward_backbone(coords=gb["coords"], input_feats=gb["input_feats"], batch_ids=gb["batch_ids"], batch_size=1)
+        out2 = m.forward_head(bb, v2p)
+    for k in ("semantic_prediction_logits", "offset_predictions", "backbone_feats"):
+        assert torch.equal(ref[k], out[k]) and torch.equal(ref[k], out2[k])

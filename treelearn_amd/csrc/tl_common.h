@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/treelearn_hip.h"
 
 #define TL_CHECK_LAUNCH()                                   \
@@ -10,6 +11,22 @@
   } while (0)
 
 static inline hipStream_t tl_s(tl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute of a kernel: remembered per kernel instantiation (one static
+// TlAttrOnce in its launcher) and per device ordinal, so that a process that drives several GPUs sets it on each of them.
+struct TlAttrOnce {
+  std::atomic<uint64_t> done[4];                  // device ordinals 0..255
+};
+static inline bool tl_lds_attr(TlAttrOnce& once, const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::atomic<uint64_t>& w = once.done[(dev >> 6) & 3];
+  const uint64_t bit = 1ull << (dev & 63);
+  if (w.load(std::memory_order_acquire) & bit) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  w.fetch_or(bit, std::memory_order_release);
+  return true;
+}
 
 static inline int64_t tl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -188,12 +188,8 @@ __global__ void __launch_bounds__(256) k_conv_mfma_f32(ConvP p) {
 template <int NB>
 int launch_mfma_f32(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)p.K * TM * 4 + 16 + 2 * (size_t)TM * LDA * 4 + 2 * (size_t)NB * 32 * LDA * 4;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma_f32<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_mfma_f32<NB>), 160 * 1024)) return TL_ERR_LAUNCH;
   k_conv_mfma_f32<NB><<<p.nblk, 256, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }

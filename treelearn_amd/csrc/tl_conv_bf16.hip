@@ -280,12 +280,8 @@ int launch_b(const ConvP& p, hipStream_t s) {
   const size_t epi_b = 4 * (size_t)32 * (NB * 32 + 4) * 4;
   const size_t lds = (size_t)p.K * TM * 4 + 128 + (size_t)p.Cin * 8 + (main_b > epi_b ? main_b : epi_b);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<NB, U, D, BUF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_bf16<NB, U, D, BUF>), 160 * 1024)) return TL_ERR_LAUNCH;
   k_conv_bf16<NB, U, D, BUF><<<p.nblk, 256, lds, s>>>(p);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
@@ -297,8 +293,8 @@ int launch(const ConvP& p, hipStream_t s) {
     constexpr int PITCH = 32 * U * 2 + 16;
     const size_t main_b = 2 * (size_t)TM * PITCH + 2 * (size_t)NB * 32 * PITCH, epi_b = 4 * (size_t)32 * (NB * 32 + 4) * 4;
     const size_t lds = (size_t)p.K * TM * 4 + 128 + (size_t)p.Cin * 8 + (main_b > epi_b ? main_b : epi_b);
-    if (g_abl == 1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<2, 2, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); k_conv_bf16<2, 2, 2, true, 1><<<p.nblk, 256, lds, s>>>(p); }
-    else { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<2, 2, 2, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); k_conv_bf16<2, 2, 2, true, 2><<<p.nblk, 256, lds, s>>>(p); }
+    if (g_abl == 1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<2, 2, 2, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); k_conv_bf16<2, 2, 2, true, 1><<<p.nblk, 256, lds, s>>>(p); }
+    else { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf16<2, 2, 2, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); k_conv_bf16<2, 2, 2, true, 2><<<p.nblk, 256, lds, s>>>(p); }
     return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
   }
   // buffer-resource gathers need the whole input view below 4 GB (32-bit offsets)

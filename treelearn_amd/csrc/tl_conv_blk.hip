@@ -432,12 +432,8 @@ template <int W, bool RES, int NV, bool TR = false, bool PRO = false>
 int launch_blk(const ConvP& p, hipStream_t s) {
   constexpr size_t lds = (size_t)WS_B + AFF_B + (size_t)W * STAGE_B + (TR ? (size_t)W * 2 * 32 * 8 : 0);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV, TR, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_blk<W, RES, NV, TR, PRO>), 160 * 1024)) return TL_ERR_LAUNCH;
   k_conv_blk<W, RES, NV, TR, PRO><<<256, W * 64, lds, s>>>(p);
   if (TR && p.red_nparts) *p.red_nparts = 256;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;

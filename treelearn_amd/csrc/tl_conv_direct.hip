@@ -456,12 +456,8 @@ int launch(const ConvP& p, hipStream_t s) {
   constexpr int UB = BF16 ? 64 : 128;
   const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4 + (TR ? (size_t)WAVES * 2 * NB * 32 * 8 : 0);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH>), 160 * 1024)) return TL_ERR_LAUNCH;
   const int ntiles = (int)tl_cdiv(p.n_out, 32);
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);

@@ -212,12 +212,8 @@ int launch(ConvP p, hipStream_t s) {
   const size_t wt = 2 * (size_t)NB * 32 * (UN * 32 * EB + 16), ep = (size_t)WAVES * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH>), 160 * 1024)) return TL_ERR_LAUNCH;
   p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32 * RB);
   k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH><<<p.nblk, NT, lds, s>>>(p);
   if (p.red_nparts) *p.red_nparts = p.nblk;

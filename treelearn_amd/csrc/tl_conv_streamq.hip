@@ -255,12 +255,8 @@ int launch(ConvP p, hipStream_t s) {
   const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)W * K * 32 * RB * 4, ep = (size_t)W * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP>), 160 * 1024)) return TL_ERR_LAUNCH;
   p.nblk = (int)tl_cdiv(p.n_out, W * 32 * RB);
   k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP><<<p.nblk, W * 64, lds, s>>>(p);
   if (p.red_nparts) *p.red_nparts = p.nblk;

@@ -106,12 +106,8 @@ template <int NBI, int NBO, int WAVES>
 int launch_up(const ConvP& p, const int32_t* child, hipStream_t s) {
   const size_t lds = (size_t)8 * NBO * NBI * 2 * 1024 + (size_t)WAVES * 32 * 36 * 4;
   static_assert(8 * NBO * NBI * 2 * 1024 + WAVES * 32 * 36 * 4 <= 160 * 1024, "weights + epilogue tiles must fit the LDS");
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_up<NBI, NBO, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_up<NBI, NBO, WAVES>), 160 * 1024)) return TL_ERR_LAUNCH;
   const int ntiles = (int)tl_cdiv(p.n_in, 32);
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int grid = 256 * (per_cu > 4 ? 4 : per_cu);

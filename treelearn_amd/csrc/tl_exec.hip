@@ -5,7 +5,7 @@
 // every rulebook, 72 sparse convs in the pre-activated dataflow (BatchNorm + ReLU in producer epilogues or applied at staging, residual
 // adds and the skip concat as views; blocks.py:55-79,137-149) and the fused heads.  Driven from Python that is ~80 ctypes calls with ~60
 // field stores each plus a tensor allocation per launch; here it is one call: the layout arithmetic between the two read-backs takes
-// microseconds, activations come out of the caller's arena through a size-keyed free list (planned by a dry run of the same code, so
+// microseconds, activations come out of the caller's arena through a best-fit free list (planned by a dry run of the same code, so
 // `needed_bytes` is exact), and the launch thread never waits for an interpreter.  Same kernels, same order, same arguments as
 // treelearn_amd/model/engine.py issues them: results are bit-identical (tests/test_gpu_exec.py).
 #include <vector>
@@ -18,22 +18,40 @@ constexpr int64_t kCompactMinRows = 65536;      // geometry.COMPACT_MIN_ROWS: le
 constexpr int64_t kBlkMinRows = 16384;          // geometry.BLK_MIN_ROWS / BLK_MAX_ROWS: the level-1 sizes that go into the block-local order
 constexpr int64_t kBlkMaxRows = (1 << 25) - 64;
 
-struct Arena {                                   // bump allocator + exact-size free list over the caller's block; dry = measure only
+struct Arena {                                   // best-fit free list with coalescing over the caller's block; dry = measure only
   char* base = nullptr;
   int64_t cap = 0, cur = 0, peak = 0;
   bool dry = true;
   struct Slot { int64_t off, bytes; };
-  std::vector<Slot> free_;
+  std::vector<Slot> free_;                       // sorted by offset, neighbours merged
   int64_t take(int64_t bytes) {
     bytes = (bytes + 255) & ~int64_t(255);
+    int best = -1;
     for (size_t i = 0; i < free_.size(); ++i)
-      if (free_[i].bytes == bytes) { const int64_t o = free_[i].off; free_[i] = free_.back(); free_.pop_back(); return o; }
-    const int64_t o = cur;
-    cur += bytes;
+      if (free_[i].bytes >= bytes && (best < 0 || free_[i].bytes < free_[best].bytes)) best = (int)i;
+    if (best >= 0) {
+      const int64_t o = free_[best].off;
+      if (free_[best].bytes == bytes) free_.erase(free_.begin() + best);
+      else { free_[best].off += bytes; free_[best].bytes -= bytes; }
+      return o;
+    }
+    int64_t o = cur;
+    if (!free_.empty() && free_.back().off + free_.back().bytes == cur) {      // a free block at the very end grows instead of being skipped
+      o = free_.back().off;
+      free_.pop_back();
+    }
+    cur = o + bytes;
     if (cur > peak) peak = cur;
     return o;
   }
-  void give(int64_t off, int64_t bytes) { free_.push_back({off, (bytes + 255) & ~int64_t(255)}); }
+  void give(int64_t off, int64_t bytes) {
+    bytes = (bytes + 255) & ~int64_t(255);
+    size_t i = 0;
+    while (i < free_.size() && free_[i].off < off) ++i;
+    free_.insert(free_.begin() + i, Slot{off, bytes});
+    if (i + 1 < free_.size() && free_[i].off + free_[i].bytes == free_[i + 1].off) { free_[i].bytes += free_[i + 1].bytes; free_.erase(free_.begin() + i + 1); }
+    if (i > 0 && free_[i - 1].off + free_[i - 1].bytes == free_[i].off) { free_[i - 1].bytes += free_[i].bytes; free_.erase(free_.begin() + i); }
+  }
   char* at(int64_t off) const { return base + off; }      // (dry: base = nullptr, the pointer is never used)
 };
 
@@ -148,10 +166,10 @@ struct Run {
       r.level = level; r.kind = kind; r.K = w.K; r.Cin = w.Cin; r.Cout = w.Cout; r.residual = residual != nullptr; r.esize = esize;
       r.split_part = split_part; r.split_cin = split_cin; r.in_prologue = in_aff.scale != nullptr || in_relu; r.n_out = n_out; r.n_in = x.n;
       ex->recs.push_back(r);
-      hipEventRecord(e0, s);
+      if (hipEventRecord(e0, s) != hipSuccess) rc = TL_ERR_LAUNCH;
     }
     const int r = tl_conv_fwd(&c, s);
-    if (prof) hipEventRecord(ex->pev.back(), s);
+    if (prof && hipEventRecord(ex->pev.back(), s) != hipSuccess) rc = TL_ERR_LAUNCH;
     if (r != TL_OK) rc = r;
   }
 

@@ -502,12 +502,8 @@ int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, con
            int gx, float* ws, hipStream_t s) {
   constexpr int MBR = 64 * KS;
   const size_t lds = 2 * (size_t)MBR * NBO * 64 + (size_t)NW * 2 * (16 * KS) * (NBIW * 64);
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_dense<NBO, NBIW, KS, PD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_wgrad_dense<NBO, NBIW, KS, PD, NW>), 160 * 1024)) return TL_ERR_LAUNCH;
   const int nmb = (int)tl_cdiv(n_out, MBR);
   const int gy = (int)tl_cdiv((int64_t)K * NS, NW);
   k_wgrad_dense<NBO, NBIW, KS, PD, NW><<<dim3((unsigned)gx, (unsigned)gy), NW * 64, lds, s>>>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, NS, nmb, ws);
@@ -520,12 +516,8 @@ int launch_dma(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld,
   constexpr int MBR = 64 * KS;
   const size_t lds = 2 * (size_t)MBR * NBO * 64 + (size_t)NW * NR * (16 * KS) * (NBIW * 64);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_dense_dma<NBO, NBIW, KS, NR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_wgrad_dense_dma<NBO, NBIW, KS, NR, NW>), 160 * 1024)) return TL_ERR_LAUNCH;
   const int nmb = (int)tl_cdiv(n_out, MBR);
   const int gy = (int)tl_cdiv((int64_t)K * NS, NW);
   k_wgrad_dense_dma<NBO, NBIW, KS, NR, NW><<<dim3((unsigned)gx, (unsigned)gy), NW * 64, lds, s>>>(x, x_ld, g, g_ld, table, n_out, n_in, K, Cin, NS, nmb, ws);

@@ -266,12 +266,8 @@ template <int NBO, int NBIW, int KS, int PD>
 int launch(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld, int64_t n, int Cin, int gx, float* ws, hipStream_t s) {
   const size_t lds = (size_t)kRW * 2 * (16 * KS) * (NBO * 64 + NBIW * 64);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows<NBO, NBIW, KS, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return TL_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_wgrad_rows<NBO, NBIW, KS, PD>), 160 * 1024)) return TL_ERR_LAUNCH;
   k_wgrad_rows<NBO, NBIW, KS, PD><<<dim3((unsigned)gx, (unsigned)(Cin / (NBIW * 32))), kRW * 64, lds, s>>>(x, x_ld, g, g_ld, n, Cin, ws);
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }

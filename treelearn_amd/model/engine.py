@@ -222,7 +222,9 @@ class InferencePlan:
         lv = geom.levels[0]
         vf = voxel_feats.to(self.dtype).contiguous()
         if self.preact:
-            ones = all_ones and os.environ.get("TL_NO_ONES_TABLE") != "1"
+            # TL_NO_ONES_TABLE=1 (A/B knob: run the input conv on the general kernels): honoured where the canonical table exists; a blocked
+            # geometry built without it (the default all-ones inference) keeps the presence-mask form -- same result either way
+            ones = all_ones and (os.environ.get("TL_NO_ONES_TABLE") != "1" or (geom.blocked and lv.nbr_ref is None))
             # block-local level 1: BatchNorm + ReLU of the blocks' first convs at staging, raw tensors only (TL_BLK_PRO=0: the two-view form)
             staged = (geom.blocked and self.unet.deeper and self.unet.C == 32 and self.unet.tail[0].w1_halves is not None
                       and os.environ.get("TL_BLK_PRO", "1") != "0")

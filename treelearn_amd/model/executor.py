@@ -40,7 +40,9 @@ class Executor:
     """`tl_net_desc` of one InferencePlan + the per-stream contexts and arenas of its forwards."""
 
     def __init__(self, plan, model):
-        self.plan = plan
+        import weakref
+        self._plan_ref = weakref.ref(plan)        # (the plan owns this object: no reference cycle, so `del model` frees the arenas at once)
+        self._keep = (plan.w_in, plan.so, plan.ho, plan.w1, plan.b1, plan.w2, plan.b2)
         d = self.desc = _hip.NetDesc()
         d.dtype = _hip.dtype_code(plan.dtype)
         d.num_levels = model.num_blocks
@@ -144,7 +146,10 @@ class Executor:
         ctx = self._context(dev, stream)
         if self.profiling:
             L.tl_exec_profile(ctx[0], 1)
-        self.desc.blocked = int(self.plan.supports_blocked())
+        plan = self._plan_ref()
+        if plan is None:
+            raise RuntimeError("the InferencePlan of this executor is gone")
+        self.desc.blocked = int(plan.supports_blocked())
         bb = torch.empty((N, self.head_C), dtype=torch.float32, device=dev) if want_backbone else None
         logits = torch.empty((N, 2), dtype=torch.float32, device=dev)
         offsets = torch.empty((N, 3), dtype=torch.float32, device=dev)

@@ -209,3 +209,77 @@ class SparseInverseConv3d(SparseConvolution):
         assert int(self.kernel_size) == 2 and x.level > 0
         lv = x.geometry.levels[x.level - 1]
         return TableRef(lv.inv, lv.n, lv.child, x.geometry.levels[x.level].n, False, one_hot=True), x.level - 1
+
+
+class PointToVoxel:
+    """`spconv.pytorch.utils.PointToVoxel` as the reference's `voxelize` uses it (tree_learn/model/tree_learn.py:136-143), on the HIP
+    voxel kernels: occupancy bitmap + popcount ranks (tl_bitmap_from_points / tl_bitmap_scan / tl_expand_coords / tl_point_rank) and the
+    first-<=P-points selection of tl_voxel_mean_feats.  Lets the reference's own `voxelize` run unchanged on this package
+    (INTEGRATION.md seam 2); the fused engine does not go through it (geometry.build_geometry builds the same voxels in one pass).
+
+    Semantics: c = floor((p - lo) / vsize) in float32, valid iff 0 <= c < round((hi - lo) / vsize) on every axis; one voxel
+    per distinct c; the first <= max_num_points_per_voxel points of a voxel in input order are stored, later ones keep the voxel's id.
+    Voxels come in ascending (x, y, z) order (spconv: hash order -- unspecified); with more than max_num_voxels voxels the first
+    max_num_voxels of that order are kept and the points of the others get id -1, as do out-of-range points."""
+
+    def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels, max_num_points_per_voxel, device=None):
+        self.vsize = [float(v) for v in vsize_xyz]
+        self.lo = [float(v) for v in coors_range_xyz[:3]]
+        self.hi = [float(v) for v in coors_range_xyz[3:]]
+        self.C, self.max_voxels, self.P = int(num_point_features), int(max_num_voxels), int(max_num_points_per_voxel)
+        self.device = torch.device(device) if device is not None else None
+        import numpy as np
+        lo32, hi32, vs32 = (np.asarray(a, np.float32) for a in (self.lo, self.hi, self.vsize))
+        self.grid = [int(g) for g in np.round((hi32.astype(np.float64) - lo32) / vs32)]
+
+    def generate_voxel_with_id(self, pc):
+        """pc f32[n, C] (x, y, z, features...) -> (voxels f32[M, P, C], indices i32[M, 3] in ZYX order, num_per_voxel i32[M],
+        pc_voxel_id i64[n])."""
+        from . import _hip
+        L = _hip.lib()
+        _hip.require_cuda(pc.contiguous(), "pc")
+        pc = pc.contiguous().float()
+        n, C = pc.shape
+        dev = pc.device
+        if C != self.C:
+            raise ValueError(f"PointToVoxel was built for {self.C} point features, got {C}")
+        lo = torch.tensor(self.lo, dtype=torch.float32, device=dev); vs = torch.tensor(self.vsize, dtype=torch.float32, device=dev)
+        c = torch.floor((pc[:, :3] - lo) / vs)
+        grid = torch.tensor(self.grid, dtype=torch.float32, device=dev)
+        valid = ((c >= 0) & (c < grid)).all(1)
+        ids = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        vidx = torch.nonzero(valid).squeeze(1)
+        nv = int(vidx.numel())
+        if nv == 0:
+            z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)      # noqa: E731
+            return z(0, self.P, C), z(0, 3, dt=torch.int32), z(0, dt=torch.int32), ids
+        pcoords = torch.zeros((nv, 4), dtype=torch.int32, device=dev)
+        pcoords[:, 1:] = c[vidx].int()
+        ext = [int(v) + 1 for v in pcoords[:, 1:].max(0).values.tolist()]
+        dims = (1, ext[0], ext[1], ext[2])
+        nw = dims[1] * dims[2] * ((dims[3] + 63) // 64)
+        st = _hip.stream()
+        bitmap = torch.empty(nw, dtype=torch.int64, device=dev); prefix = torch.empty(nw, dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(L.tl_scan_ws_words(nw)), dtype=torch.int32, device=dev)
+        _hip.check(L.tl_bitmap_from_points(_hip.ptr(pcoords), nv, _hip.dims4(dims), _hip.ptr(bitmap), st), "tl_bitmap_from_points")
+        _hip.check(L.tl_bitmap_scan(_hip.ptr(bitmap), nw, _hip.ptr(prefix), _hip.ptr(total), _hip.ptr(ws), st), "tl_bitmap_scan")
+        M = int(total.item())
+        coords = torch.empty((M, 4), dtype=torch.int32, device=dev)
+        _hip.check(L.tl_expand_coords(_hip.ptr(bitmap), _hip.ptr(prefix), _hip.dims4(dims), _hip.ptr(coords), st), "tl_expand_coords")
+        v2p = torch.empty(nv, dtype=torch.int64, device=dev)
+        _hip.check(L.tl_point_rank(_hip.ptr(pcoords), nv, _hip.ptr(bitmap), _hip.ptr(prefix), _hip.dims4(dims), _hip.ptr(v2p), st), "tl_point_rank")
+        if M > self.max_voxels:                                        # capacity: the first max_num_voxels voxels of the canonical order survive
+            v2p = torch.where(v2p < self.max_voxels, v2p, torch.full_like(v2p, -1))
+            M = self.max_voxels
+            coords = coords[:M]
+        ids[vidx] = v2p
+        # the first <= P points of every voxel in input order: the selection pass of tl_voxel_mean_feats leaves them in its workspace
+        sel = torch.empty(M * self.P, dtype=torch.int32, device=dev)
+        mean = torch.empty((M, C), dtype=torch.float32, device=dev)
+        pv = pc.index_select(0, vidx)
+        _hip.check(L.tl_voxel_mean_feats(_hip.ptr(pv), C, _hip.ptr(v2p), nv, M, self.P, _hip.ptr(sel), _hip.ptr(mean), st), "tl_voxel_mean_feats")
+        sel = sel.view(M, self.P).long()
+        taken = sel != 0x7FFFFFFF
+        voxels = pv[sel.clamp(max=nv - 1)] * taken[:, :, None].to(pv.dtype)
+        return voxels, coords[:, [3, 2, 1]].contiguous(), taken.sum(1).int(), ids
