@@ -300,7 +300,7 @@ def training_step_bench(args, rank, world, dist):
                 cpu_baseline=None)
 
 
-DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "bf16x3": "bf16x3"}     # bf16x3: fp32 storage, split-bf16 contraction
 
 
 def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
@@ -406,7 +406,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"],
                     help="fp16: the float16 inference kernels (forward workloads; the training step runs its 16-bit kernels in bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode reference timing (profiling runs)")
@@ -612,7 +612,7 @@ def main():
                               launch_path="tl_forward: one C-ABI call per tile enqueues geometry + convs + heads" if ex is not None else "Python-driven engine: one ctypes call per launch",
                               definition="one model(batch, return_loss=False) on device-resident input, torch.cuda.synchronize() after each (SURVEY.md 8d); "
                                          "host_enqueue = time until the call returns (includes the two geometry read-backs)")
-        if world == 1 and args.dtype in ("bf16", "fp16") and not args.no_fp32_mode:
+        if world == 1 and args.dtype in ("bf16", "fp16") and not args.no_fp32_mode and args.workload == "config2":
             # the fp32 parity mode (the precision the 1e-3 parity gate is checked in), same tile, for reference
             m32 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype=torch.float32)
             m32.load_state_dict(model.state_dict(), strict=True); m32 = m32.cuda().eval()
@@ -622,7 +622,22 @@ def main():
                 for _ in range(5): m32(gbatch, return_loss=False)
                 torch.cuda.synchronize(); d32 = (time.perf_counter() - t1) / 5
             res["fp32_parity_mode"] = dict(value=n_pts / d32 / 1e6, unit="Mpoints/s", ms_per_step=d32 * 1e3)
+            out32 = m32(gbatch, return_loss=False)
             del m32
+            # the parity-FAST mode: fp32 storage / BatchNorm / residuals / heads, the convs of the large levels contracted as split-bf16
+            # products on the bf16 matrix cores (compute_dtype="bf16x3"); held to the same 1e-3 gate by the tests, reported beside the exact mode
+            m3 = TreeLearn(use_feats=False, use_coords=False, spatial_shape=model.spatial_shape, voxel_size=cfg["voxel"], compute_dtype="bf16x3")
+            m3.load_state_dict(model.state_dict(), strict=True); m3 = m3.cuda().eval()
+            with torch.no_grad():
+                for _ in range(2): out3 = m3(gbatch, return_loss=False)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(8): m3(gbatch, return_loss=False)
+                torch.cuda.synchronize(); d3 = (time.perf_counter() - t1) / 8
+            dev3 = {k: float((out3[k] - out32[k]).abs().max() / out32[k].abs().max()) for k in ("semantic_prediction_logits", "offset_predictions")}
+            res["parity_fast_mode"] = dict(value=n_pts / d3 / 1e6, unit="Mpoints/s", ms_per_step=d3 * 1e3, compute_dtype="bf16x3",
+                                           max_rel_dev_from_exact_fp32=dev3,
+                                           note="fp32 storage; conv contraction = 3 bf16 MFMAs on hi/lo splits (tl_conv_args.weight_x3); one tile at a time like fp32_parity_mode")
+            del m3, out3, out32
         if world == 1 and args.workload == "config2" and not args.no_extra_workloads:
             # BASELINE configs 3 and 5 ride along in the default line (each with its own ms_per_step / value / roofline), so the driver's
             # one run carries them: the training step (config 3) and the 0.05 m stress tile (config 5)

@@ -251,6 +251,13 @@ typedef struct tl_conv_args {
    * (tl_level.child).  Optional (NULL: the gather forms run); when given, 16-bit launches of the widths of levels 1-4 walk the INPUT rows
    * instead: each read once, eight small products, rows scattered to the children that exist (csrc/tl_conv_up.hip).  Same results. */
   const int32_t* table_scatter;
+  /* Optional split-bf16 copy of fp32 weights (tl_pack_weight_x3; TL_F32 launches only, NULL = absent).  When given, the kernel families
+   * that serve the large levels (csrc/tl_conv_direct.hip, tl_conv_stream.hip) contract in the "bf16x3" form: every fp32 operand x is split in
+   * registers into hi = bf16(x) and lo = bf16(x - hi), and a . b is formed as alo.bhi + ahi.blo + ahi.bhi on the bf16 matrix cores with fp32
+   * accumulation -- storage, BatchNorm, residual and epilogues stay fp32, the contraction costs 3/16 of the fp32-input MFMA, products are
+   * exact to ~2^-15 relative (the reference's fp32 inference, tree_learn/util/pipeline.py:86, within the 1e-3 parity gate at a third of
+   * the exact mode's time).  Shapes without such an instantiation run the exact fp32 kernels on `weight`. */
+  const void* weight_x3;
 } tl_conv_args;
 
 #define TL_EPI_NONE 0
@@ -264,6 +271,9 @@ int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
 /* Repack a reference-layout conv weight [Cout, k,k,k, Cin] (spconv `.weight`)
  * into the kernel layout [K=k^3][Cout][Cin] with dtype conversion. */
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream);
+/* The split-bf16 form of a reference-layout fp32 conv weight for tl_conv_args.weight_x3 (Cin % 32 == 0): [K][Cout][Cin / 32][64 bf16] =
+ * per 32-channel unit the hi parts bf16(w) of its four 8-channel MFMA pieces, then the lo parts bf16(w - hi); as many bytes as [K][Cout][Cin] fp32. */
+int tl_pack_weight_x3(const float* w_ref, int Cout, int K, int Cin, void* w_x3, tl_stream_t stream);
 /* Weights of the input-gradient ("dgrad") conv of the same layer, for tl_conv_fwd over the transposed rulebook: w_t[k][ci][co] =
  * w_ref[co][flip ? K-1-k : k][ci] (taps flip for SubM convs: nbr[k][o] = i <=> nbr[K-1-k][i] = o), with dtype conversion. */
 int tl_pack_weight_dgrad(const float* w_ref, int Cout, int K, int Cin, int flip, void* w_t, int dtype, tl_stream_t stream);
@@ -505,7 +515,7 @@ int tl_knn_vote_grid(const float* ref_sorted_xyz, const int64_t* ref_sorted_labe
 #define TL_ERR_REACH_ZERO (-5)   /* a level's spatial shape or voxel set collapsed (spconv's "reach zero!!!", util/pipeline.py:91-97) */
 #define TL_ERR_EXTENT (-6)       /* the tile's voxel extent exceeds spatial_shape, a batch id is out of range, or a voxel coordinate leaves [0, 65536) */
 typedef struct tl_affine { const float* scale; const float* shift; } tl_affine;
-typedef struct tl_weight { const void* w; const void* frag; int32_t K, Cout, Cin, reserved; } tl_weight;
+typedef struct tl_weight { const void* w; const void* frag; int32_t K, Cout, Cin, reserved; const void* x3; /* tl_pack_weight_x3 copy or NULL */ } tl_weight;
 typedef struct tl_res_desc {      /* ResidualBlock, blocks.py:42-79 */
   tl_affine bn0; tl_weight w1; tl_affine bn3; tl_weight w2;
   tl_weight w1x1;                 /* i_branch: w == NULL = Identity (blocks.py:48-52) */

@@ -240,6 +240,11 @@ def test_config2_forward_fp32_vs_oracle_end_to_end(full):
     model = _model(torch.float32)
     with torch.no_grad():
         out = model(batch, return_loss=False)
+        # the parity-fast mode (fp32 storage, split-bf16 contraction on the bf16 matrix cores) is held to the SAME gate by the same oracle run
+        model_x3 = _model("bf16x3")
+        out_x3 = model_x3(batch, return_loss=False)
+    assert model_x3._plan.x3 and not model._plan.x3
+    assert not torch.equal(out_x3["backbone_feats"], out["backbone_feats"]), "the bf16x3 plan ran the exact kernels"
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         np.savez(os.path.join(td, "in.npz"), coords=batch["coords"].numpy(), feats=batch["input_feats"].numpy(), bids=batch["batch_ids"].numpy())
@@ -253,6 +258,8 @@ def test_config2_forward_fp32_vs_oracle_end_to_end(full):
         ref = dict(np.load(os.path.join(td, "out.npz")))
     for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
         assert rel_err(out[k].cpu().numpy(), ref[k]) < REL_TOL, (k, rel_err(out[k].cpu().numpy(), ref[k]))
+        assert rel_err(out_x3[k].cpu().numpy(), ref[k]) < REL_TOL, ("bf16x3", k, rel_err(out_x3[k].cpu().numpy(), ref[k]))
+    print("rel err vs oracle: exact fp32", {k: rel_err(out[k].cpu().numpy(), ref[k]) for k in ref}, "bf16x3", {k: rel_err(out_x3[k].cpu().numpy(), ref[k]) for k in ref})
 
 
 def test_config2_full_tile_bf16_decision_level(tile2):

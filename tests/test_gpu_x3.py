@@ -1,0 +1,109 @@
+"""The split-bf16 ("bf16x3") contraction of fp32 convs (tl_conv_args.weight_x3; csrc/tl_conv_internal.h mma16_x3) against the exact fp32
+kernels and the float64 oracle: fp32 storage, every product formed as alo.bhi + ahi.blo + ahi.bhi on the bf16 matrix cores.  The mode
+serves the reference's fp32 inference (tree_learn/util/pipeline.py:86) inside the 1e-3 gate at a fraction of the fp32-MFMA time."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sparse_ops as osp
+from treelearn_amd.synth import make_batch, make_tile
+
+
+def _geom(extent=12.0, levels=3, seed=1):
+    from treelearn_amd.geometry import build_geometry
+    t = make_tile(extent=extent, voxel=0.1, n_trees=5, fill=0.1, seed=seed)
+    xyz = torch.from_numpy(t["points"]).cuda()
+    return build_geometry(xyz, torch.zeros(len(xyz), dtype=torch.int64, device="cuda"), 1, 0.1, levels, [500, 500, 1000])
+
+
+def _packs(w):
+    from treelearn_amd import ops
+    exact = ops.pack_weight(w, torch.float32)
+    ops.PACK_X3 = True
+    try:
+        x3 = ops.pack_weight(w, torch.float32)
+    finally:
+        ops.PACK_X3 = False
+    assert getattr(x3, "_tl_x3", None) is not None and getattr(exact, "_tl_x3", None) is None
+    return exact, x3
+
+
+@pytest.mark.parametrize("cin,cout,kind,level", [(32, 32, "subm", 0), (64, 64, "subm", 0), (128, 64, "subm", 0), (96, 96, "subm", 0), (128, 128, "subm", 0),
+                                                 (64, 32, "subm", 0), (32, 64, "down", 0), (64, 96, "down", 0), (96, 128, "down", 1)])
+def test_x3_conv_vs_exact_fp32_and_float64(cin, cout, kind, level):
+    from treelearn_amd import ops
+    g = _geom()
+    lv = g.levels[level]
+    table, n_out = (lv.nbr, lv.n) if kind == "subm" else (lv.child, g.levels[level + 1].n)
+    assert n_out > 16384                                   # the large-level kernels (direct / stream), not the small-level one
+    K = table.shape[0]
+    k = 3 if K == 27 else 2
+    gen = torch.Generator(device="cuda"); gen.manual_seed(cin * 1000 + cout)
+    w = torch.randn((cout, k, k, k, cin), device="cuda", generator=gen) / (cin * K) ** 0.5
+    x = torch.randn((lv.n, cin), device="cuda", generator=gen)
+    res = torch.randn((n_out, cout), device="cuda", generator=gen)
+    sc = torch.rand(cout, device="cuda", generator=gen) + 0.5; sh = torch.randn(cout, device="cuda", generator=gen)
+    w_exact, w_x3 = _packs(w)
+    y_exact = ops.conv_fwd(x, w_exact, table, n_out, residual=res, out_scale=sc, out_shift=sh, out_relu=True)
+    y2 = torch.empty_like(y_exact)
+    y_x3 = ops.conv_fwd(x, w_x3, table, n_out, residual=res, out_scale=sc, out_shift=sh, out_relu=True, out2=(y2, None, None, False))
+    assert not torch.equal(y_exact, y_x3), "the split-bf16 kernel did not run (results are bit-identical to the exact fp32 kernel)"
+    scale = float(y_exact.abs().max())
+    assert float((y_exact - y_x3).abs().max()) / scale < 1e-4
+    # float64 reference on a sample of rows: the x3 result is as close to it as 2^-15-per-product allows
+    rows = torch.randperm(n_out, device="cuda", generator=gen)[:2048].sort().values
+    sub = table[:, rows].T.contiguous().cpu().numpy()
+    ref = osp.conv_table(x.double().cpu(), w.double().cpu(), sub).numpy() + res[rows].double().cpu().numpy()
+    raw = y2[rows].double().cpu().numpy()
+    assert np.abs(raw - ref).max() / np.abs(ref).max() < 5e-5
+    act = np.maximum(ref * sc.double().cpu().numpy() + sh.double().cpu().numpy(), 0)
+    assert np.abs(y_x3[rows].double().cpu().numpy() - act).max() / max(np.abs(act).max(), 1e-9) < 5e-5
+
+
+def test_x3_forward_small_model_vs_exact_and_executor():
+    """A whole forward in the parity-fast mode: close to the exact fp32 forward, identical through tl_forward and the Python-driven engine."""
+    import os
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import random_state_dict
+    b = make_batch([make_tile(extent=16.0, voxel=0.1, n_trees=10, fill=0.1, seed=3)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    outs = {}
+    for mode in (torch.float32, "bf16x3"):
+        m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=mode)
+        m.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); m = m.cuda().eval()
+        with torch.no_grad():
+            outs[mode] = m(gb, return_loss=False)
+            if mode == "bf16x3":
+                os.environ["TL_EXEC"] = "0"
+                try:
+                    py = m(gb, return_loss=False)
+                finally:
+                    del os.environ["TL_EXEC"]
+                for k in py:
+                    assert torch.equal(py[k], outs[mode][k])
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        a, c = outs[torch.float32][k], outs["bf16x3"][k]
+        assert float((a - c).abs().max()) / float(a.abs().max()) < 1e-3
+    assert not torch.equal(outs[torch.float32]["backbone_feats"], outs["bf16x3"]["backbone_feats"])
+
+
+def test_x3_wide_conv_runs_as_two_half_width_launches():
+    """256 -> 128 (the decoder's 2C -> C conv of level 4): no split-bf16 instantiation that wide, so tl_pack_weight_x3 stores two half-width
+    convs and tl_conv_fwd chains two 128 -> 128 launches through `out` (csrc/tl_conv.hip)."""
+    from treelearn_amd import ops
+    g = _geom()
+    lv = g.levels[0]
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    w = torch.randn((128, 3, 3, 3, 256), device="cuda", generator=gen) / (256 * 27) ** 0.5
+    x = torch.randn((lv.n, 256), device="cuda", generator=gen)
+    sc = torch.rand(128, device="cuda", generator=gen) + 0.5; sh = torch.randn(128, device="cuda", generator=gen)
+    w_exact, w_x3 = _packs(w)
+    y_exact = ops.conv_fwd(x, w_exact, lv.nbr, lv.n, out_scale=sc, out_shift=sh, out_relu=True)
+    y_x3 = ops.conv_fwd(x, w_x3, lv.nbr, lv.n, out_scale=sc, out_shift=sh, out_relu=True)
+    assert not torch.equal(y_exact, y_x3)
+    assert float((y_exact - y_x3).abs().max()) / float(y_exact.abs().max()) < 1e-4
+    # with a residual or a second view the chained form does not apply: the exact kernel runs on the plain weights
+    res = torch.randn((lv.n, 128), device="cuda", generator=gen)
+    assert torch.equal(ops.conv_fwd(x, w_x3, lv.nbr, lv.n, residual=res), ops.conv_fwd(x, w_exact, lv.nbr, lv.n, residual=res))

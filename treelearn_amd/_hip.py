@@ -36,6 +36,7 @@ class ConvArgs(_c.Structure):
         ("bn_x", _vp), ("bn_x_ld", _i64), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_scale", _vp), ("bn_shift", _vp), ("bn_relu", _i32),
         # block-local form of a 27-tap rulebook (tl_blk_build)
         ("blk_unit", _vp), ("blk_counter", _vp), ("blk_halo", _vp), ("blk_lrb", _vp), ("blk_pmask", _vp), ("table_scatter", _vp),
+        ("weight_x3", _vp),
     ]
 
 
@@ -67,7 +68,7 @@ class Affine(_c.Structure):                # tl_affine
 
 
 class Weight(_c.Structure):                # tl_weight
-    _fields_ = [("w", _vp), ("frag", _vp), ("K", _i32), ("Cout", _i32), ("Cin", _i32), ("reserved", _i32)]
+    _fields_ = [("w", _vp), ("frag", _vp), ("K", _i32), ("Cout", _i32), ("Cin", _i32), ("reserved", _i32), ("x3", _vp)]
 
 
 class ResDesc(_c.Structure):               # tl_res_desc
@@ -130,6 +131,7 @@ PROTOTYPES = {
     "tl_bn_train_finish": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_bn_train_bwd_from_parts": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "tl_pack_weight_x3": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weights_batch": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "tl_pack_weight_dgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
@@ -203,7 +205,13 @@ def ptr(t):
     return None if t is None else _vp(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the raw handle: no Stream object per launch)."""
+    if _raw_stream is not None:
+        return _vp(_raw_stream(torch.cuda.current_device()))
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 

@@ -205,6 +205,27 @@ __global__ void k_pack_weight(const float* __restrict__ w, int Cout, int K, int 
   }
 }
 
+// split-bf16 form of fp32 weights (tl_conv_internal.h: the bf16x3 contraction): [K][Cout][Cin / 32][64 x bf16] -- per 32-channel unit the hi
+// parts of the four 8-channel pieces (J, fh) at 16-B slots 2 J + fh, the lo parts at slots 4 + 2 J + fh; piece (J, fh) = channels
+// 16 J + 4 fh + {0..3}, 16 J + 8 + 4 fh + {0..3} of the unit
+__global__ void k_pack_weight_x3(const float* __restrict__ w, int Cout, int K, int Cin, uint16_t* __restrict__ o) {
+  // Cin >= 256: stored as TWO independent half-width convs (input channels [0, Cin / 2) then [Cin / 2, Cin)), each [K][Cout][Cin / 64][64]:
+  // tl_conv_fwd runs such a conv as two launches of the kernel that has an instantiation for the half width
+  const int un_all = Cin / 32, halves = Cin >= 256 ? 2 : 1, un = un_all / halves;
+  const int64_t per_half = (int64_t)Cout * K * un * 64, total = per_half * halves;
+  for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += (int64_t)gridDim.x * blockDim.x) {
+    const int hf = (int)(t0 / per_half); const int64_t t = t0 - hf * per_half;
+    const int e = (int)(t & 63); const int64_t r = t >> 6; const int c = (int)(r % un); const int64_t r2 = r / un;
+    const int n = (int)(r2 % Cout); const int k = (int)(r2 / Cout);
+    const int half = e >> 5, piece = (e & 31) >> 3, q = e & 7, J = piece >> 1, fh = piece & 1;
+    const int ch = 32 * (c + hf * un) + 16 * J + (q < 4 ? 4 * fh + q : 8 + 4 * fh + (q - 4));
+    const float v = w[((int64_t)n * K + k) * Cin + ch];                // reference layout [Cout][K][Cin]
+    const __hip_bfloat16 hi = __float2bfloat16(v);
+    const __hip_bfloat16 lo = __float2bfloat16(v - __bfloat162float(hi));
+    o[t0] = half ? __builtin_bit_cast(uint16_t, lo) : __builtin_bit_cast(uint16_t, hi);
+  }
+}
+
 // weights of the input-gradient conv straight from the reference layout: o[k][ci][co] = w[co][flip ? K-1-k : k][ci]
 __global__ void k_pack_weight_dgrad(const float* __restrict__ w, int Cout, int K, int Cin, int flip, void* __restrict__ o, int dtype) {
   const int64_t total = (int64_t)Cout * K * Cin;
@@ -398,7 +419,8 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const auto L_up = f16 ? tl_launch_conv_up_f16 : tl_launch_conv_up;
   if (f16 && a->epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;       // the training epilogues take TL_F32 / TL_BF16
   ConvP p;
-  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
+  p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag;
+  p.w_x3 = (a->dtype == TL_F32 && a->Cin % 32 == 0 && ((uintptr_t)a->weight_x3) % 16 == 0) ? a->weight_x3 : nullptr; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
   p.K = a->K; p.Cin = a->Cin; p.Cout = a->Cout; p.in_scale = a->in_scale; p.in_shift = a->in_shift;
   p.in_relu = a->in_relu; p.out_relu = a->out_relu; p.res = a->residual; p.res_ld = a->res_ld;
   p.out_scale = a->out_scale; p.out_shift = a->out_shift; p.out = a->out; p.out_ld = a->out_ld;
@@ -426,8 +448,8 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
                        (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));
-  if (a->in_all_ones && !train && dt == TL_BF16 && out_vec && (g_direct || !a->table) && ((uintptr_t)a->weight) % 2 == 0 && !a->residual) {
-    const int rc = L_ones27(p, s);
+  if (a->in_all_ones && !train && (dt == TL_BF16 || (dt == TL_F32 && !f16)) && out_vec && (g_direct || !a->table) && ((uintptr_t)a->weight) % 4 == 0 && !a->residual) {
+    const int rc = L_ones27(p, dt, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
   if (has_blk && dt == TL_BF16 && g_blk && vec_ok && out_vec && (!a->residual || (a->res_ld % 8 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
@@ -451,6 +473,25 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   if (train && a->n_out <= g_small_rows) return TL_ERR_UNSUPPORTED;            // small levels: the separate passes
   const bool aligned = (a->in_ld % 4 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0) &&
                        (!a->in_scale || (((uintptr_t)a->in_scale) % 16 == 0 && ((uintptr_t)a->in_shift) % 16 == 0));
+  if (p.w_x3 && a->Cin >= 256) {
+    // split-bf16 weights of a wide conv come as two half-width convs (tl_pack_weight_x3): the decoder's 2C -> C conv of level 4 (256 -> 128)
+    // runs as two 128 -> 128 launches, the first leaving its raw sums in `out`, the second taking them as its residual
+    if (dt == TL_F32 && !train && g_stream && aligned && out_vec && a->Cin % 64 == 0 && a->Cout % 32 == 0 && !a->in_scale && !a->in_relu && !a->residual &&
+        !a->out2 && !a->out3 && a->n_out > g_small_rows && (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
+      ConvP p1 = p;
+      p1.Cin = a->Cin / 2; p1.out_scale = nullptr; p1.out_shift = nullptr; p1.out_relu = 0;
+      const int rc1 = L_stream(p1, TL_F32, s);
+      if (rc1 == TL_OK) {
+        ConvP p2 = p;
+        p2.Cin = a->Cin / 2; p2.in = static_cast<const float*>(a->in) + a->Cin / 2;
+        p2.w_x3 = static_cast<const char*>(p.w_x3) + (size_t)a->K * a->Cout * (a->Cin / 2) * 4;
+        p2.res = a->out; p2.res_ld = a->out_ld;
+        return L_stream(p2, TL_F32, s);
+      }
+      if (rc1 != TL_ERR_UNSUPPORTED) return rc1;
+    }
+    p.w_x3 = nullptr;                                            // (the half layout is not what the single-launch kernels read)
+  }
   if (dt == TL_F32 && aligned && out_vec && a->Cin % 32 == 0 && a->Cout % 32 == 0 && !a->in_scale && !a->in_relu &&
       (!a->residual || (a->res_ld % 4 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
@@ -523,6 +564,13 @@ int64_t tl_conv_red_parts(int64_t n_out) {
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream) {
   if (!w_ref || !w_packed || Cout <= 0 || K <= 0 || Cin <= 0 || (dtype != TL_F32 && dtype != TL_BF16 && dtype != TL_F16)) return TL_ERR_ARG;
   k_pack_weight<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_packed, dtype);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_pack_weight_x3(const float* w_ref, int Cout, int K, int Cin, void* w_x3, tl_stream_t stream) {
+  if (!w_ref || !w_x3 || Cout <= 0 || K <= 0 || Cin <= 0 || Cin % 32) return TL_ERR_ARG;
+  k_pack_weight_x3<<<tl_grid((int64_t)Cout * K * Cin * 2, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, reinterpret_cast<uint16_t*>(w_x3));
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

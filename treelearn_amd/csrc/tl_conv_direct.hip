@@ -26,8 +26,10 @@ __device__ unsigned long long g_tmd[8];   // developer timing mode (ABL bit 16):
 // TR: the training-mode epilogue (tl_conv_args.epi_mode) is compiled in; the inference instantiations (TR = false) carry none of it
 // OH: every output row has at most ONE valid table entry (inverse conv): that row is gathered once and routed to its tap by a per-lane
 // select (K gathers of which K - 1 fetch nothing otherwise); all K taps are still contracted, against zeros except one
-template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false>
+// X3 (fp32 storage only): split-bf16 contraction (tl_conv_internal.h: mma16_x3) on weights in the tl_pack_weight_x3 form
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false, bool X3 = false>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles, int walk) {
+  static_assert(!X3 || (!BF16 && !OH && !TR), "the split-bf16 contraction: fp32 rows, inference");
   constexpr bool TM = (ABL & 16) != 0;
   [[maybe_unused]] unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
   auto tick = [&](int seg) __attribute__((always_inline)) {
@@ -198,6 +200,22 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
       for (int t = 0; t < G; ++t) {
         const int k = g * G + t;
         if (k < K) {
+          if constexpr (X3) {
+#pragma unroll
+            for (int c = 0; c < UN; ++c)
+#pragma unroll
+              for (int J = 0; J < 2; ++J) {
+                u32x4 ah, al;
+                x3_split8(a[g & 1][t][c][2 * J], a[g & 1][t][c][2 * J + 1], ah, al);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                  const char* wb = wl + ((k * UN + c) * COUT + nb * 32) * UB;
+                  const u32x4 bh = *reinterpret_cast<const u32x4*>(wb + (((2 * J + fh) ^ swz) * 16));
+                  const u32x4 blo = *reinterpret_cast<const u32x4*>(wb + (((4 + 2 * J + fh) ^ swz) * 16));
+                  mma16_x3(acc[nb], ah, al, bh, blo);
+                }
+              }
+          } else
 #pragma unroll
           for (int c = 0; c < UN; ++c)
 #pragma unroll
@@ -417,12 +435,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_in4(ConvP p, int ntiles) {
 // voxel feature is 1, so out[o][co] = sum over the PRESENT taps k of S[k][co], S[k][co] = sum_c W[k][co][c]: no gather at all, just the
 // 27-bit presence mask of the column-form rulebook (4 B / voxel) and a 27 x 32 table in LDS.  Write-bound (the output views).
 // One thread = one row x 8 channels.
+template <bool BF16>
 __global__ void __launch_bounds__(256) k_conv_ones27(ConvP p) {
   __shared__ __attribute__((aligned(16))) float S[27][32];
-  const uint16_t* w = (const uint16_t*)p.w;                                 // [27][32][Cin] bf16
-  for (int e = threadIdx.x; e < 27 * 32; e += 256) {
+  for (int e = threadIdx.x; e < 27 * 32; e += 256) {                        // weights [27][32][Cin] in the launch's storage type
     float t = 0.f;
-    for (int c = 0; c < p.Cin; ++c) t += bf16_lo((uint32_t)w[(int64_t)e * p.Cin + c]);
+    if constexpr (BF16) {
+      const uint16_t* w = (const uint16_t*)p.w;
+      for (int c = 0; c < p.Cin; ++c) t += bf16_lo((uint32_t)w[(int64_t)e * p.Cin + c]);
+    } else {
+      const float* w = (const float*)p.w;
+      for (int c = 0; c < p.Cin; ++c) t += w[(int64_t)e * p.Cin + c];
+    }
     S[e >> 5][e & 31] = t;
   }
   __syncthreads();
@@ -438,14 +462,19 @@ __global__ void __launch_bounds__(256) k_conv_ones27(ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { v[q] += a[q]; v[q + 4] += b[q]; }
     }
-    epi_views8<true>(p, row, c0, v);
+    epi_views8<BF16>(p, row, c0, v);
   }
 }
 
 int g_direct_walk = 0;
 
-template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false>
-int launch(const ConvP& p, hipStream_t s) {
+template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false, bool X3 = false>
+int launch(const ConvP& p_, hipStream_t s) {
+  ConvP p = p_;
+  if constexpr (X3) {
+    if (p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
+    p.w = p.w_x3;
+  }
   if constexpr (!TR && BF16 && ABL == 0) {
     if (p.epi_mode != TL_EPI_NONE) return launch<BF16, K, NB, UN, G, WAVES, ABL, CT, true, OH>(p, s);  // training-mode epilogue: its own instantiation
   } else if constexpr (!TR) {
@@ -457,13 +486,13 @@ int launch(const ConvP& p, hipStream_t s) {
   const size_t lds = (size_t)K * UN * NB * 32 * UB + (size_t)WAVES * 32 * (NB * 32 + 4) * 4 + (TR ? (size_t)WAVES * 2 * NB * 32 * 8 : 0);
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
-  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH>), 160 * 1024)) return TL_ERR_LAUNCH;
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH, X3>), 160 * 1024)) return TL_ERR_LAUNCH;
   const int ntiles = (int)tl_cdiv(p.n_out, 32);
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   const int need = (int)tl_cdiv(ntiles, WAVES);
   if (grid > need) grid = need;
-  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
+  k_conv_direct<BF16, K, NB, UN, G, WAVES, ABL, CT, TR, OH, X3><<<grid, WAVES * 64, lds, s>>>(p, ntiles, (g_direct_walk && grid % 8 == 0) ? 1 : 0);
   if (p.red_nparts) *p.red_nparts = grid;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
   }
@@ -518,7 +547,11 @@ int dispatch(const ConvP& p, hipStream_t s) {
 #define TL_D(NB_, UN_)                                                                                               \
   if (nb == NB_ && un == UN_) {                                                                                      \
     if constexpr (BF16) return wbytes <= 64 * 1024 ? launch<true, K, NB_, UN_, G, 16>(p, s) : launch<true, K, NB_, UN_, G, 8>(p, s); \
-    else return launch<false, K, NB_, UN_, (G > 2 ? 2 : G), 8>(p, s);                                                \
+    else {                                                                                                           \
+      if (p.w_x3 && p.epi_mode == TL_EPI_NONE)       /* split-bf16: latency-bound, so as many waves as the LDS holds beside 110 KB of weights */ \
+        return launch<false, K, NB_, UN_, (G > 2 ? 2 : G), (K == 27 && NB_ == 1 && UN_ == 1 ? 11 : 8), 0, false, false, false, true>(p, s);         \
+      return launch<false, K, NB_, UN_, (G > 2 ? 2 : G), 8>(p, s);                                                   \
+    }                                                                                                                \
   }
   TL_D(1, 1) TL_D(1, 2) TL_D(2, 1) TL_D(2, 2) TL_D(2, 3) TL_D(3, 2) TL_D(1, 3) TL_D(3, 1)
 #undef TL_D
@@ -528,9 +561,10 @@ int dispatch(const ConvP& p, hipStream_t s) {
 }  // namespace
 
 // all-ones input (tl_conv_args.in_all_ones): bf16, K = 27 with the column-form rulebook, Cout = 32
-int tl_launch_conv_ones27(const ConvP& p, hipStream_t s) {
+int tl_launch_conv_ones27(const ConvP& p, int dtype, hipStream_t s) {
   if (p.K != 27 || p.Cout != 32 || (!p.ctab && !p.blk_pmask) || p.Cin <= 0 || p.Cin > 64 || p.in_scale || p.in_relu || p.epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;
-  k_conv_ones27<<<tl_grid(p.n_out * 4, 256), 256, 0, s>>>(p);
+  if (dtype == TL_BF16) k_conv_ones27<true><<<tl_grid(p.n_out * 4, 256), 256, 0, s>>>(p);
+  else k_conv_ones27<false><<<tl_grid(p.n_out * 4, 256), 256, 0, s>>>(p);          // fp32 storage (the exact and the bf16x3 parity modes)
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 

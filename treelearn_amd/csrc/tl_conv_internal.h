@@ -27,6 +27,7 @@ struct ConvP {
   const void* in; int64_t in_ld;
   const void* w;
   const void* w_frag;   // optional fragment-order copy of w (tl_pack_weight_frag) or nullptr
+  const void* w_x3;     // optional split-bf16 copy of fp32 weights (tl_pack_weight_x3) or nullptr: permits the bf16x3 contraction
   const int32_t* table;
   const int32_t* ctab;  // optional column form of a 27-tap table (tl_rulebook_compact) or nullptr
   int64_t n_out, n_in;
@@ -124,6 +125,34 @@ static __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
   }
 }
+// ---- split-bf16 ("bf16x3") contraction of fp32 operands.  x = hi + lo + O(2^-16 |x|) with hi = the upper half of x's bits (activations; bf16(x) for the weights), lo =
+// bf16(x - hi); a . b ~= alo.bhi + ahi.blo + ahi.bhi on the bf16 matrix cores with fp32 accumulation: three 32x32x16 MFMAs per
+// 16 channels where the exact fp32 path issues eight 32x32x2 ones -- 3/16 of the matrix time at ~2^-15 relative error per product.
+// Fragment convention (shared by the direct and the stream kernel): lane half fh of a 32-channel unit holds, for J = 0, 1, the fp32
+// channels 16 J + 4 fh + {0..3} (16-B piece j = 2 J) and 16 J + 8 + 4 fh + {0..3} (piece j = 2 J + 1); tl_pack_weight_x3 stores the
+// weights' hi parts of those eight channels as ONE 16-B piece at slot 2 J + fh of the unit's 128 B and the lo parts at slot 4 + 2 J + fh.
+static __device__ __forceinline__ uint32_t x3_pack2(float a, float b) {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  const v2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+static __device__ __forceinline__ void x3_split8(const u32x4& a0, const u32x4& a1, u32x4& hi, u32x4& lo) {
+  // hi = the upper 16 bits of x (truncation: ONE v_perm_b32 per pair of elements), lo = bf16(x - hi) with x - hi exact in fp32
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t u0 = a0[2 * q], u1 = a0[2 * q + 1], v0 = a1[2 * q], v1 = a1[2 * q + 1];
+    hi[q] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    hi[2 + q] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    lo[q] = x3_pack2(__uint_as_float(u0) - __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1) - __uint_as_float(u1 & 0xFFFF0000u));
+    lo[2 + q] = x3_pack2(__uint_as_float(v0) - __uint_as_float(v0 & 0xFFFF0000u), __uint_as_float(v1) - __uint_as_float(v1 & 0xFFFF0000u));
+  }
+}
+static __device__ __forceinline__ void mma16_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+}
+
 template <bool BF16>
 static __device__ __forceinline__ void res_add8(const void* res, int64_t elem, float (&v)[8]) {   // v += res[elem .. elem+7]
   if constexpr (BF16) {
@@ -304,7 +333,7 @@ int tl_launch_conv_bf16(const ConvP& p, int depth, int units, hipStream_t s);   
 
 // tl_conv_direct.hip
 int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s);   // whole weight tensor resident in LDS, per-wave tiles
-int tl_launch_conv_ones27(const ConvP& p, hipStream_t s);               // every input element is 1: presence-mask table, no gather
+int tl_launch_conv_ones27(const ConvP& p, int dtype, hipStream_t s);               // every input element is 1: presence-mask table, no gather
 
 // tl_conv_up.hip
 int tl_launch_conv_up(const ConvP& p, const int32_t* child, hipStream_t s);   // 16-bit inverse conv, coarse-stationary scatter form
@@ -330,7 +359,7 @@ int tl_launch_conv_tinycin(const ConvP& p, int dtype, hipStream_t s);   // Cin <
 #ifndef TL_F16_BUILD
 // the float16 compilations of the same units (tl_half.h): inside them dtype TL_BF16 means "the 16-bit type"
 int tl_launch_conv_direct_f16(const ConvP& p, int dtype, hipStream_t s);
-int tl_launch_conv_ones27_f16(const ConvP& p, hipStream_t s);
+int tl_launch_conv_ones27_f16(const ConvP& p, int dtype, hipStream_t s);
 int tl_launch_conv_stream_f16(const ConvP& p, int dtype, hipStream_t s);
 int tl_launch_conv_streamq_f16(const ConvP& p, hipStream_t s);
 int tl_launch_conv_small_f16(const ConvP& p, int dtype, hipStream_t s);

@@ -24,8 +24,10 @@ __device__ unsigned long long g_tm[8];   // developer timing mode (tl_dev_stream
 
 // OH (inverse conv, one valid table entry per output row): the row's single input row is gathered ONCE and routed to its
 // tap by a per-lane select, instead of K gathers of which K - 1 are out of range.
-template <bool BF16, int K, int NB, int UN, int DA, int RB, int OCC, bool TM = false, bool OH = false>
+// X3 (fp32 storage only): the contraction runs as split-bf16 products (tl_conv_internal.h: mma16_x3) on weights in the tl_pack_weight_x3 form
+template <bool BF16, int K, int NB, int UN, int DA, int RB, int OCC, bool TM = false, bool OH = false, bool X3 = false>
 __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
+  static_assert(!X3 || (!BF16 && !OH), "the split-bf16 contraction reads fp32 rows");
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32, SLOTS = UB / 16;
   constexpr int COUT = NB * 32, CIN = UN * 32;
   constexpr int BROW = CIN * EB + 16;                  // LDS pitch of a weight row (one output channel, one tap): +16 B pad =>
@@ -151,6 +153,23 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
     if constexpr (TM) { if (k + DA < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (RB * UN * NJ + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
     tick(0);
     const char* bl = Bs + (k & 1) * COUT * BROW + fi * BROW;
+    if constexpr (X3) {
+#pragma unroll
+      for (int c = 0; c < UN; ++c)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+          u32x4 ah[RB], al[RB];
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) x3_split8(a[k % DA][rb][c][2 * J], a[k % DA][rb][c][2 * J + 1], ah[rb], al[rb]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const char* bp = bl + nb * 32 * BROW + (c * SLOTS + 2 * J + fh) * 16;
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(bp), blo = *reinterpret_cast<const u32x4*>(bp + 64);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) mma16_x3(acc[rb][nb], ah[rb], al[rb], bh, blo);
+          }
+        }
+    } else
 #pragma unroll
     for (int c = 0; c < UN; ++c)
 #pragma unroll
@@ -203,19 +222,20 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   if (p.epi_mode != TL_EPI_NONE) epi_finish_wg<WAVES, EP, NB>(p, Es, tid, red0, red1);
 }
 
-template <bool BF16, int K, int NB, int UN, int DA, int RB, bool TM = false, bool OH = false>
+template <bool BF16, int K, int NB, int UN, int DA, int RB, bool TM = false, bool OH = false, bool X3 = false>
 int launch(ConvP p, hipStream_t s) {
+  if constexpr (X3) p.w = p.w_x3;
   constexpr int EB = BF16 ? 2 : 4;
   constexpr int BPTL = (NB * 32 * UN * (BF16 ? 4 : 8) + NT - 1) / NT;
   constexpr int VG = RB * NB * 16 + DA * RB * UN * (BF16 ? 8 : 16) + (K <= 8 ? 8 : 27) * RB + 4 * BPTL * (DA > 2 ? DA - 1 : 1) + 20;   // rough VGPR need
-  constexpr int OCC = VG <= 120 ? 4 : 2;
+  constexpr int OCC = (VG <= 120 || (X3 && NB * UN <= 4)) ? 4 : 2;      // (the split-bf16 form is latency-bound at two waves per SIMD: measured)
   const size_t wt = 2 * (size_t)NB * 32 * (UN * 32 * EB + 16), ep = (size_t)WAVES * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
-  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH>), 160 * 1024)) return TL_ERR_LAUNCH;
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH, X3>), 160 * 1024)) return TL_ERR_LAUNCH;
   p.nblk = (int)tl_cdiv(p.n_out, WAVES * 32 * RB);
-  k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH><<<p.nblk, NT, lds, s>>>(p);
+  k_conv_stream<BF16, K, NB, UN, DA, RB, OCC, TM, OH, X3><<<p.nblk, NT, lds, s>>>(p);
   if (p.red_nparts) *p.red_nparts = p.nblk;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
@@ -248,7 +268,10 @@ int dispatch(const ConvP& p, hipStream_t s) {
     if constexpr (BF16) {                                                                            \
       if (DB2_ > 0 && (g_stream_rb == 2 || (g_stream_rb == 0 && NB_ == 3 && UN_ == 3))) return launch<true, K, NB_, UN_, (DB2_ > 0 ? DB2_ : 1), 2>(p, s); \
       return launch<true, K, NB_, UN_, DB1_, 1>(p, s);                                               \
-    } else return launch<false, K, NB_, UN_, DF_, 1>(p, s);                                          \
+    } else {                                                                                         \
+      if (p.w_x3) return launch<false, K, NB_, UN_, 1, 1, false, false, true>(p, s);   /* split-bf16 contraction */ \
+      return launch<false, K, NB_, UN_, DF_, 1>(p, s);                                               \
+    }                                                                                                \
   }
   TL_S(2, 2, 3, 2, 2) TL_S(2, 4, 2, 1, 1) TL_S(3, 3, 2, 1, 1) TL_S(3, 6, 1, 0, 1) TL_S(4, 4, 2, 0, 1) TL_S(2, 3, 3, 1, 1) TL_S(3, 2, 3, 2, 2)
   TL_S(3, 4, 2, 1, 1) TL_S(4, 3, 2, 1, 1) TL_S(1, 2, 3, 2, 2) TL_S(2, 1, 3, 2, 2) TL_S(1, 1, 3, 2, 2)

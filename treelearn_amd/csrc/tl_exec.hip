@@ -144,7 +144,7 @@ struct Run {
     ++launches;
     if (ar.dry) return;
     tl_conv_args c{};
-    c.in = ar.at(x.off); c.in_ld = x.ld; c.weight = w.w; c.weight_frag = w.frag;
+    c.in = ar.at(x.off); c.in_ld = x.ld; c.weight = w.w; c.weight_frag = w.frag; c.weight_x3 = w.x3;
     c.table = tb.table; c.table_compact = tb.compact; c.table_one_hot = tb.one_hot; c.table_scatter = tb.scatter;
     if (tb.blk) {
       c.blk_unit = gw(o_unit); c.blk_counter = gw(o_counter); c.blk_halo = gw(o_halo);

@@ -197,11 +197,18 @@ class _UPro:
 
 class InferencePlan:
     """Folded BatchNorms + packed weights of one TreeLearn module, for one compute dtype."""
-    def __init__(self, model, dtype):
+    def __init__(self, model, dtype, x3=False):
+        """`x3` (fp32 only): the "bf16x3" parity-fast mode -- fp32 storage and epilogues, every conv weight also packed in its split-bf16 form
+        so that the kernels of the large levels contract hi / lo bf16 parts on the bf16 matrix cores (tl_conv_args.weight_x3)."""
         self.dtype = dtype
+        self.x3 = bool(x3) and dtype == torch.float32
         self.preact = os.environ.get("TL_ENGINE", "preact") != "prologue"
-        self.w_in = ops.pack_weight(model.input_conv[0].weight, dtype)
-        self.unet = (_U if self.preact else _UPro)(model.unet, dtype)
+        prev, ops.PACK_X3 = ops.PACK_X3, self.x3
+        try:
+            self.w_in = ops.pack_weight(model.input_conv[0].weight, dtype)
+            self.unet = (_U if self.preact else _UPro)(model.unet, dtype)
+        finally:
+            ops.PACK_X3 = prev
         self.so, self.ho = _bn_affine(model.output_layer[0])
         w1, b1 = [], []
         for mlp in (model.semantic_linear, model.offset_linear):

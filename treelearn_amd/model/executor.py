@@ -26,7 +26,7 @@ def _aff(dst, pair):
 def _wt(dst, w):
     if w is None:
         return
-    dst.w = w.data_ptr(); dst.frag = _hip.ptr(getattr(w, "_tl_frag", None))
+    dst.w = w.data_ptr(); dst.frag = _hip.ptr(getattr(w, "_tl_frag", None)); dst.x3 = _hip.ptr(getattr(w, "_tl_x3", None))
     dst.K, dst.Cout, dst.Cin = w.shape
 
 

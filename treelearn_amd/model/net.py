@@ -34,7 +34,10 @@ class TreeLearn(nn.Module):
         self.spatial_shape = spatial_shape
         self.max_num_points_per_voxel = max_num_points_per_voxel
         self.num_blocks = num_blocks
-        self.compute_dtype = compute_dtype          # torch.float32 (parity) | torch.bfloat16 (throughput)
+        # torch.float32 (exact parity mode) | torch.bfloat16 / torch.float16 (throughput) | "bf16x3" (parity-fast: fp32 storage, the convs of the
+        # large levels contract split-bf16 parts on the bf16 matrix cores -- inside the 1e-3 gate at a third of the exact mode's time; inference)
+        self.split_bf16 = isinstance(compute_dtype, str) and compute_dtype.lower() == "bf16x3"
+        self.compute_dtype = torch.float32 if self.split_bf16 else compute_dtype
         self.return_backbone_feats = True           # reference always returns them (tree_learn.py:100)
         self._plan = None
         self._geom_stream = None
@@ -60,20 +63,26 @@ class TreeLearn(nn.Module):
             elif isinstance(m, MLP):
                 m.init_weights()
 
+    def _plan_ok(self, dtype):
+        return self._plan is not None and self._plan.dtype == dtype and self._plan.x3 == (self.split_bf16 and dtype == torch.float32)
+
     def ensure_plan(self):
         """Build the fused inference plan (folded BatchNorms, packed weights) now, on the current stream.  Callers that spread
         forwards over several streams do this first: the plan is otherwise built by the first forward, on that forward's stream,
         and a forward on another stream could read weights that are still being packed."""
-        if not self.training and (self._plan is None or self._plan.dtype != self.active_dtype(False)):
-            self._plan = InferencePlan(self, self.active_dtype(False))
+        if not self.training and (self._plan is None or not self._plan_ok(self.active_dtype(False))):
+            self._plan = InferencePlan(self, self.active_dtype(False), x3=self.split_bf16)
         return self
 
     def _refresh_packed(self, dtype):
         """Training: all conv weights -> kernel layouts in ONE launch when any parameter changed (autograd.PackPlan), instead of three small
         launches per layer and step."""
         from ..autograd import PackPlan
-        convs = [(m.weight, bool(m.subm) and int(m.kernel_size) == 3) for m in self.modules()
-                 if isinstance(m, spconv.SparseConvolution) and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
+        mods = getattr(self, "_conv_modules", None)                     # (the module tree is fixed after __init__: walk it once)
+        if mods is None:
+            mods = self._conv_modules = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
+        convs = [(m.weight, bool(m.subm) and int(m.kernel_size) == 3) for m in mods
+                 if m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.is_contiguous()]
         plan = getattr(self, "_pack_plan", None)
         if plan is None or not plan.valid_for(convs, dtype):
             plan = self._pack_plan = PackPlan(convs, dtype) if convs else None
@@ -103,8 +112,8 @@ class TreeLearn(nn.Module):
         """The C-side forward executor of the current plan (model/executor.py), or None when this configuration stays on the
         Python-driven engine."""
         from .executor import Executor
-        if self._plan is None or self._plan.dtype != dtype:
-            self._plan = InferencePlan(self, dtype)
+        if self._plan is None or not self._plan_ok(dtype):
+            self._plan = InferencePlan(self, dtype, x3=self.split_bf16)
         ex = getattr(self._plan, "_exec", False)
         if ex is False:
             ex = self._plan._exec = Executor(self._plan, self) if Executor.supported(self._plan, self) else None
@@ -173,8 +182,8 @@ class TreeLearn(nn.Module):
     def forward_backbone(self, coords, input_feats, batch_ids, batch_size, **kwargs):
         dtype = self.active_dtype()
         fused = not (self.training or torch.is_grad_enabled())
-        if fused and (self._plan is None or self._plan.dtype != dtype):
-            self._plan = InferencePlan(self, dtype)
+        if fused and (self._plan is None or not self._plan_ok(dtype)):
+            self._plan = InferencePlan(self, dtype, x3=self.split_bf16)
         # training under mixed precision: level 1 in the block-local order too (the staged-unit kernel serves its 32 -> 32 forward and
         # input-gradient convs; weight gradients and the other widths read the plain table in the new order, BlockedRulebook.nn_table)
         blk_train = (not fused and dtype == torch.bfloat16 and self.unet.nPlanes[0] == 32 and os.environ.get("TL_BLK", "1") != "0"
@@ -205,8 +214,8 @@ class TreeLearn(nn.Module):
         Returns a handle for `infer`.  Calling `prepare(next_tile)` right after `infer(this_tile)` lets the next tile's
         geometry (small latency-bound kernels + two host syncs) run while this tile's convs occupy the main stream."""
         assert not self.training, "prepare/infer is the eval-mode fused path"
-        if self._plan is None or self._plan.dtype != self.active_dtype(False):
-            self._plan = InferencePlan(self, self.active_dtype(False))
+        if self._plan is None or not self._plan_ok(self.active_dtype(False)):
+            self._plan = InferencePlan(self, self.active_dtype(False), x3=self.split_bf16)
         if self._geom_stream is None:
             self._geom_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()

@@ -14,6 +14,7 @@ PROFILE = None
 BLK_LAUNCHES = 0        # conv_fwd calls that carried the block-local rulebook form (a test / tool counter)
 
 HEAD_WIDTHS = (8, 16, 32, 64)      # backbone widths tl_head_mlp is instantiated for
+PACK_X3 = False         # while True (engine.InferencePlan(..., x3=True)), fp32 weights also get their split-bf16 copy (tl_pack_weight_x3)
 
 
 def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -31,6 +32,11 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         frag = torch.empty(K * co * ci, dtype=dtype, device=w.device)
         _hip.check(L.tl_pack_weight_frag(_hip.ptr(w), co, K, ci, _hip.ptr(frag), _hip.dtype_code(dtype), _hip.stream()), "tl_pack_weight_frag")
         out._tl_frag = frag
+    if PACK_X3 and dtype == torch.float32 and ci % 32 == 0:
+        # split-bf16 copy (hi / lo bf16 parts in MFMA-piece order; as many bytes as the fp32 tensor): tl_conv_args.weight_x3
+        x3 = torch.empty(K * co * ci, dtype=torch.float32, device=w.device)
+        _hip.check(L.tl_pack_weight_x3(_hip.ptr(w), co, K, ci, _hip.ptr(x3), _hip.stream()), "tl_pack_weight_x3")
+        out._tl_x3 = x3
     return out
 
 
@@ -103,6 +109,7 @@ def conv_fwd(x: torch.Tensor, w_packed: torch.Tensor, table, n_out: int, out: to
         a.blk_lrb = blk.lrb.data_ptr(); a.blk_pmask = blk.pmask.data_ptr()
     a.table = table.data_ptr() if table is not None else None
     a.weight_frag = _hip.ptr(getattr(w_packed, "_tl_frag", None))
+    a.weight_x3 = _hip.ptr(getattr(w_packed, "_tl_x3", None))      # fp32 weights of a bf16x3 plan: the split-bf16 contraction where a kernel offers it
     a.table_one_hot = int(bool(one_hot))          # inverse conv: one valid entry per output row
     if scatter is not None:                       # ... and its scatter form (the stride-2 conv's rulebook, i32[K][n_in])
         if not one_hot or scatter.dtype != torch.int32 or tuple(scatter.shape) != (K, x.shape[0]) or not scatter.is_contiguous() or scatter.device != x.device:
