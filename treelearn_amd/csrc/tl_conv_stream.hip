@@ -161,12 +161,21 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
           u32x4 ah[RB], al[RB];
 #pragma unroll
           for (int rb = 0; rb < RB; ++rb) x3_split8(a[k % DA][rb][c][2 * J], a[k % DA][rb][c][2 * J + 1], ah[rb], al[rb]);
+          // the three products of a column block form a dependent chain on its accumulator: issue term by term ACROSS the column blocks
+          u32x4 bh[NB], blo[NB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             const char* bp = bl + nb * 32 * BROW + (c * SLOTS + 2 * J + fh) * 16;
-            const u32x4 bh = *reinterpret_cast<const u32x4*>(bp), blo = *reinterpret_cast<const u32x4*>(bp + 64);
+            bh[nb] = *reinterpret_cast<const u32x4*>(bp); blo[nb] = *reinterpret_cast<const u32x4*>(bp + 64);
+          }
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) mma16_x3(acc[rb][nb], ah[rb], al[rb], bh, blo);
+          for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[rb]), __builtin_bit_cast(bf16x8, bh[nb]), acc[rb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[rb]), __builtin_bit_cast(bf16x8, blo[nb]), acc[rb][nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[rb]), __builtin_bit_cast(bf16x8, bh[nb]), acc[rb][nb], 0, 0, 0);
           }
         }
     } else
