@@ -250,6 +250,31 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
           A[s_][t][1] = lds_r128(a0 ^ pc16[1]);
         }
       };
+#ifdef TL_DEV
+      // developer ablations (tl_set_tuning "dbg"; results are wrong on purpose): 4 = no MFMAs at all, 16 = MFMAs for 5 of the 27 taps only
+      // (the level-1 average of PRESENT taps per row: what an ideal present-pairs-only contraction would issue), 32 = also only those 5
+      // taps' LDS reads -- the floor of any formulation that skips absent (row, tap) pairs with zero bookkeeping cost
+      const int dbg = p.dbg;
+      if (dbg & (4 | 16 | 32)) {
+        issue(0, 0);
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+          const int s_ = k & 1;
+          const bool rd = !(dbg & 32) || k + 1 < 5;
+          if (k + 1 < 27 && rd) { issue(k + 1, s_ ^ 1); TL_LGKM(6); } else TL_LGKM(0);
+          TL_KEEP(B[s_][0]); TL_KEEP(B[s_][1]);
+          if (!(dbg & 4) && k < 5) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              TL_KEEP(A[s_][t][0]); TL_KEEP(A[s_][t][1]);
+              acc[t] = h16_mfma(A[s_][t][0], B[s_][0], acc[t]);
+              acc[t] = h16_mfma(A[s_][t][1], B[s_][1], acc[t]);
+            }
+          }
+        }
+      } else
+#endif
+      {
       issue(0, 0);
 #pragma unroll
       for (int k = 0; k < 27; ++k) {
@@ -262,6 +287,7 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk(ConvP p) {
           acc[t] = h16_mfma(A[s_][t][0], B[s_][0], acc[t]);
           acc[t] = h16_mfma(A[s_][t][1], B[s_][1], acc[t]);
         }
+      }
       }
     }
     TL_SWAIT(d3r);
