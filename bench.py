@@ -212,14 +212,25 @@ def sharded_plot(model, dist, rank, world, n_tiles, steps, warmup):
     tiles), every rank materialising only its own tiles, inputs resident in HBM; one step = the whole plot through
     util.sharding.get_pointwise_preds_sharded: per-rank tile loop (inner-square filter on the device) + the two collectives of
     the record gather INSIDE the timed region.  Returns (seconds per plot (max over ranks), total points, gathered rows)."""
-    from treelearn_amd.synth import CONFIGS, make_batch, plot_tiles
+    from treelearn_amd.synth import PLOT4, make_plot, plot_squares
     from treelearn_amd.util.sharding import TileList, assign_tiles, get_pointwise_preds_sharded
+    from treelearn_amd.util.tiles import PlotTiler
+    # ONE synthetic plot (68 x 68 m for 64 tiles), resident in HBM on every rank; the tiles are its overlapping 40 x 40 m crops (inner squares of
+    # 8 m every 4 m: neighbouring tiles share 36 m, the ensemble has duplicates to average), cut on the device by tl_tile_crop (PlotTiler)
+    side = int(np.ceil(n_tiles ** 0.5))                                  # (a count that is not a square takes the first n_tiles squares of the next grid)
+    geo = dict(PLOT4, tiles_per_side=side)
+    plot = make_plot(**geo, seed=0)
+    inner, outer = plot_squares(**geo)
+    tiler = PlotTiler(plot["points"], plot["instance_label"].astype(np.float32), plot["feat"])
     mine = assign_tiles([1] * n_tiles, world)[rank]
-    cache = {}
     batches = {}
     for i in mine:
-        b = make_batch(plot_tiles([i], CONFIGS["config2"], cache))
-        batches[i] = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+        b = tiler.tile_batch(inner[i], outer[i], geo["inner_edge"], offset_labels="none", tile_index=i)
+        assert b is not None, "every inner square of the synthetic plot holds points"
+        torch.cuda.current_stream().wait_event(b.pop("_ready_event"))
+        batches[i] = b
+    torch.cuda.synchronize()
+    del tiler
     npts = torch.zeros(n_tiles, dtype=torch.int64, device="cuda")
     for i in mine:
         npts[i] = batches[i]["coords"].shape[0]
@@ -314,6 +325,7 @@ def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
     batch = make_batch([make_tile(**cfg, seed=0)])
     n_pts = batch["coords"].shape[0]
     dtype = DTYPES[dtype_name]
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); mem0 = torch.cuda.memory_allocated()
     model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000] if cfg["voxel"] >= 0.1 else None, voxel_size=cfg["voxel"], compute_dtype=dtype)
     model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
     gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -357,7 +369,8 @@ def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
     ach = by / (ms * 1e-3) / 1e9
     out = dict(value=n_pts / sec / 1e6, unit="Mpoints/s", ms_per_step=sec * 1e3, steps=steps, warmup=warmup, dtype=dtype_name, tiles_in_flight=nfl,
                weights="synthetic, BatchNorm running statistics re-estimated on the tile (trained-like)" if trained_like else "synthetic random init",
-               nonfinite_outputs=nonfinite,
+               nonfinite_outputs=nonfinite, active_voxels=(model._plan._exec.last["level_n"][0] if getattr(model._plan, "_exec", None) else None),
+               peak_hbm_gb=(torch.cuda.max_memory_allocated() - mem0) / 1e9,
                workload=f"{workload}: single {cfg['extent']:.0f}x{cfg['extent']:.0f} m tile, voxel {cfg['voxel']} m, {n_pts} points, {model.num_blocks}-level 32-ch sparse U-Net fwd",
                roofline=dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None, launches_per_step=len(recs),
                              conv_ms_per_step=ms, algorithmic_gb_per_step=by / 1e9, mfma_tflops=fl / (ms * 1e-3) / 1e12))
@@ -464,7 +477,7 @@ def main():
             res = dict(metric="Mpoints/sec through sparse U-Net fwd (0.1 m voxel, 40x40 m tile)", value=total_pts / sec / 1e6, unit="Mpoints/s",
                        n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3, higher_is_better=True, scaling="strong",
                        vs_baseline=None, dtype=args.dtype, data="synthetic",
-                       config=dict(workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares) sharded "
+                       config=dict(workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares every 4 m) of ONE synthetic plot, cut on the device (PlotTiler), sharded "
                                             f"round-robin over {world} GPU(s), device-resident record gather (2 collectives) inside the timed region",
                                    tiles=args.plot_tiles, total_points=total_pts, gathered_rows=rows, ms_per_tile=sec * 1e3 / args.plot_tiles * world),
                        roofline=None, cpu_baseline=None)
@@ -474,7 +487,7 @@ def main():
         return
 
     used_rccl_extra = False
-    cfg = CONFIGS[args.workload]
+    cfg = CONFIGS["config5_20m" if args.workload == "config5" else args.workload]     # (config 5 at BASELINE's ~20 M active voxels)
     tile = make_tile(**cfg, seed=rank)                                 # every rank its own tile
     batch = make_batch([tile])
     n_pts = batch["coords"].shape[0]
@@ -650,7 +663,13 @@ def main():
             torch.cuda.empty_cache()
             try:
                 # BASELINE words config 5 as fp16: float16 kernels on trained-like weights, overflow count in the block
-                res["config5"] = forward_block("config5", "fp16" if args.dtype == "bf16" else args.dtype, 5, 2, nfl, trained_like=True)
+                ex0 = model._executor(model.active_dtype(False))
+                if ex0 is not None:
+                    ex0.release_memory()                                # the headline model's arenas (re-allocated by its next forward)
+                torch.cuda.empty_cache()
+                # BASELINE's size: ~20 M active voxels (fill 0.16); two tiles in flight (a tile of this size fills the chip by itself and
+                # every stream in flight holds an arena of ~35 GB)
+                res["config5"] = forward_block("config5_20m", "fp16" if args.dtype == "bf16" else args.dtype, 5, 2, min(nfl, 2), trained_like=True)
             except Exception as e:                                      # noqa: BLE001
                 res["config5"] = dict(error=f"{type(e).__name__}: {e}")
         if world == 1 and args.workload == "config2" and not args.no_extra_workloads and dist is None:
@@ -665,7 +684,7 @@ def main():
                 sec4, tp4, rows4 = sharded_plot(model, d4, 0, 1, args.plot_tiles, 1, 1)
                 res["config4"] = dict(value=tp4 / sec4 / 1e6, unit="Mpoints/s", ms_per_plot=sec4 * 1e3, ms_per_tile=sec4 * 1e3 / args.plot_tiles, tiles=args.plot_tiles,
                                       total_points=tp4, gathered_rows=rows4, collectives_per_plot=2, n_gpus=1, dtype=args.dtype,
-                                      workload=f"config4: whole-plot inference, {args.plot_tiles} 40x40 m tiles (voxel 0.1 m, 8 m inner squares) through "
+                                      workload=f"config4: whole-plot inference, {args.plot_tiles} overlapping 40x40 m tiles (voxel 0.1 m, 8 m inner squares every 4 m) of ONE synthetic plot through "
                                                "get_pointwise_preds_sharded on 1 GPU, record gather timed")
                 d4.destroy_process_group()
             except Exception as e:                                      # noqa: BLE001

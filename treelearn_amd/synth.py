@@ -15,7 +15,8 @@ import numpy as np
 CONFIGS = {
     "config1": dict(extent=10.0, voxel=0.2, n_trees=4, fill=0.10),
     "config2": dict(extent=40.0, voxel=0.1, n_trees=64, fill=0.10),
-    "config5": dict(extent=40.0, voxel=0.05, n_trees=64, fill=0.12),
+    "config5": dict(extent=40.0, voxel=0.05, n_trees=64, fill=0.12),          # 15.2 M points (the parity tests' stress tile)
+    "config5_20m": dict(extent=40.0, voxel=0.05, n_trees=64, fill=0.16),      # BASELINE config 5's "~20 M active voxels" (fill 0.16)
 }
 
 
@@ -100,6 +101,33 @@ def plot_tiles(indices, cfg=None, cache=None):
             cache[seed] = make_tile(**cfg, seed=seed)
         out.append(tile_variant(cache[seed], sym))
     return out
+
+
+PLOT4 = dict(tiles_per_side=8, inner_edge=8.0, outer_edge=16.0, stride=0.5)     # BASELINE config 4: 64 overlapping 40 x 40 m tiles of ONE plot
+
+
+def plot_squares(tiles_per_side=8, inner_edge=8.0, outer_edge=16.0, stride=0.5):
+    """Inner and outer squares (x0, x1, y0, y1), float64 [T, 4], of the config-4 plot: tiles_per_side^2 inner squares of `inner_edge` laid
+    out every stride * inner_edge (the reference's generate_tiles produces its inference tiles the same way: overlapping inner squares,
+    each with its context of outer_edge on every side -- tree_learn/util/data_preparation.py:362-389, tools/pipeline/pipeline.py:52-70),
+    row-major from the top-left corner, the plot centred on the origin.  Neighbouring 40 m tiles overlap by 36 m: every point of the plot's
+    interior is predicted by up to four tiles' inner squares, which is what `ensemble` then averages."""
+    step = stride * inner_edge
+    span = (tiles_per_side - 1) * step + inner_edge
+    x0 = -span / 2 + step * np.arange(tiles_per_side)
+    y1 = span / 2 - step * np.arange(tiles_per_side)
+    inner = np.stack([np.tile(x0, tiles_per_side), np.tile(x0 + inner_edge, tiles_per_side),
+                      np.repeat(y1 - inner_edge, tiles_per_side), np.repeat(y1, tiles_per_side)], axis=1).astype(np.float64)
+    outer = inner + np.array([-outer_edge, outer_edge, -outer_edge, outer_edge])
+    return inner, outer
+
+
+def make_plot(tiles_per_side=8, inner_edge=8.0, outer_edge=16.0, stride=0.5, voxel=0.1, fill=0.10, seed=0):
+    """The ONE synthetic plot the config-4 tiles are cropped from: the config-2 generator over the union of all outer squares (68 x 68 m for
+    the default 8 x 8 tiles), with the tree density of config 2 (64 trees per 40 x 40 m)."""
+    inner, outer = plot_squares(tiles_per_side, inner_edge, outer_edge, stride)
+    extent = float(outer[:, 1].max() - outer[:, 0].min())
+    return make_tile(extent=extent, voxel=voxel, n_trees=int(round(64 * (extent / 40.0) ** 2)), fill=fill, seed=seed)
 
 
 def make_batch(tiles, inner_square_edge_length=8.0):

@@ -114,28 +114,41 @@ class PlotTiler:
         main = torch.cuda.current_stream()
         self._stream.wait_stream(main)                         # the plot arrays may have just been produced on the caller's stream
         for t in range(len(inner)):
-            # The crop (and its one host sync for the row count) goes on the tiler's own stream: a consumer that pulls the next
-            # tile before launching the current forward (util/pipeline.get_pointwise_preds) then never waits for its own convs.
-            with torch.cuda.stream(self._stream):
-                kept, n_inner, center = self.crop(inner[t], outer[t], inner_square_edge_length)
-                if n_inner == 0:                               # data_preparation.py:412-427: tiles whose inner square is empty are dropped
-                    continue
-                b = self._buf
-                coords = b["coords"][:kept].clone(); inst = b["inst"][:kept].clone(); sem = b["sem"][:kept].clone()
-                m_inner = b["m_inner"][:kept].bool(); m_sem = b["m_sem"][:kept].bool()
-                if offset_labels == "host":
-                    off, valid = _offset_labels_host(coords.cpu().numpy(), inst.cpu().numpy(), sem.cpu().numpy())
-                    off_t = torch.from_numpy(off.astype(np.float32)).to(coords.device)
-                    m_off = m_sem & (sem != NON_TREE_CLASS) & torch.from_numpy(valid).to(coords.device)
-                else:
-                    off_t = torch.zeros_like(coords); m_off = torch.zeros_like(m_sem)
-                c32 = torch.from_numpy(center.astype(np.float32)).to(coords.device)
-                batch = dict(coords=coords, input_feats=b["feats"][:kept, :F].clone(), batch_ids=torch.zeros(kept, dtype=torch.int64, device=coords.device),
-                             semantic_labels=sem, instance_labels=inst, masks_inner=m_inner, masks_off=m_off, masks_sem=m_sem,
-                             offset_labels=off_t, batch_size=1, centers=c32.expand(kept, 3).contiguous(), tile_index=t)
-                ready = torch.cuda.Event(); ready.record(self._stream)
-            for v in batch.values():
-                if torch.is_tensor(v):
-                    v.record_stream(main)                      # allocated on the tiler's stream, consumed on the caller's
-            batch["_ready_event"] = ready                      # consumers on another stream wait for this before reading the tile
-            yield batch
+            batch = self.tile_batch(inner[t], outer[t], inner_square_edge_length, offset_labels, tile_index=t)
+            if batch is not None:
+                yield batch
+
+    def tile_batch(self, inner, outer, inner_square_edge_length, offset_labels="host", tile_index=0):
+        """ONE tile as a batch dict (collate_fn's keys, batch size 1) from its inner / outer square (x0, x1, y0, y1), or None when the inner
+        square holds no point (data_preparation.py:412-427).  Random access for callers that own only some tiles of a plot (a rank of the
+        sharded tile loop) or lay the squares out themselves."""
+        assert offset_labels in ("host", "none")
+        F = self.feats.shape[1]
+        main = torch.cuda.current_stream()
+        self._stream.wait_stream(main)                         # the plot arrays may have just been produced on the caller's stream
+        t = tile_index
+        # The crop (and its one host sync for the row count) goes on the tiler's own stream: a consumer that pulls the next
+        # tile before launching the current forward (util/pipeline.get_pointwise_preds) then never waits for its own convs.
+        with torch.cuda.stream(self._stream):
+            kept, n_inner, center = self.crop(np.asarray(inner, np.float64), np.asarray(outer, np.float64), inner_square_edge_length)
+            if n_inner == 0:                               # data_preparation.py:412-427: tiles whose inner square is empty are dropped
+                return None
+            b = self._buf
+            coords = b["coords"][:kept].clone(); inst = b["inst"][:kept].clone(); sem = b["sem"][:kept].clone()
+            m_inner = b["m_inner"][:kept].bool(); m_sem = b["m_sem"][:kept].bool()
+            if offset_labels == "host":
+                off, valid = _offset_labels_host(coords.cpu().numpy(), inst.cpu().numpy(), sem.cpu().numpy())
+                off_t = torch.from_numpy(off.astype(np.float32)).to(coords.device)
+                m_off = m_sem & (sem != NON_TREE_CLASS) & torch.from_numpy(valid).to(coords.device)
+            else:
+                off_t = torch.zeros_like(coords); m_off = torch.zeros_like(m_sem)
+            c32 = torch.from_numpy(center.astype(np.float32)).to(coords.device)
+            batch = dict(coords=coords, input_feats=b["feats"][:kept, :F].clone(), batch_ids=torch.zeros(kept, dtype=torch.int64, device=coords.device),
+                         semantic_labels=sem, instance_labels=inst, masks_inner=m_inner, masks_off=m_off, masks_sem=m_sem,
+                         offset_labels=off_t, batch_size=1, centers=c32.expand(kept, 3).contiguous(), tile_index=t)
+            ready = torch.cuda.Event(); ready.record(self._stream)
+        for v in batch.values():
+            if torch.is_tensor(v):
+                v.record_stream(main)                      # allocated on the tiler's stream, consumed on the caller's
+        batch["_ready_event"] = ready                      # consumers on another stream wait for this before reading the tile
+        return batch
