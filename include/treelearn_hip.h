@@ -513,6 +513,7 @@ int tl_knn_vote_grid(const float* ref_sorted_xyz, const int64_t* ref_sorted_labe
 #define TL_MAX_LEVELS 8
 #define TL_ERR_ARENA (-4)        /* arena too small: args->needed_bytes */
 #define TL_ERR_REACH_ZERO (-5)   /* a level's spatial shape or voxel set collapsed (spconv's "reach zero!!!", util/pipeline.py:91-97) */
+#define TL_ERR_BLK (-7)          /* the block-local unit builder of the PREVIOUS tl_forward on this context flagged skipped units (an internal assertion) */
 #define TL_ERR_EXTENT (-6)       /* the tile's voxel extent exceeds spatial_shape, a batch id is out of range, or a voxel coordinate leaves [0, 65536) */
 typedef struct tl_affine { const float* scale; const float* shift; } tl_affine;
 typedef struct tl_weight { const void* w; const void* frag; int32_t K, Cout, Cin, reserved; const void* x3; /* tl_pack_weight_x3 copy or NULL */ } tl_weight;

@@ -1364,3 +1364,29 @@ def test_point_to_voxel_shim_runs_the_reference_voxelize_golden_g3(golden_dir):
     assert ids.tolist() == [0, 0, 0, -1, -1, -1, -1, 2, 1]          # ascending (x, y, z): (0,0,0), (0,2,4), (0,4,4) kept; (2,2,2), (4,4,4) over capacity
     assert num.tolist() == [2, 1, 1] and vc.tolist() == [[0, 0, 0], [4, 2, 0], [4, 4, 0]]
     assert vf[0, :, 3].tolist() == [1.0, 2.0] and vf[1, :, 3].tolist() == [9.0, 0.0]
+
+
+def test_hdbscan_prim_fallback_threshold_is_a_documented_knob():
+    """Tie-heavy input ABOVE the Prim fall-back cap (50 000 points by default: the O(n^2) form takes minutes beyond): `auto` keeps the quadtree
+    form's tree and warns; `prim_fallback_max` (or TL_HDBSCAN_PRIM_MAX) moves the cap, and with the cap raised the result IS the Prim form's.
+    The kept-tree labels are the same clusters with >= 97 % identical point assignments on a 0.25 m lattice (INTEGRATION.md states this)."""
+    import warnings
+    from treelearn_amd.cluster import hdbscan
+    rng = np.random.default_rng(3)
+    n = 52_000
+    c = rng.uniform(0, 120, (40, 2))
+    xy = (np.round((c[rng.integers(0, 40, n)] + rng.normal(0, 1.5, (n, 2))) * 4) / 4).astype(np.float32)       # lattice + duplicates: ties everywhere
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        kept = hdbscan(xy, 50)
+    assert any("tied tree weights" in str(x.message) for x in w), "the kept-tree path must say so"
+    prim = hdbscan(xy, 50, algorithm="prim")
+    np.testing.assert_array_equal(hdbscan(xy, 50, prim_fallback_max=60_000), prim)
+    assert len(set(kept[kept >= 0])) == len(set(prim[prim >= 0]))
+    agree = 0
+    for cl in set(kept.tolist()):
+        m = kept == cl
+        vals, cnts = np.unique(prim[m], return_counts=True)
+        agree += cnts.max() if cl != -1 else int((prim[m] == -1).sum())
+    print(f"hdbscan kept-tree vs Prim form on {n} tied points: {agree / n:.4f} identical assignments")
+    assert agree / n >= 0.97

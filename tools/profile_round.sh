@@ -2,6 +2,7 @@
 # `python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<tag>` here.  Two un-profiled default lines (four tiles in
 # flight = the headline configuration; one tile at a time), kernel-trace stats for BOTH, and the three PMC passes (one tile at a
 # time: cleaner per-kernel attribution; counters never combined with trace domains other than the kernel trace).
+export GPU_MAX_HW_QUEUES=8   # rocprofv3 starts the HIP runtime before python runs: the package's own default would come too late
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_${1:-r2}; mkdir -p $O
 Q="--no-cpu-baseline --no-fp32-mode --no-power-probe --no-extra-workloads"

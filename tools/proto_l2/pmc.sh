@@ -1,4 +1,5 @@
 # effective shader clock and MFMA-busy share of the gather kernel and the two prototypes (rocprofv3 PMC pass over run_l2.py)
+export GPU_MAX_HW_QUEUES=8   # rocprofv3 starts the HIP runtime before python runs: the package's own default would come too late
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/proto/pmc; rm -rf $O; mkdir -p $O
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O -o p -- python3 tools/proto_l2/run_l2.py > $O/out.txt 2> $O/err.txt
 python3 - <<'PY'

@@ -44,6 +44,14 @@ def _forced_mask(bn, relu):
     return RELU_MASK_SOURCE.get(bn) if (RELU_MASK_SOURCE is not None and relu) else None
 
 
+CAT_IN_PLACE = os.environ.get("TL_TRAIN_CAT", "1") != "0"   # skip concat without a copy: both producers write into the halves of one buffer (0: torch.cat, for A/B)
+
+
+def _rows_ok(x):
+    """A feature matrix the kernels take as it is: unit column stride, 16-B aligned rows (a column half of a skip-concat buffer qualifies)."""
+    return x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+
+
 def set_stats(t, stats):
     """Attach a conv epilogue's per-channel partial sums to its result `t` for the BatchNorm that consumes it, with the tensor's version
     counter and address: an in-place change of the features in between (an inplace ReLU, `mul_`, a user module in a SparseSequential) makes
@@ -59,16 +67,16 @@ def get_stats(t):
     return stats if (t._version == version and t.data_ptr() == addr) else None
 
 
-def _conv_with_stats(x, w_packed, ref, residual, holder):
+def _conv_with_stats(x, w_packed, ref, residual, holder, out=None):
     """Forward conv whose epilogue also sums y and y^2 per channel when the kernel family can (ops.conv_fwd(epi="stats")); the partial
     sums go to holder["stats"] = [(parts, nparts, Cout)] for the BatchNorm that consumes the result (attached to the output tensor as
     `_tl_stats` by the caller)."""
     if holder is not None and FUSE_BN and ref.n_out > 1:
-        r = ops.conv_fwd(x, w_packed, ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot, epi="stats")
+        r = ops.conv_fwd(x, w_packed, ref.table, ref.n_out, out=out, residual=residual, one_hot=ref.one_hot, epi="stats")
         if r is not None:
             holder["stats"] = [(r[1], r[2], int(w_packed.shape[1]))]
             return r[0]
-    return ops.conv_fwd(x, w_packed, ref.table, ref.n_out, residual=residual, one_hot=ref.one_hot)
+    return ops.conv_fwd(x, w_packed, ref.table, ref.n_out, out=out, residual=residual, one_hot=ref.one_hot)
 
 
 _dgrad_cache = {}           # id(parameter) -> (weakref, (version, dtype, device, data_ptr, flip), [K, Cin, Cout] weights of the input-gradient conv)
@@ -202,8 +210,9 @@ class _BNReLUConvFn(torch.autograd.Function):
     Where a kernel family has no such epilogue the separate passes run instead (same results up to summation order)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, residual, bn, relu, ref, want_skip, stats_in, holder):
-        x = x.contiguous()
+    def forward(ctx, x, gamma, beta, weight, residual, bn, relu, ref, want_skip, stats_in, holder, out=None):
+        if not _rows_ok(x) or (stats_in is None and not x.is_contiguous()):     # (the statistics kernel reads dense matrices; a column view with
+            x = x.contiguous()                                                  #  its producer's partial sums goes through as it is)
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
         fm = _forced_mask(bn, relu)
         if fm is not None:
@@ -212,7 +221,7 @@ class _BNReLUConvFn(torch.autograd.Function):
             a = ops.affine_relu(x, st[2], st[3], relu)
         if RELU_MASK_SINK is not None and relu:
             RELU_MASK_SINK[bn] = fm if fm is not None else a > 0
-        y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder)
+        y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder, out=out)
         ctx.save_for_backward(x, a, st, weight)
         ctx.ref, ctx.relu, ctx.fm = ref, relu, fm
         if want_skip:
@@ -234,15 +243,40 @@ class _BNReLUConvFn(torch.autograd.Function):
             dx, dgamma, dbeta = ops.bn_train_bwd(x, ga * ctx.fm.to(ga.dtype), st, False, dx_add=gskip)
         else:
             dx, dgamma, dbeta, gw = bw.bn_conv_backward(x, a, st, ctx.relu, weight, ctx.ref, gy, need_gw, gskip)
-        return dx, dgamma, dbeta, gw, (gy if ctx.needs_input_grad[4] else None), None, None, None, None, None, None
+        return dx, dgamma, dbeta, gw, (gy if ctx.needs_input_grad[4] else None), None, None, None, None, None, None, None
 
 
-def bn_relu_conv(x, bn, relu, weight, ref, residual=None, want_skip=False):
+class _CatViewsFn(torch.autograd.Function):
+    """cat((a, b), dim=1) when a and b ARE the two column halves of `buf` (their producers wrote them there: reference blocks.py:146 without
+    the copy).  Backward hands the halves of the incoming gradient on as column views (the kernels take a row stride)."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.C = a.shape[1]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.C], g[:, ctx.C:], None
+
+
+def cat_views(a, b, buf):
+    """The skip concat of UBlock.forward: `buf` if a / b alias its halves, else torch.cat."""
+    C = a.shape[1]
+    if (buf is not None and a.dtype == buf.dtype and b.dtype == buf.dtype and b.shape[1] == buf.shape[1] - C and a.data_ptr() == buf.data_ptr()
+            and b.data_ptr() == buf.data_ptr() + C * buf.element_size() and a.stride(0) == buf.stride(0) and b.stride(0) == buf.stride(0)):
+        return _CatViewsFn.apply(a, b, buf)
+    return torch.cat((a, b), dim=1)
+
+
+def bn_relu_conv(x, bn, relu, weight, ref, residual=None, want_skip=False, out=None):
     """Fused training-mode BatchNorm1d(+ReLU) -> sparse conv of the feature matrix x; returns y, or (y, skip) with want_skip (skip = x
     passed through: the caller's identity path must use it, see _BNReLUTrainFn).  y carries `_tl_stats` when the conv kernel summed it."""
     holder = {}
     stats_in = get_stats(x) if FUSE_BN else None
-    out = _BNReLUConvFn.apply(x, bn.weight, bn.bias, weight, residual, bn, relu, ref, want_skip, stats_in, holder)
+    if out is not None and (out.dtype != x.dtype or not _rows_ok(out) or out.shape != (ref.n_out, weight.shape[0])):
+        out = None                                              # not a view the conv can write: plain result (the caller's concat then copies)
+    out = _BNReLUConvFn.apply(x, bn.weight, bn.bias, weight, residual, bn, relu, ref, want_skip, stats_in, holder, out)
     y = out[0] if want_skip else out
     if "stats" in holder:
         set_stats(y, holder["stats"])

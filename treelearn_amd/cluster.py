@@ -1,5 +1,6 @@
 """Instance grouping on the GPU (reference tree_learn/util/pipeline.py:173-191)."""
 import ctypes as _c
+import os
 
 import numpy as np
 import torch
@@ -32,13 +33,13 @@ TIE_FRACTION = 0.10
 # ... but only up to this many points: the Prim form is O(n^2) (50 k points: ~1 s; 400 k: minutes).  Above it the grid form's tree is kept
 # (it is a minimal tree of the same weights, put into Prim's order; labels can differ from sklearn's only where exact ties decide a split)
 # and a warning says so.
-PRIM_FALLBACK_MAX_POINTS = 50_000
+PRIM_FALLBACK_MAX_POINTS = int(os.environ.get("TL_HDBSCAN_PRIM_MAX", "50000"))     # (argument `prim_fallback_max` / env TL_HDBSCAN_PRIM_MAX)
 
 
 GRID_MIN_POINTS = 8192          # from here on the quadtree / Boruvka device stage replaces the two O(n^2) passes
 
 
-def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False, algorithm="auto"):
+def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False, algorithm="auto", prim_fallback_max=None):
     """sklearn HDBSCAN(min_cluster_size=m).fit(xy).labels_ (min_samples = m, EOM): core distances + MST of the mutual-reachability
     graph on the GPU, hierarchy condensation on the host (tl_hdbscan_labels_host).
     algorithm: "prim" = tl_hdbscan_mst (O(n^2), sklearn's edge order exactly), "grid" = tl_hdbscan_mst_grid (quadtree k-NN + Boruvka,
@@ -78,7 +79,7 @@ def hdbscan(xy, min_cluster_size, device="cuda", return_mst=False, algorithm="au
             # coordinates, tiny min_samples) the default therefore re-builds the tree in Prim's own order -- slower, sklearn's labels.
             ws_ = np.sort(gw)
             if (ws_[1:] == ws_[:-1]).sum() > TIE_FRACTION * max(len(gw), 1):
-                if n <= PRIM_FALLBACK_MAX_POINTS:
+                if n <= (PRIM_FALLBACK_MAX_POINTS if prim_fallback_max is None else prim_fallback_max):
                     return hdbscan(xy, min_cluster_size, device=device, return_mst=return_mst, algorithm="prim")
                 import warnings
                 warnings.warn(f"hdbscan: {n} points with more than {TIE_FRACTION:.0%} exactly tied tree weights (quantised or duplicated "

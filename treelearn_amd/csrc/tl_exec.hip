@@ -8,6 +8,7 @@
 // microseconds, activations come out of the caller's arena through a best-fit free list (planned by a dry run of the same code, so
 // `needed_bytes` is exact), and the launch thread never waits for an interpreter.  Same kernels, same order, same arguments as
 // treelearn_amd/model/engine.py issues them: results are bit-identical (tests/test_gpu_exec.py).
+#include <string.h>
 #include <vector>
 
 #include "tl_common.h"
@@ -310,7 +311,7 @@ extern "C" {
 tl_exec* tl_exec_create(void) {
   tl_exec* ex = new (std::nothrow) tl_exec();
   if (!ex) return nullptr;
-  if (hipHostMalloc(reinterpret_cast<void**>(&ex->host), 64, hipHostMallocDefault) != hipSuccess ||
+  if (hipHostMalloc(reinterpret_cast<void**>(&ex->host), 64, hipHostMallocDefault) != hipSuccess || (memset(ex->host, 0, 64), false) ||
       hipEventCreateWithFlags(&ex->ev_main, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ex->ev_side, hipEventDisableTiming) != hipSuccess) {
     tl_exec_destroy(ex);
     return nullptr;
@@ -371,6 +372,10 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
   if (rc != TL_OK) return rc;
   if (hipMemcpyAsync(ex->host, R.ar.at(o_maxc), 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return TL_ERR_LAUNCH;   // host sync #1
   if (ex->host[3]) return TL_ERR_EXTENT;
+  if (ex->host[8]) {                    // the block-local builder's error flag of the PREVIOUS forward on this context (copied behind it, complete by now)
+    ex->host[8] = 0;
+    return TL_ERR_BLK;
+  }
   const int32_t extent[3] = {ex->host[0] + 1, ex->host[1] + 1, ex->host[2] + 1};
   int32_t shape[TL_MAX_LEVELS][3];
   for (int j = 0; j < 3; ++j) {
@@ -474,6 +479,9 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
   rc = tl_rulebooks_build(arr, nl, W(o_m1), o_m1_end - o_m1, pcoords, N, reinterpret_cast<int64_t*>(W(R.o_v2p)), stream);
   if (rc != TL_OK) return rc;
   if (side != s && (hipEventRecord(ex->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, ex->ev_side, 0) != hipSuccess)) return TL_ERR_LAUNCH;
+  // tl_blk_build's error flag (units skipped: cannot happen with cap_units >= n and halo_max <= 126, so this is an assertion) goes home behind
+  // the builder and is looked at by the next forward of this context after its first read-back -- a check that costs no synchronisation
+  if (R.blocked && hipMemcpyAsync(ex->host + 8, W(R.o_counter) + 1, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return TL_ERR_LAUNCH;
 
   // ---- the network
   R.network();

@@ -142,8 +142,8 @@ class TreeLearn(nn.Module):
     def _voxelize(self, coords, input_feats, batch_ids, batch_size, blocked=False, nn_table=False):
         """`voxelize` of tree_learn.py:129-167 on the HIP library: geometry + voxel features
         ([M, dim_feat+dim_coord] in (feat, x, y, z) order; ones unless use_feats/use_coords).  `blocked`: level 1 in the block-local row
-        order of the fused inference engine (geometry.BlockedRulebook); the voxel features stay in canonical order (the engine's input
-        conv carries them over)."""
+        order of the fused inference engine (geometry.BlockedRulebook); the voxel features are then averaged through the blocked v2p map,
+        i.e. they come back in the NEW row order (the engine treats them so)."""
         geom = G.build_geometry(coords.contiguous(), batch_ids.contiguous(), int(batch_size), self.voxel_size,
                                 self.num_blocks, self.spatial_shape, blocked=blocked, ref_table=(self.use_coords or self.use_feats) and not nn_table,
                                 nn_table=nn_table)

@@ -93,7 +93,10 @@ class ResidualBlock(SparseModule):
             norm_fn(out_channels), nn.ReLU(),
             spconv.SubMConv3d(out_channels, out_channels, kernel_size=int(kernel_size), padding=pad, bias=False, indice_key=indice_key))
 
-    def forward(self, input):
+    accepts_out = True
+
+    def forward(self, input, out=None):
+        """`out` (training, optional): the [n, Cout] column view the block's result should be written into (UBlock's skip-concat buffer)."""
         last = len(self.conv_branch) - 1
         cb = self.conv_branch
         from ..autograd import fusable_bn
@@ -103,8 +106,8 @@ class ResidualBlock(SparseModule):
             # input back (`skip`) for the identity branch, the second adds the identity result in its epilogue
             t, skip = cb[2].forward_fused(input, cb[0], True, want_skip=True)
             res = self.i_branch(input.replace_feature(skip)).features
-            out, _ = cb[5].forward_fused(t, cb[3], True, residual=res)
-            return out
+            y, _ = cb[5].forward_fused(t, cb[3], True, residual=res, out=out)
+            return y
         # the input feeds the conv branch AND the identity branch: in training the first BatchNorm hands it back (`skip`) and the
         # identity branch takes that, so the two gradients of the fan-out are added inside the BatchNorm backward kernel
         branch, skip = self.conv_branch(input, stop=last, want_skip=True)
@@ -134,13 +137,21 @@ class UBlock(nn.Module):
                 for i in range(block_reps)))
 
     def forward(self, input):
-        output = self.blocks(input)
+        from ..autograd import CAT_IN_PLACE, cat_views, get_stats, set_stats
+        buf = None
+        f = input.features
+        if len(self.nPlanes) > 1 and CAT_IN_PLACE and f.is_cuda and torch.is_grad_enabled() and f.requires_grad and self.training:
+            # training: the skip concat (reference blocks.py:146) without its copy -- the encoder's last block and the inverse conv write
+            # straight into the two column halves of one [n, 2C] buffer (what the inference engine does with its views)
+            C = self.nPlanes[0]
+            dt = spconv.SparseConvolution.amp_dtype or f.dtype
+            buf = torch.empty((f.shape[0], 2 * C), dtype=dt, device=f.device)
+        output = self.blocks(input, out=buf[:, :self.nPlanes[0]]) if buf is not None else self.blocks(input)
         if len(self.nPlanes) > 1:
             down, skip = self.conv(output, want_skip=True)     # same fan-out as in ResidualBlock: skip = the features the concat takes
             identity = skip if skip is not None else output.features
-            dec = self.deconv(self.u(down))
-            cat = torch.cat((identity, dec.features), dim=1)
-            from ..autograd import get_stats, set_stats
+            dec = self.deconv(self.u(down), out=buf[:, self.nPlanes[0]:]) if buf is not None else self.deconv(self.u(down))
+            cat = cat_views(identity, dec.features, buf)
             sa, sb = get_stats(identity), get_stats(dec.features)
             if sa is not None and sb is not None:              # per-channel statistics of a concat = those of its halves
                 set_stats(cat, list(sa) + list(sb))

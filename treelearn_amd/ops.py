@@ -234,8 +234,9 @@ def affine_relu(x, scale, shift, relu, out_dtype=None):
     """y = relu?(x * scale + shift) over the rows of x (tl_affine_relu); x and y may differ in dtype only through `out_dtype`
     == x.dtype (the kernel is single-dtype), so a bf16 result of an fp32 input is produced by the caller's cast."""
     L = _hip.lib()
-    _hip.require_cuda(x, "x")
-    y = torch.empty_like(x)
+    if not x.is_cuda or x.stride(1) != 1:
+        raise RuntimeError("affine_relu: x must live on the GPU with unit column stride (a column view of a wider matrix is fine); no CPU fallback")
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     _hip.check(L.tl_affine_relu(_hip.ptr(x), x.stride(0), _hip.ptr(y), y.stride(0), x.shape[0], x.shape[1], _hip.dtype_code(x.dtype),
                                 _hip.ptr(scale), _hip.ptr(shift), int(bool(relu)), _hip.stream()), "tl_affine_relu")
     return y

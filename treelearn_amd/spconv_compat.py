@@ -58,19 +58,21 @@ class SparseSequential(SparseModule):
     def __len__(self):
         return len(self._modules)
 
-    def forward(self, x, stop=None, want_skip=False):
+    def forward(self, x, stop=None, want_skip=False, out=None):
         """`stop`: run only the first `stop` modules (the caller runs the rest itself, e.g. the last conv with its residual fused).
         `want_skip`: returns (result, skip) where skip is the input's feature matrix handed back by the FIRST module when that is a
         BatchNorm served by the HIP training kernels (autograd.bn_relu_train(skip=True): the caller's identity / skip path must use
         it instead of the input so that the two gradients of the fan-out are added inside the BatchNorm backward kernel), else None."""
         from .autograd import bn_relu_train, fusable_bn      # late import (autograd depends on ops)
+        # `out` (training, optional): a [n, C] column view the LAST module's conv should write its result into (a half of the skip-concat
+        # buffer of UBlock.forward); modules that cannot do so ignore it and the caller's concat copies
         mods = list(self._modules.values())[:stop]
         i = 0
         skip = None
         while i < len(mods):
             module = mods[i]
             if isinstance(module, SparseModule):
-                x = module(x)
+                x = module(x, out=out) if (out is not None and i == len(mods) - 1 and getattr(module, "accepts_out", False)) else module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.features.shape[0] != 0:
                     if fusable_bn(module, x.features):
@@ -81,7 +83,8 @@ class SparseSequential(SparseModule):
                             # BatchNorm -> ReLU -> conv as one autograd node (autograd._BNReLUConvFn): statistics and backward
                             # reductions ride on the conv kernels' epilogues
                             ws = want_skip and i == 0 and x.features.requires_grad
-                            x, sk = nxt.forward_fused(x, module, relu, want_skip=ws)
+                            last = i + 2 + int(relu) >= len(mods)
+                            x, sk = nxt.forward_fused(x, module, relu, want_skip=ws, out=out if last else None)
                             if ws:
                                 skip = sk
                             i += 2 + int(relu)
@@ -131,7 +134,7 @@ class SparseConvolution(SparseModule):
     def _table(self, x):
         raise NotImplementedError
 
-    def forward_fused(self, x, bn, relu, residual=None, want_skip=False):
+    def forward_fused(self, x, bn, relu, residual=None, want_skip=False, out=None):
         """conv(relu?(bn(x))) [+ residual] of a training-mode BatchNorm1d `bn` in front of this conv, as one autograd node
         (autograd.bn_relu_conv).  Returns (SparseConvTensor, skip features or None)."""
         from .autograd import bn_relu_conv, fusable_bn
@@ -143,8 +146,8 @@ class SparseConvolution(SparseModule):
             out = self.forward(x.replace_feature(torch.relu(f) if relu else f), residual)
             return out, (x.features if want_skip else None)
         fuse = residual is not None and residual.dtype == fin.dtype and residual.is_cuda
-        out = bn_relu_conv(fin, bn, relu, self.weight, ref, residual if fuse else None, want_skip)
-        feats, skip = out if want_skip else (out, None)
+        res_ = bn_relu_conv(fin, bn, relu, self.weight, ref, residual if fuse else None, want_skip, out=out if (residual is None or fuse) else None)
+        feats, skip = res_ if want_skip else (res_, None)
         if residual is not None and not fuse:
             feats = feats + residual.to(feats.dtype)
         lv = x.geometry.levels[out_level]

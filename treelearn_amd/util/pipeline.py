@@ -117,7 +117,10 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     # Tiles in flight: consecutive tiles run on NF compute streams round-robin, so that the stretches of one forward that leave
     # most CUs idle (the 36 small launches of the deep levels, the geometry kernels and their two host syncs) are filled by the
     # big convs of another tile: measured 8.63 -> 7.90 (2) -> 7.69 (3) -> 7.96 (4) ms per 40 m tile (tools/dev_two_streams.py).
-    nf = max(1, int(os.environ.get("TL_TILES_IN_FLIGHT", "4"))) if use_gpu else 1
+    # (four tiles in flight need eight hardware queues -- GPU_MAX_HW_QUEUES=8, set by the package at import when the HIP runtime has not started
+    # yet; with the runtime's default of four the fourth tile's stream shares a queue and three in flight are faster: 7.69 vs 7.96 ms per tile)
+    from .. import hw_queues
+    nf = max(1, int(os.environ.get("TL_TILES_IN_FLIGHT", "4" if hw_queues() >= 8 else "3"))) if use_gpu else 1
     if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":
         nf = 1
     cstreams = _compute_streams(nf) if (use_gpu and nf > 1) else []
