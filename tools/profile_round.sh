@@ -25,3 +25,12 @@ python tools/dev_train_host.py > $O/config3_phases.txt 2>&1
 python tools/dev_wgrad_dense.py > $O/wgrad_dense_vs_pair_list.txt 2>&1
 python tools/dev_conv_table.py > $O/conv_launch_table.txt 2>&1
 tail -c 400 $O/bench_unprofiled.json; ls $O/*
+# round 5: host cost of a lone forward through tl_forward / the Python-driven engine, the timeline of one lone forward, the parity modes per layer
+python tools/dev_fwd_host.py > $O/fwd_host_tl_forward.txt 2>&1
+TL_EXEC=0 python tools/dev_fwd_host.py > $O/fwd_host_python_engine.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/tr1 -o p -- python3 bench.py --steps 6 --warmup 2 --tiles-in-flight 1 $Q > /dev/null 2> $O/tr1.err
+python tools/trace_forward.py $O/tr1 3 > $O/forward_timeline_lone.txt 2>&1
+find $O/tr1 -name "*kernel_trace.csv" -delete
+python bench.py --dtype bf16x3 --no-cpu-baseline --no-power-probe --no-extra-workloads --tiles-in-flight 1 --steps 5 --warmup 2 --layer-table $O/layer_table_bf16x3.txt > $O/bench_bf16x3.json 2>> $O/bench_unprofiled.err
+python bench.py --dtype fp32 --no-cpu-baseline --no-power-probe --no-extra-workloads --tiles-in-flight 1 --steps 5 --warmup 2 --layer-table $O/layer_table_fp32.txt > $O/bench_fp32.json 2>> $O/bench_unprofiled.err
+python bench.py --tiles-in-flight 1 $Q --layer-table $O/layer_table_bf16.txt > /dev/null 2>> $O/bench_unprofiled.err
