@@ -12,6 +12,7 @@ import weakref
 import torch
 
 from . import ops
+from .geometry import BlockedRulebook
 
 _packed_cache = {}          # id(parameter) -> (weakref to it, (version, dtype, device, data_ptr), packed); evicted when the parameter dies
 
@@ -44,6 +45,11 @@ def _forced_mask(bn, relu):
     return RELU_MASK_SOURCE.get(bn) if (RELU_MASK_SOURCE is not None and relu) else None
 
 
+# block-local level 1 in training: BatchNorm + ReLU applied when the conv stages its rows instead of an apply pass (the activated tensor is then
+# recomputed for the weight gradient on its stream).  OPT-IN (TL_BLK_TRAIN_PRO=1): measured at no gain on the step (61.2 vs 61.3 ms, three
+# alternations) -- the pass it removes from the main stream re-appears on the weight-gradient stream and the two streams share the device --
+# and the 2C -> C conv as two staged halves rounds its half sums once more (gradients at cosine >= 0.9989 of the default's)
+STAGE_TRAIN = os.environ.get("TL_BLK_TRAIN_PRO", "0") == "1"
 CAT_IN_PLACE = os.environ.get("TL_TRAIN_CAT", "1") != "0"   # skip concat without a copy: both producers write into the halves of one buffer (0: torch.cat, for A/B)
 
 
@@ -200,6 +206,42 @@ def _bn_forward_stats(x, bn, gamma, beta, stats_in):
     return ops.bn_train_stats(x, g32, b32, bn.eps, bn.momentum, rm, rv, nbt)
 
 
+_halves_cache = {}
+
+
+def _packed_halves(weight, dtype):
+    """The two input-channel halves [K, Cout, Cin / 2] of a packed conv weight, cached like `_packed`."""
+    key = (weight._version, dtype, weight.device, weight.data_ptr())
+    hit = _halves_cache.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2]
+    w = _packed(weight, dtype)
+    h = w.shape[2] // 2
+    val = (w[:, :, :h].contiguous(), w[:, :, h:].contiguous())
+    if hit is None or hit[0]() is not weight:
+        weakref.finalize(weight, _halves_cache.pop, id(weight), None)
+    _halves_cache[id(weight)] = (weakref.ref(weight), key, val)
+    return val
+
+
+def _staged_bn_conv(x, st, relu, weight, ref, residual, holder, out):
+    """conv(relu?(x * scale + shift)) on the staged-unit kernel with the affine applied at staging and the statistics epilogue; None when the
+    kernel does not serve the launch (nothing enqueued)."""
+    n = ref.n_out
+    if weight.shape[-1] == 32:
+        r = ops.conv_fwd(x, _packed(weight, x.dtype), ref.table, n, out=out, residual=residual, in_scale=st[2], in_shift=st[3], in_relu=relu, epi="stats")
+    else:
+        if residual is not None:
+            return None
+        w0, w1 = _packed_halves(weight, x.dtype)
+        part = ops.conv_fwd(x[:, :32], w0, ref.table, n, in_scale=st[2, :32], in_shift=st[3, :32], in_relu=relu, split=(0, 64))
+        r = ops.conv_fwd(x[:, 32:], w1, ref.table, n, out=out, residual=part, in_scale=st[2, 32:], in_shift=st[3, 32:], in_relu=relu, epi="stats", split=(1, 64))
+    if r is None:
+        return None
+    holder["stats"] = [(r[1], r[2], 32)]
+    return r[0]
+
+
 class _BNReLUConvFn(torch.autograd.Function):
     """y = conv(relu?(BatchNorm1d_train(x))) [+ residual] as ONE autograd node -- the `norm_fn(C), nn.ReLU(), conv` triple of reference
     blocks.py:55-70,102-123 in training mode -- so that the BatchNorm's reductions ride on the neighbouring conv kernels:
@@ -215,13 +257,22 @@ class _BNReLUConvFn(torch.autograd.Function):
             x = x.contiguous()                                                  #  its producer's partial sums goes through as it is)
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
         fm = _forced_mask(bn, relu)
-        if fm is not None:
-            a = ops.affine_relu(x, st[2], st[3], False) * fm.to(x.dtype)
-        else:
-            a = ops.affine_relu(x, st[2], st[3], relu)
-        if RELU_MASK_SINK is not None and relu:
-            RELU_MASK_SINK[bn] = fm if fm is not None else a > 0
-        y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder, out=out)
+        y = a = None
+        if (STAGE_TRAIN and fm is None and RELU_MASK_SINK is None and FUSE_BN and holder is not None and x.dtype == torch.bfloat16
+                and isinstance(ref.table, BlockedRulebook) and weight.shape[0] == 32 and weight.numel() // (32 * weight.shape[-1]) == 27
+                and weight.shape[-1] in (32, 64)):
+            # block-local level 1: the staged-unit kernel applies relu(x * scale + shift) to every row it stages (1.8 rows per output row), so the
+            # activated tensor is neither written nor read here; the weight gradient recomputes it on its own stream (backward.bn_conv_backward).
+            # The 2C -> C conv of the decoder block runs as its two input-channel halves, the second taking the first one's sums as residual.
+            y = _staged_bn_conv(x, st, relu, weight, ref, residual, holder, out)
+        if y is None:
+            if fm is not None:
+                a = ops.affine_relu(x, st[2], st[3], False) * fm.to(x.dtype)
+            else:
+                a = ops.affine_relu(x, st[2], st[3], relu)
+            if RELU_MASK_SINK is not None and relu:
+                RELU_MASK_SINK[bn] = fm if fm is not None else a > 0
+            y = _conv_with_stats(a, _packed(weight, a.dtype), ref, residual, holder, out=out)
         ctx.save_for_backward(x, a, st, weight)
         ctx.ref, ctx.relu, ctx.fm = ref, relu, fm
         if want_skip:

@@ -124,6 +124,8 @@ def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, g
         side = _side_stream(grad_out.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if a is None:                                  # the forward applied the BatchNorm at staging and kept no activated tensor: one apply pass here
+                a = ops.affine_relu(x, st[2], st[3], relu)
             gw = _wgrad_param(a, grad_out, ref, K, weight)
         gw.record_stream(cur)
     wt = _dgrad_weight(weight, ref, grad_out.dtype)
@@ -157,9 +159,11 @@ def bn_conv_backward(x, a, st, relu, weight, ref: TableRef, grad_out, need_gw, g
             ops.conv_fwd(grad_out, wsl, ref.t_table, ref.n_in, out=ga[:, s0:s0 + w_], one_hot=ref.t_one_hot)
         res = ops.bn_train_bwd(x, ga, st, relu, dx_add=gskip)
     if need_gw and not overlap:
+        if a is None:
+            a = ops.affine_relu(x, st[2], st[3], relu)
         gw = _wgrad_param(a, grad_out, ref, K, weight)
     if overlap:
-        _join_side(cur, side, weight, (a, grad_out))
+        _join_side(cur, side, weight, (a, grad_out, x))
     return res[0], res[1], res[2], gw
 
 

@@ -481,8 +481,11 @@ int tl_launch_conv_blk(const ConvP& p, hipStream_t s) {
 #ifdef TL_F16_BUILD
     return TL_ERR_UNSUPPORTED;                                   // the training epilogues are bf16
 #else
-    if (pro || p.out2 || p.out_scale || p.out_relu || p.out_ld % 8 || ((uintptr_t)p.out) % 16) return TL_ERR_UNSUPPORTED;
-    return launch_blk<8, false, 1, true>(p, s);                   // (a residual goes through the shared row stage)
+    if (p.out2 || p.out_scale || p.out_relu || p.out_ld % 8 || ((uintptr_t)p.out) % 16) return TL_ERR_UNSUPPORTED;
+    if (pro && p.epi_mode != TL_EPI_STATS) return TL_ERR_UNSUPPORTED;
+    // (a residual goes through the shared row stage; with the prologue the training forward applies its BatchNorm + ReLU at staging, so the
+    //  activated tensor is never written -- the weight gradient recomputes it on its own stream)
+    return pro ? launch_blk<8, false, 1, true, true>(p, s) : launch_blk<8, false, 1, true>(p, s);
 #endif
   }
   const int nv = p.out3 ? 3 : p.out2 ? 2 : 1;
