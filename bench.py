@@ -259,20 +259,31 @@ def training_step_bench(args, rank, world, dist):
     cfg = CONFIGS["config2"]
     batch = make_batch([make_tile(**cfg, seed=2 * rank + s) for s in (0, 1)])
     n_pts = batch["coords"].shape[0]
-    dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16          # (fp16 requested: the training kernels' 16-bit type is bf16)
+    # bf16: compute_dtype switch, no scaler needed.  fp16: the REFERENCE's regime verbatim -- torch.autocast(float16) around the forward and a
+    # GradScaler around backward / step (tools/training/train.py:32,40-44) on a model left at its fp32 default; the float16 training kernels run
+    fp16 = args.dtype == "fp16"
+    dtype = torch.float32 if (args.dtype == "fp32" or fp16) else torch.bfloat16
     model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=cfg["voxel"], compute_dtype=dtype)
     model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
     model = model.cuda().train()
     opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3)
     gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
+    scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+    skipped = [0]
+
     def step():
         opt.zero_grad()
-        loss, ld = model(gb, return_loss=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+            loss, ld = model(gb, return_loss=True)
         vals = [v.detach().cpu().item() for v in ld.values()]
-        loss.backward()
+        scaler.scale(loss).backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0, norm_type=2)
-        opt.step()
+        s0 = scaler.get_scale() if fp16 else 1.0
+        scaler.step(opt)
+        scaler.update()
+        if fp16:
+            skipped[0] += int(scaler.get_scale() < s0)
         return vals
 
     for _ in range(max(args.warmup, 1)):
@@ -304,8 +315,9 @@ def training_step_bench(args, rank, world, dist):
                 value=float(npts) / sec / 1e6, unit="Mpoints/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3,
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                 config=dict(workload=f"config3: training step, batch of 2 crops of 40x40 m at 0.1 m ({n_pts} points), default 7-level 32-ch model "
-                                     f"(30.1 M params, random init), AdamW, grad-norm clip 1.0, {'bf16 mixed precision (autocast-like)' if args.dtype == 'bf16' else 'fp32'}",
-                            points_per_step=n_pts, last_losses=vals),
+                                     f"(30.1 M params, random init), AdamW, grad-norm clip 1.0, " + {"bf16": "bf16 mixed precision (autocast-like)", "fp32": "fp32", "fp16":
+                            "float16 autocast + GradScaler (the reference's regime, tools/training/train.py:32,40-44)"}.get(args.dtype, args.dtype),
+                            points_per_step=n_pts, last_losses=vals, **(dict(gradscaler_skipped_steps=skipped[0], gradscaler_final_scale=scaler.get_scale()) if fp16 else {})),
                 roofline=dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,
                               note="algorithmic conv flops of the step (forward + dgrad + wgrad = 3 x 2 * pairs * Cin * Cout) / whole step time"),
                 cpu_baseline=None)
@@ -658,6 +670,12 @@ def main():
             try:
                 ts = training_step_bench(types.SimpleNamespace(steps=5, warmup=2, dtype=args.dtype), 0, 1, None)
                 res["training_step"] = {k: ts[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
+                if args.dtype == "bf16":
+                    # the reference's own regime beside it: float16 autocast + GradScaler on the float16 training kernels
+                    t16 = training_step_bench(types.SimpleNamespace(steps=5, warmup=2, dtype="fp16"), 0, 1, None)
+                    res["training_step"]["fp16_autocast_gradscaler"] = dict(ms_per_step=t16["ms_per_step"], value=t16["value"], unit=t16["unit"],
+                                                                            gradscaler_skipped_steps=t16["config"]["gradscaler_skipped_steps"],
+                                                                            gradscaler_final_scale=t16["config"]["gradscaler_final_scale"], last_losses=t16["config"]["last_losses"])
             except Exception as e:                                      # noqa: BLE001
                 res["training_step"] = dict(error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()

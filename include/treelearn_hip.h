@@ -33,9 +33,11 @@ enum {
   TL_ERR_UNSUPPORTED = -3
 };
 
-/* TL_F16 (IEEE half, BASELINE config 5's "fp16"; the reference trains under fp16 autocast, tools/training/train.py:32): served by
- * tl_conv_fwd, tl_pack_weight*, tl_head_mlp and tl_affine_relu -- the inference path; the training-only entry points (tl_conv_wgrad,
- * tl_bn_train_*, epilogue modes) take TL_F32 / TL_BF16.  Values beyond 65504 become inf (no saturation), as on any fp16 path. */
+/* TL_F16 (IEEE half, BASELINE config 5's "fp16"; the reference trains under fp16 autocast + GradScaler, tools/training/train.py:32,40-44):
+ * served by every entry point that takes a dtype -- the conv / head / weight-packing path and, since round 5, the training entry points
+ * (tl_conv_wgrad*, tl_bn_train_*, the epilogue modes of tl_conv_fwd, tl_gather_rows / tl_scatter_add_rows, tl_linear_small_f32): the units are
+ * compiled a second time for _Float16 (csrc/tl_half.h, tl_f16_train.h).  One 16-bit type per call (no bf16 / f16 mixtures).  Values beyond
+ * 65504 become inf (no saturation), as on any fp16 path. */
 enum { TL_F32 = 0, TL_BF16 = 1, TL_F16 = 2 };
 
 int tl_version(void);
@@ -295,7 +297,7 @@ int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_fr
 /* Weight gradient (training step; spconv's autograd behind the conv modules, tools/training/train.py:40):
  *   gw[k][co][ci] = sum_o gout[o][co] * x[table[k][o]][ci]   over the present rulebook entries, fp32.
  * x [n_in, x_ld >= Cin] and gout [n_out, g_ld >= Cout] in `dtype` (TL_F32, or TL_BF16 = mixed-precision training: widened
- * to fp32 in registers), table i32[K][n_out] or NULL (K = 1: identity), gw f32[K][Cout][Cin] out (fully written),
+ * to fp32 in registers; TL_F16 likewise), table i32[K][n_out] or NULL (K = 1: identity), gw f32[K][Cout][Cin] out (fully written),
  * ws f32[tl_conv_wgrad_ws_floats(...)] scratch.  Deterministic. */
 int64_t tl_conv_wgrad_ws_floats(int64_t n_out, int K, int Cin, int Cout);
 int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out,

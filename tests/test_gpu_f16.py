@@ -124,3 +124,99 @@ def test_autocast_float16_eval_runs_the_f16_kernels():
     for k in ("semantic_prediction_logits", "offset_predictions"):
         assert bool(torch.isfinite(o[k]).all())
         assert rel_err(o[k].float().cpu().numpy(), ref[k].float().cpu().numpy()) < 3e-2, k
+
+
+@pytest.mark.parametrize("cin,cout,K", [(32, 32, 27), (64, 64, 27), (96, 96, 27), (32, 64, 8), (64, 32, 1), (32, 3, 1), (4, 32, 27)])
+def test_f16_weight_gradient_vs_float64(cin, cout, K):
+    """tl_conv_wgrad on IEEE-half operands (the _f16 compilation of the weight-gradient units, csrc/tl_f16_train.h) against float64 on the same
+    rounded inputs, and against the bf16 kernels' accuracy class."""
+    import torch
+    from treelearn_amd import ops
+    from treelearn_amd.geometry import build_geometry
+    from treelearn_amd.synth import make_tile
+    t = make_tile(extent=12.0, voxel=0.1, n_trees=5, fill=0.1, seed=2)
+    xyz = torch.from_numpy(t["points"]).cuda()
+    g = build_geometry(xyz, torch.zeros(len(xyz), dtype=torch.int64, device="cuda"), 1, 0.1, 3, [500, 500, 1000])
+    lv = g.levels[0]
+    if K == 27:
+        table, n_out = lv.nbr, lv.n
+    elif K == 8:
+        table, n_out = lv.child, g.levels[1].n
+    else:
+        table, n_out = None, lv.n
+    gen = torch.Generator(device="cuda"); gen.manual_seed(cin + 7 * cout + K)
+    x = torch.randn((lv.n, cin), device="cuda", generator=gen).half()
+    go = (torch.randn((n_out, cout), device="cuda", generator=gen) * 0.1).half()
+    gw = ops.conv_wgrad(x, go, table, n_out, K)
+    assert gw.dtype == torch.float32 and tuple(gw.shape) == (K, cout, cin)
+    xd, gd = x.double(), go.double()
+    ref = torch.zeros((K, cout, cin), dtype=torch.float64, device="cuda")
+    for k in range(K):
+        if table is None:
+            ref[k] = gd.T @ xd
+        else:
+            idx = table[k].long(); m = idx >= 0
+            ref[k] = gd[m].T @ xd[idx[m]]
+    err = float((gw.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
+def test_f16_batchnorm_train_kernels_vs_torch():
+    """tl_bn_train_stats / tl_bn_train_bwd on float16 rows against torch's float64 BatchNorm + ReLU on the same rounded inputs."""
+    import torch
+    from treelearn_amd import ops
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    n, C = 50_000, 64
+    x = (torch.randn((n, C), device="cuda", generator=gen) * 1.7 + 0.3).half()
+    dy = torch.randn((n, C), device="cuda", generator=gen).half()
+    gamma = torch.rand(C, device="cuda", generator=gen) + 0.5; beta = torch.randn(C, device="cuda", generator=gen) * 0.2
+    st = ops.bn_train_stats(x, gamma, beta, 1e-4, 0.1)
+    y = ops.affine_relu(x, st[2], st[3], True)
+    dx, dgamma, dbeta = ops.bn_train_bwd(x, dy, st, True)
+    assert y.dtype == torch.float16 and dx.dtype == torch.float16
+    xd = x.double().requires_grad_(True)
+    yd = torch.relu(torch.nn.functional.batch_norm(xd, None, None, gamma.double(), beta.double(), True, 0.1, 1e-4))
+    gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    yd2 = torch.relu(torch.nn.functional.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-4))
+    yd2.backward(dy.double())
+    assert float((y.double() - yd).abs().max()) < 4e-3                            # one half-precision rounding of values up to ~4
+    assert float((st[0].double() - x.double().mean(0)).abs().max()) < 1e-5
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())        # noqa: E731
+    assert rel(dgamma, gd.grad) < 2e-3 and rel(dbeta, bd.grad) < 2e-3             # (the ReLU mask is decided on the fp32 affine of the rounded x)
+    assert rel(dx, xd.grad) < 5e-3
+
+
+def test_f16_training_step_close_to_fp32_step():
+    """One training step (loss + every gradient) under a float16 autocast against the fp32 step of the same model: the loss within 2e-2 and
+    every large gradient tensor at cosine >= 0.98 -- the accuracy class of the bf16 regime (which has three bits less) or better."""
+    import torch
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    cfg = dict(channels=32, num_blocks=4)
+    b = make_batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=s) for s in (1, 2)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+    def step(dt):
+        m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, **cfg)
+        m.load_state_dict(random_state_dict(5, **cfg), strict=True)
+        m = m.cuda().train()
+        if dt is None:
+            loss, _ = m(gb, return_loss=True)
+        else:
+            with torch.autocast("cuda", dtype=dt):
+                loss, _ = m(gb, return_loss=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().double().flatten() for n, p in m.named_parameters() if p.grad is not None}
+
+    l32, g32 = step(None)
+    res = {}
+    for dt in (torch.float16, torch.bfloat16):
+        l, g = step(dt)
+        assert abs(l - l32) <= 2e-2 * abs(l32), (dt, l, l32)
+        nmax = max(float(v.norm()) for v in g32.values())
+        worst = min(float((g[k] * g32[k]).sum() / (g[k].norm() * g32[k].norm())) for k in g32 if float(g32[k].norm()) > 1e-3 * nmax)
+        res[dt] = worst
+        assert all(bool(torch.isfinite(v).all()) for v in g.values()), dt
+    print("worst gradient cosine vs the fp32 step:", {str(k): round(v, 5) for k, v in res.items()})
+    assert res[torch.float16] >= 0.98 and res[torch.float16] >= res[torch.bfloat16] - 5e-3

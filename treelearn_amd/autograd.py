@@ -258,7 +258,7 @@ class _BNReLUConvFn(torch.autograd.Function):
         st = _bn_forward_stats(x, bn, gamma, beta, stats_in)
         fm = _forced_mask(bn, relu)
         y = a = None
-        if (STAGE_TRAIN and fm is None and RELU_MASK_SINK is None and FUSE_BN and holder is not None and x.dtype == torch.bfloat16
+        if (STAGE_TRAIN and fm is None and RELU_MASK_SINK is None and FUSE_BN and holder is not None and x.dtype in (torch.bfloat16, torch.float16)
                 and isinstance(ref.table, BlockedRulebook) and weight.shape[0] == 32 and weight.numel() // (32 * weight.shape[-1]) == 27
                 and weight.shape[-1] in (32, 64)):
             # block-local level 1: the staged-unit kernel applies relu(x * scale + shift) to every row it stages (1.8 rows per output row), so the
@@ -368,7 +368,7 @@ class _BNReLUTrainFn(torch.autograd.Function):
         x, st = ctx.saved_tensors
         if dy.stride(1) != 1 or dy.stride(0) % 8 or dy.data_ptr() % 16:
             dy = dy.contiguous()
-        if dy.dtype not in (torch.float32, torch.bfloat16):
+        if dy.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             dy = dy.float()
         if dskip is not None and (dskip.dtype != x.dtype or dskip.stride(1) != 1 or dskip.stride(0) % 8 or dskip.data_ptr() % 16):
             dskip = dskip.to(x.dtype).contiguous()
@@ -400,9 +400,9 @@ class _BiasAddFn(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         n, C = g.shape
-        if g.is_cuda and C % 4 == 0 and C <= 1024 and n > 1 and g.dtype in (torch.float32, torch.bfloat16):
+        if g.is_cuda and C % 4 == 0 and C <= 1024 and n > 1 and g.dtype in (torch.float32, torch.bfloat16, torch.float16):
             db = ops.column_sum(g)
-        elif g.is_cuda and C < 4 and n >= 64 and g.dtype in (torch.float32, torch.bfloat16):
+        elif g.is_cuda and C < 4 and n >= 64 and g.dtype in (torch.float32, torch.bfloat16, torch.float16):
             # 2 or 3 columns (the heads' output layers): fold rows so that the matrix is a multiple of four wide -- [n, C] read as
             # [n / r, r * C] with r * C = lcm(C, 4) -- sum its columns on the same kernel, then add the r partial rows (and the < r
             # left-over rows); ATen's dim-0 reduction of a [3.7 M, 3] matrix takes 0.6 ms
@@ -423,7 +423,7 @@ def bias_add(x, bias):
 def fusable_bn(module, x):
     """True when `module` is a BatchNorm1d that the HIP training kernels serve for x (batch statistics, affine, CUDA, C % 4 == 0)."""
     return (isinstance(module, torch.nn.BatchNorm1d) and module.training and module.affine and module.momentum is not None and x.is_cuda
-            and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16))
+            and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -455,7 +455,7 @@ class _GatherRowsFn(torch.autograd.Function):
 def gather_rows(feats, idx, cache=None):
     """feats[idx] for a 2-D feature matrix and an int64 index vector; differentiable w.r.t. feats.  `cache`: a dict that lives as long
     as idx is valid (TileGeometry.cache) and keeps the argsort the backward pass needs."""
-    if feats.is_cuda and feats.dim() == 2 and idx.dtype == torch.int64 and feats.dtype in (torch.float32, torch.bfloat16) \
+    if feats.is_cuda and feats.dim() == 2 and idx.dtype == torch.int64 and feats.dtype in (torch.float32, torch.bfloat16, torch.float16) \
             and (feats.shape[1] * feats.element_size()) % 16 == 0 and feats.shape[0] > 0 and idx.numel() > 0:
         return _GatherRowsFn.apply(feats, idx, cache)
     return feats[idx]
@@ -484,6 +484,6 @@ class _LinearSmallFn(torch.autograd.Function):
 
 def linear_small_f32(x, weight5):
     """x . W^T -> fp32 for a [Cout <= 8, 1, 1, 1, Cin] weight view, or None when the shape is not served (caller falls back)."""
-    if x.is_cuda and x.dim() == 2 and x.shape[1] % 8 == 0 and weight5.shape[0] <= 8 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[0] > 0:
+    if x.is_cuda and x.dim() == 2 and x.shape[1] % 8 == 0 and weight5.shape[0] <= 8 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[0] > 0:
         return _LinearSmallFn.apply(x, weight5)
     return None

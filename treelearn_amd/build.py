@@ -27,7 +27,9 @@ DEV_ONLY = ("tl_dev.hip", "tl_conv_win.hip")     # the gather micro-benchmarks; 
 
 # units compiled a SECOND time with -DTL_F16_BUILD (csrc/tl_half.h): the same kernels with IEEE-half conversions and the f16 MFMA,
 # launchers suffixed _f16 -- the float16 inference path (TL_F16)
-F16_UNITS = ("tl_conv_direct.hip", "tl_conv_blk.hip", "tl_conv_up.hip", "tl_conv_stream.hip", "tl_conv_streamq.hip", "tl_conv_small.hip", "tl_conv_bf16.hip", "tl_head.hip")
+F16_UNITS = ("tl_conv_direct.hip", "tl_conv_blk.hip", "tl_conv_up.hip", "tl_conv_stream.hip", "tl_conv_streamq.hip", "tl_conv_small.hip", "tl_conv_bf16.hip", "tl_head.hip",
+             # the training units (csrc/tl_f16_train.h): weight gradients, BatchNorm train forward / backward, row gather / scatter-add, the heads' small Linears
+             "tl_wgrad.hip", "tl_wgrad_dense.hip", "tl_wgrad_rows.hip", "tl_bn.hip", "tl_rows.hip", "tl_linear_small.hip")
 
 
 def sources(dev=False):

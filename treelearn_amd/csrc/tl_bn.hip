@@ -12,6 +12,7 @@
 //   backward:  tl_bn_train_bwd_reduce  g = dy * [y > 0];  sum_g, sum_g_xhat per channel  (= dbeta, dgamma)
 //              tl_bn_train_bwd_apply   dx = scale * (g - sum_g / n - xhat * sum_g_xhat / n)
 #include "tl_conv_internal.h"
+#include "tl_f16_train.h"
 
 namespace {
 
@@ -303,6 +304,13 @@ int tl_bn_train_bwd_from_parts(const void* x, int64_t ld, int x_dtype, const voi
                                const float* rstd, const float* scale, const float* shift, const double* part, int64_t nparts, float* dgamma, float* dbeta,
                                void* dx, int64_t xld, const void* dx_add, int64_t ald, tl_stream_t stream) {
   if (!x || !g || !mean || !rstd || !scale || !shift || !part || nparts <= 0 || nparts > 0x7FFFFFFF || !dgamma || !dbeta || !dx || n <= 0 || C <= 0) return TL_ERR_ARG;
+#ifndef TL_F16_BUILD
+  if (x_dtype == TL_F16 || g_dtype == TL_F16) {
+    if (x_dtype == TL_BF16 || g_dtype == TL_BF16) return TL_ERR_ARG;            // one 16-bit type per call
+    return tl_bn_train_bwd_from_parts_f16(x, ld, tl_f16_code(x_dtype), g, gld, tl_f16_code(g_dtype), n, C, mean, rstd, scale, shift, part, nparts, dgamma, dbeta, dx, xld,
+                                          dx_add, ald, stream);
+  }
+#endif
   if ((x_dtype != TL_F32 && x_dtype != TL_BF16) || (g_dtype != TL_F32 && g_dtype != TL_BF16)) return TL_ERR_ARG;
   hipStream_t s = tl_s(stream);
   k_bn_bwd_finish<<<C, kFin, 0, s>>>(part, (int)nparts, C, dgamma, dbeta);
@@ -324,6 +332,10 @@ int tl_bn_train_stats(const void* x, int64_t ld, int64_t n, int C, int dtype, co
                       int64_t* num_batches_tracked, tl_stream_t stream) {
   if (!x || !gamma || !beta || !ws || !mean || !rstd || !scale || !shift || n <= 0 || C <= 0 || C % 4 || C > 4 * kThreads || ld % 4) return TL_ERR_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return TL_ERR_ARG;
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16)
+    return tl_bn_train_stats_f16(x, ld, n, C, TL_BF16, gamma, beta, eps, momentum, ws, mean, rstd, scale, shift, running_mean, running_var, num_batches_tracked, stream);
+#endif
   int blocks;
   const Part pt = partition(n, C, blocks);
   const size_t lds = (size_t)pt.rl * 2 * C * sizeof(double);
@@ -344,6 +356,13 @@ int tl_bn_train_bwd(const void* x, int64_t ld, int x_dtype, const void* dy, int6
   if (!x || !dy || !mean || !rstd || !scale || !shift || !ws || !dgamma || !dbeta || !dx || n <= 0 || C <= 0 || C % 4 || C > 4 * kThreads || ld % 4 ||
       dld % 4 || xld % 4 || (dx_add && ald % 4))
     return TL_ERR_ARG;
+#ifndef TL_F16_BUILD
+  if (x_dtype == TL_F16 || dy_dtype == TL_F16) {
+    if (x_dtype == TL_BF16 || dy_dtype == TL_BF16) return TL_ERR_ARG;
+    return tl_bn_train_bwd_f16(x, ld, tl_f16_code(x_dtype), dy, dld, tl_f16_code(dy_dtype), n, C, mean, rstd, scale, shift, relu, ws, dgamma, dbeta, dx, xld, dx_add, ald,
+                               stream);
+  }
+#endif
   int blocks;
   const Part pt = partition(n, C, blocks);
   const size_t lds = (size_t)pt.rl * 2 * C * sizeof(double);

@@ -304,7 +304,8 @@ __global__ void k_affine_relu(const T* __restrict__ in, int64_t in_ld, T* __rest
 // The same over 8-channel vectors (C % 8 == 0, 16-B aligned rows): one 16-B (bf16) / two 16-B (f32) loads and stores per thread and
 // step; the grid stride is a multiple of the vectors per row, so a thread keeps ONE channel group and its scale / shift live in
 // registers (the scalar kernel above re-reads them per element and moves 2 bytes per load: 1.7 TB/s on the training step's 67 passes).
-template <bool BF16>
+// T16: 0 = fp32 rows, 1 = bf16, 2 = IEEE half (this unit is compiled once: the half conversions are spelled out here)
+template <int T16>
 __global__ void __launch_bounds__(256) k_affine_relu_v8(const void* __restrict__ in, int64_t in_ld, void* __restrict__ out, int64_t out_ld, int64_t n, int C,
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
   const int vpr = C >> 3;
@@ -318,10 +319,18 @@ __global__ void __launch_bounds__(256) k_affine_relu_v8(const void* __restrict__
   for (; v < total; v += stride) {
     const int64_t r = v / vpr;
     float x[8];
-    if constexpr (BF16) {
+    typedef _Float16 hx2 __attribute__((ext_vector_type(2)));
+    if constexpr (T16 == 1) {
       const u32x4 q4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>((const uint16_t*)in + r * in_ld + c0));
 #pragma unroll
       for (int q = 0; q < 4; ++q) { x[2 * q] = bf16_lo(q4[q]); x[2 * q + 1] = bf16_hi(q4[q]); }
+    } else if constexpr (T16 == 2) {
+      // (a plain 16-B load: with __builtin_nontemporal_load hipcc 7.0 fetched ONE dword here and fed all eight v_fma_mix from it)
+      const u32x4 q4 = *reinterpret_cast<const u32x4*>((const uint16_t*)in + r * in_ld + c0);
+      const uint32_t w0 = q4[0], w1 = q4[1], w2 = q4[2], w3 = q4[3];
+      const uint32_t ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const hx2 h = __builtin_bit_cast(hx2, ws[q]); x[2 * q] = (float)h[0]; x[2 * q + 1] = (float)h[1]; }
     } else {
       const f32x4* s4 = reinterpret_cast<const f32x4*>((const float*)in + r * in_ld + c0);
       const f32x4 a = __builtin_nontemporal_load(s4), b = __builtin_nontemporal_load(s4 + 1);
@@ -330,10 +339,15 @@ __global__ void __launch_bounds__(256) k_affine_relu_v8(const void* __restrict__
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { x[q] = fmaf(x[q], sc[q], sh[q]); if (relu) x[q] = fmaxf(x[q], 0.f); }
-    if constexpr (BF16) {
+    if constexpr (T16 == 1) {
       u32x4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = pack_bf16x2(x[2 * q], x[2 * q + 1]);
+      *reinterpret_cast<u32x4*>((uint16_t*)out + r * out_ld + c0) = o;
+    } else if constexpr (T16 == 2) {
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const hx2 h = {(_Float16)x[2 * q], (_Float16)x[2 * q + 1]}; o[q] = __builtin_bit_cast(uint32_t, h); }
       *reinterpret_cast<u32x4*>((uint16_t*)out + r * out_ld + c0) = o;
     } else {
       f32x4* d = reinterpret_cast<f32x4*>((float*)out + r * out_ld + c0);
@@ -417,7 +431,6 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   const auto L_tinycin = f16 ? tl_launch_conv_tinycin_f16 : tl_launch_conv_tinycin;
   const auto L_blk = f16 ? tl_launch_conv_blk_f16 : tl_launch_conv_blk;
   const auto L_up = f16 ? tl_launch_conv_up_f16 : tl_launch_conv_up;
-  if (f16 && a->epi_mode != TL_EPI_NONE) return TL_ERR_UNSUPPORTED;       // the training epilogues take TL_F32 / TL_BF16
   ConvP p;
   p.in = a->in; p.in_ld = a->in_ld; p.w = a->weight; p.w_frag = a->weight_frag;
   p.w_x3 = (a->dtype == TL_F32 && a->Cin % 32 == 0 && ((uintptr_t)a->weight_x3) % 16 == 0) ? a->weight_x3 : nullptr; p.table = a->table; p.ctab = (a->K == 27) ? a->table_compact : nullptr; p.n_out = a->n_out; p.n_in = a->n_in;
@@ -599,13 +612,14 @@ int tl_pack_weight_frag(const float* w_ref, int Cout, int K, int Cin, void* w_fr
 int tl_affine_relu(const void* in, int64_t in_ld, void* out, int64_t out_ld, int64_t n, int C, int dtype, const float* scale,
                    const float* shift, int relu, tl_stream_t stream) {
   if (!in || !out || n <= 0 || C <= 0 || (scale == nullptr) != (shift == nullptr)) return TL_ERR_ARG;
-  if ((dtype == TL_F32 || dtype == TL_BF16) && C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && ((uintptr_t)in) % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
+  if ((dtype == TL_F32 || dtype == TL_BF16 || dtype == TL_F16) && C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && ((uintptr_t)in) % 16 == 0 && ((uintptr_t)out) % 16 == 0) {
     const int vpr = C / 8;
     int64_t gv = tl_cdiv(n * vpr, 256 * 4);                      // about four vectors per thread, at most 16 workgroups per CU
     if (gv > 256 * 16) gv = 256 * 16;
     gv = tl_cdiv(gv * 256, (int64_t)vpr * 256) * vpr;           // grid * 256 must be a multiple of the vectors per row
-    if (dtype == TL_BF16) k_affine_relu_v8<true><<<(unsigned)gv, 256, 0, tl_s(stream)>>>(in, in_ld, out, out_ld, n, C, scale, shift, relu);
-    else k_affine_relu_v8<false><<<(unsigned)gv, 256, 0, tl_s(stream)>>>(in, in_ld, out, out_ld, n, C, scale, shift, relu);
+    if (dtype == TL_BF16) k_affine_relu_v8<1><<<(unsigned)gv, 256, 0, tl_s(stream)>>>(in, in_ld, out, out_ld, n, C, scale, shift, relu);
+    else if (dtype == TL_F16) k_affine_relu_v8<2><<<(unsigned)gv, 256, 0, tl_s(stream)>>>(in, in_ld, out, out_ld, n, C, scale, shift, relu);
+    else k_affine_relu_v8<0><<<(unsigned)gv, 256, 0, tl_s(stream)>>>(in, in_ld, out, out_ld, n, C, scale, shift, relu);
     TL_CHECK_LAUNCH();
     return TL_OK;
   }

@@ -478,15 +478,11 @@ int tl_launch_conv_blk(const ConvP& p, hipStream_t s) {
   if (big(p.in_ld) || big(p.out_ld) || (p.out2 && big(p.out2_ld)) || (p.out3 && big(p.out3_ld)) || (p.res && big(p.res_ld))) return TL_ERR_UNSUPPORTED;
   if (p.out3 && !p.out2) return TL_ERR_UNSUPPORTED;
   if (p.epi_mode != TL_EPI_NONE) {
-#ifdef TL_F16_BUILD
-    return TL_ERR_UNSUPPORTED;                                   // the training epilogues are bf16
-#else
     if (p.out2 || p.out_scale || p.out_relu || p.out_ld % 8 || ((uintptr_t)p.out) % 16) return TL_ERR_UNSUPPORTED;
     if (pro && p.epi_mode != TL_EPI_STATS) return TL_ERR_UNSUPPORTED;
     // (a residual goes through the shared row stage; with the prologue the training forward applies its BatchNorm + ReLU at staging, so the
     //  activated tensor is never written -- the weight gradient recomputes it on its own stream)
     return pro ? launch_blk<8, false, 1, true, true>(p, s) : launch_blk<8, false, 1, true>(p, s);
-#endif
   }
   const int nv = p.out3 ? 3 : p.out2 ? 2 : 1;
   if (pro) {                                                       // prologue form: one view (what the engine's level-1 first convs need)

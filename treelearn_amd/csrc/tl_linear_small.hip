@@ -9,6 +9,7 @@
 //   tl_launch_wgrad_tinycout: gW[j][c]  = sum_o gout[o][j] * x[o][c]                    fixed-order partial sums per workgroup, then
 //                                                                                       tl_launch_wgrad_reduce: deterministic
 #include "tl_conv_internal.h"
+#include "tl_f16_train.h"
 
 int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K = 1, int Cout = 0, int Cin = 0, int ref_layout = 0);   // tl_wgrad_dense.hip
 
@@ -139,6 +140,9 @@ int tl_launch_wgrad_tinycout(const void* x, int64_t x_ld, const void* g, int64_t
 
 extern "C" int tl_linear_small_f32(const void* x, int64_t x_ld, int dtype, const void* w, int Cin, int Cout, int64_t n, float* out, int64_t out_ld,
                                    tl_stream_t stream) {
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16) return tl_linear_small_f32_f16(x, x_ld, TL_BF16, w, Cin, Cout, n, out, out_ld, stream);
+#endif
   if (!x || !w || !out || n <= 0 || Cin <= 0 || Cout < 1 || Cout > 8 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
   if (Cin % 8 || Cin > 1024 || x_ld % 8 || ((uintptr_t)x) % 16) return TL_ERR_UNSUPPORTED;
   ConvP p{};

@@ -5,6 +5,7 @@
 //   tl_scatter_add_rows: gin[v] = sum of g[p] over the points p of voxel v, added in ascending p (the caller passes the stable argsort
 //                        of idx once per batch), fp32 accumulation, every voxel row written exactly once -- deterministic, no atomics.
 #include "tl_conv_internal.h"
+#include "tl_f16_train.h"
 
 namespace {
 
@@ -64,6 +65,9 @@ __global__ void __launch_bounds__(256) k_scatter_add_rows(const char* __restrict
 extern "C" {
 
 int tl_gather_rows(const void* in, int64_t in_ld, int dtype, int C, int64_t n_rows, const int64_t* idx, int64_t N, void* out, int64_t out_ld, tl_stream_t stream) {
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16) return tl_gather_rows_f16(in, in_ld, TL_BF16, C, n_rows, idx, N, out, out_ld, stream);
+#endif
   if (!in || !idx || !out || C <= 0 || n_rows <= 0 || N <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
   const int eb = dtype == TL_BF16 ? 2 : 4, epv = 16 / eb;
   if (C % epv || in_ld % epv || out_ld % epv || ((uintptr_t)in) % 16 || ((uintptr_t)out) % 16) return TL_ERR_UNSUPPORTED;
@@ -77,6 +81,9 @@ int tl_gather_rows(const void* in, int64_t in_ld, int dtype, int C, int64_t n_ro
 
 int tl_scatter_add_rows(const void* g, int64_t g_ld, int dtype, int C, const int64_t* order, const int64_t* sorted_idx, int64_t N, int64_t n_rows, void* gin,
                         int64_t gin_ld, tl_stream_t stream) {
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16) return tl_scatter_add_rows_f16(g, g_ld, TL_BF16, C, order, sorted_idx, N, n_rows, gin, gin_ld, stream);
+#endif
   if (!g || !order || !sorted_idx || !gin || C <= 0 || n_rows <= 0 || N <= 0 || (dtype != TL_F32 && dtype != TL_BF16)) return TL_ERR_ARG;
   const int eb = dtype == TL_BF16 ? 2 : 4, epv = 16 / eb;
   if (C % epv || g_ld % epv || gin_ld != C || ((uintptr_t)g) % 16 || ((uintptr_t)gin) % 16) return TL_ERR_UNSUPPORTED;

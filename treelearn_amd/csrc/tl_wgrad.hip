@@ -10,6 +10,7 @@
 // partial [co][ci] tile to the workspace; tl_wgrad_reduce adds the partials in ascending chunk order -> deterministic.
 // Replaces the round-1 "gather all [N, K, Cin] rows + one library GEMM" (6 GB of scratch per level-1 conv).
 #include "tl_conv_internal.h"
+#include "tl_f16_train.h"
 
 namespace {
 
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16(const uint16_t* __re
     for (int a = 0; a < NBO; ++a)
 #pragma unroll
       for (int b = 0; b < NBI; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+        acc[a][b] = h16_mfma(A[a], B[b], acc[a][b]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(kWaves * 64) k_wgrad_bf16s(const uint16_t* __r
     for (int a = 0; a < NBO; ++a)
 #pragma unroll
       for (int b = 0; b < NBI; ++b)
-        ac[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), ac[a][b], 0, 0, 0);
+        ac[a][b] = h16_mfma(A[a], B[b], ac[a][b]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
@@ -635,11 +636,17 @@ static int wgrad_impl(const void* x, int64_t x_ld, const void* gout, int64_t g_l
 
 int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
                   int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16) return tl_conv_wgrad_f16(x, x_ld, gout, g_ld, TL_BF16, table, n_out, n_in, K, Cin, Cout, gw, ws, stream);   // the IEEE-half compilation of this unit
+#endif
   return wgrad_impl(x, x_ld, gout, g_ld, dtype, table, n_out, n_in, K, Cin, Cout, gw, ws, stream, 0);
 }
 
 int tl_conv_wgrad_ref(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K,
                       int Cin, int Cout, float* gw, float* ws, tl_stream_t stream) {
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16) return tl_conv_wgrad_ref_f16(x, x_ld, gout, g_ld, TL_BF16, table, n_out, n_in, K, Cin, Cout, gw, ws, stream);
+#endif
   return wgrad_impl(x, x_ld, gout, g_ld, dtype, table, n_out, n_in, K, Cin, Cout, gw, ws, stream, 1);
 }
 

@@ -20,6 +20,7 @@
 //     eighth of the rows (neighbouring rows gather overlapping input rows: one L2), interleaved inside the XCD -- and writes ONE
 //     partial tile set; k_wgrad_reduce_par adds the <= 128 partials in a fixed order.  Deterministic.
 #include "tl_conv_internal.h"
+#include "tl_f16_train.h"
 #include <atomic>
 
 namespace {
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense(const uint16_t* __restr
         for (int a = 0; a < NBO; ++a)
 #pragma unroll
           for (int b = 0; b < NBIW; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+            acc[a][b] = h16_mfma(A[a], B[b], acc[a][b]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(NW * 64) k_wgrad_dense_dma(const uint16_t* __r
         for (int a = 0; a < NBO; ++a)
 #pragma unroll
           for (int b = 0; b < NBIW; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+            acc[a][b] = h16_mfma(A[a], B[b], acc[a][b]);
       }
       __builtin_amdgcn_sched_barrier(0);
       head = head + 1 == NR ? 0 : head + 1;

@@ -8,6 +8,7 @@
 // Cin is cut into slices of NBIW * 32 channels over blockIdx.y; the waves of a workgroup add their tiles in wave order through LDS, the
 // workgroups' partials go through the ordered reduction (tl_launch_wgrad_reduce).  Deterministic.
 #include "tl_conv_internal.h"
+#include "tl_f16_train.h"
 #include <atomic>
 
 int tl_launch_wgrad_reduce(const float* ws, int64_t nparts, int64_t per, float* gw, hipStream_t s, int K = 1, int Cout = 0, int Cin = 0, int ref_layout = 0);   // tl_wgrad_dense.hip
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(kRW * 64) k_wgrad_rows(const uint16_t* __restr
         for (int a = 0; a < NBO; ++a)
 #pragma unroll
           for (int b = 0; b < NBIW; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a]), __builtin_bit_cast(bf16x8, B[b]), acc[a][b], 0, 0, 0);
+            acc[a][b] = h16_mfma(A[a], B[b], acc[a][b]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(kRW * 64) k_wgrad_in4(const uint16_t* __restri
           B[b][2 * q] = v[0]; B[b][2 * q + 1] = v[1];
         }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B[b]), acc[b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) acc[b] = h16_mfma(A, B[b], acc[b]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }

@@ -164,18 +164,18 @@ class TreeLearn(nn.Module):
     def active_dtype(self, training=None):
         """The dtype the sparse convs run in for this call.  Inside `torch.cuda.amp.autocast` / `torch.autocast("cuda")` -- how the
         reference selects mixed precision (tools/training/train.py:32 `autocast(enabled=config.fp16)`) -- it is the autocast dtype,
-        whatever `compute_dtype` says; outside autocast: `compute_dtype`.  float16 exists for the inference path (TL_F16); the
-        training kernels (weight gradient, BatchNorm, epilogue reductions) are bf16 / fp32, so a float16 TRAINING region runs the bf16
-        kernels: same storage width and matrix-core rate, fp32's exponent range -- a GradScaler around the step stays finite and
-        simply scales and unscales."""
+        whatever `compute_dtype` says; outside autocast: `compute_dtype`.  float16 is served end to end: the conv / head units AND the
+        training units (weight gradient, BatchNorm train forward / backward, epilogue reductions, row gather / scatter-add) are compiled a
+        second time for IEEE half (csrc/tl_half.h, tl_f16_train.h), so the reference's `autocast(enabled=config.fp16)` + GradScaler step
+        (tools/training/train.py:32,40-44) runs in float16 here as it does there; under a bf16 autocast it runs bf16 (no scaler needed)."""
         dt = self.compute_dtype
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
             if dt not in (torch.float16, torch.bfloat16):
                 dt = torch.float32
         training = (self.training or torch.is_grad_enabled()) if training is None else training
-        if dt == torch.float16 and training:
-            dt = torch.bfloat16
+        if dt == torch.float16 and training and os.environ.get("TL_F16_TRAIN", "1") == "0":
+            dt = torch.bfloat16                     # (A/B switch: a float16 training region on the bf16 kernels, as before round 5)
         return dt
 
     @cuda_cast
@@ -186,7 +186,7 @@ class TreeLearn(nn.Module):
             self._plan = InferencePlan(self, dtype, x3=self.split_bf16)
         # training under mixed precision: level 1 in the block-local order too (the staged-unit kernel serves its 32 -> 32 forward and
         # input-gradient convs; weight gradients and the other widths read the plain table in the new order, BlockedRulebook.nn_table)
-        blk_train = (not fused and dtype == torch.bfloat16 and self.unet.nPlanes[0] == 32 and os.environ.get("TL_BLK", "1") != "0"
+        blk_train = (not fused and dtype in (torch.bfloat16, torch.float16) and self.unet.nPlanes[0] == 32 and os.environ.get("TL_BLK", "1") != "0"
                      and os.environ.get("TL_BLK_TRAIN", "1") != "0")
         vfeats, geom = self._voxelize(coords.float(), input_feats.float(), batch_ids.long(), batch_size,
                                       blocked=(fused and self._plan.supports_blocked()) or blk_train, nn_table=blk_train)
@@ -258,7 +258,7 @@ class TreeLearn(nn.Module):
             except AttributeError:
                 pass
         backbone_feats = gather_rows(backbone_output.features, v2p_map, cache)
-        if not (self.training and torch.is_grad_enabled() and backbone_feats.dtype == torch.bfloat16 and os.environ.get("TL_HEAD_FP32") != "1"):
+        if not (self.training and torch.is_grad_enabled() and backbone_feats.dtype in (torch.bfloat16, torch.float16) and os.environ.get("TL_HEAD_FP32") != "1"):
             backbone_feats = backbone_feats.float()
         # mixed-precision TRAINING keeps the heads in bf16 like the backbone (the reference's autocast runs their nn.Linear layers in
         # half precision too; get_loss casts logits / offsets to fp32): half the traffic of the gather, the two MLPs and their backward

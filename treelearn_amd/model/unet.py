@@ -39,7 +39,7 @@ class MLP(nn.Sequential):
                 x = bn_relu_train(x, m, relu)
                 i += int(relu)
             elif (isinstance(m, nn.Linear) and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and m.in_features % 32 == 0
-                  and (m.out_features % 32 == 0 or m.out_features <= 8) and x.dtype in (torch.float32, torch.bfloat16)
+                  and (m.out_features % 32 == 0 or m.out_features <= 8) and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
                   and x.shape[0] * max(m.in_features, m.out_features) * x.element_size() < 2 ** 31):       # 32-bit buffer offsets in tl_conv_wgrad; beyond: nn.Linear
                 # the Linears of the heads over millions of points = 1x1 "convs": forward, dgrad and wgrad on the HIP conv kernels
                 # (the library GEMMs picked for [3.7 M, 32] x [32, 32] and [3.7 M, 32] x [32, 2] ran 25x below their memory bound:

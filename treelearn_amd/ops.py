@@ -179,8 +179,8 @@ def conv_wgrad(x: torch.Tensor, grad_out: torch.Tensor, table, n_out: int, K: in
     """gW[k][co][ci] = sum_o grad_out[o][co] * x[table[k][o]][ci] (fp32, present entries only) -> [K, Cout, Cin]; with ref_layout the
     result comes back as [Cout, K, Cin], the layout of the module parameter (spconv `.weight` [Cout,k,k,k,Cin])."""
     L = _hip.lib()
-    if x.dtype == torch.bfloat16 and grad_out.dtype == torch.bfloat16:
-        g = grad_out                                     # mixed precision: the kernel widens bf16 in registers
+    if x.dtype in (torch.bfloat16, torch.float16) and grad_out.dtype == x.dtype:
+        g = grad_out                                     # mixed precision: the 16-bit operands go to the matrix cores as they are
     else:
         x = x.float(); g = grad_out.float()
     if x.stride(1) != 1: x = x.contiguous()
