@@ -486,7 +486,8 @@ def test_training_step_staged_batchnorm_equals_the_apply_pass(monkeypatch):
     monkeypatch.setattr(autograd, "STAGE_TRAIN", False)
     l0, g0, _ = _train_grads(True, gb)
     assert abs(l1 - l0) <= 1e-3 * abs(l0)
+    nmax = max(float(v.norm()) for v in g0.values())
     for k in g0:
         a, c = g0[k], g1[k]
-        if float(a.norm()) > 0:
+        if float(a.norm()) > 1e-3 * nmax:                   # (a Linear bias in front of a BatchNorm has a zero gradient: pure rounding noise)
             assert float((a * c).sum() / (a.norm() * c.norm())) >= 0.995, k

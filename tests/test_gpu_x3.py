@@ -107,3 +107,24 @@ def test_x3_wide_conv_runs_as_two_half_width_launches():
     # with a residual or a second view the chained form does not apply: the exact kernel runs on the plain weights
     res = torch.randn((lv.n, 128), device="cuda", generator=gen)
     assert torch.equal(ops.conv_fwd(x, w_x3, lv.nbr, lv.n, residual=res), ops.conv_fwd(x, w_exact, lv.nbr, lv.n, residual=res))
+
+
+@pytest.mark.parametrize("cin,cout", [(160, 160), (192, 192), (224, 224), (96, 64)])
+def test_x3_small_level_kernel(cin, cout):
+    """The small-level kernel (<= 16 384 rows: levels 5-7) in the split-bf16 form against its exact fp32 self and float64."""
+    from treelearn_amd import ops
+    g = _geom(extent=8.0, levels=3)
+    lv = g.levels[2]                                       # a few thousand rows
+    assert lv.n <= 16384
+    gen = torch.Generator(device="cuda"); gen.manual_seed(cin + cout)
+    w = torch.randn((cout, 3, 3, 3, cin), device="cuda", generator=gen) / (cin * 27) ** 0.5
+    x = torch.randn((lv.n, cin), device="cuda", generator=gen)
+    res = torch.randn((lv.n, cout), device="cuda", generator=gen)
+    w_exact, w_x3 = _packs(w)
+    y_exact = ops.conv_fwd(x, w_exact, lv.nbr, lv.n, residual=res)
+    y_x3 = ops.conv_fwd(x, w_x3, lv.nbr, lv.n, residual=res)
+    assert not torch.equal(y_exact, y_x3)
+    assert float((y_exact - y_x3).abs().max()) / float(y_exact.abs().max()) < 1e-4
+    sub = lv.nbr.T.contiguous().cpu().numpy()
+    ref = osp.conv_table(x.double().cpu(), w.double().cpu(), sub).numpy() + res.double().cpu().numpy()
+    assert np.abs(y_x3.double().cpu().numpy() - ref).max() / np.abs(ref).max() < 5e-5

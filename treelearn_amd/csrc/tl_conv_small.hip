@@ -14,8 +14,11 @@
 namespace {
 
 // FR: B operands come from the fragment-order weight copy (p.w_frag): 1 KB contiguous per load instead of 32 rows x 32 B
-template <bool BF16, int NBB, int WV, bool FR>
+// X3 (fp32 rows): split-bf16 contraction on weights in the tl_pack_weight_x3 form (p.w_x3; tl_conv_internal.h: mma16_x3) -- the B "pieces"
+// b[..][J] / b[..][2 + J] are then the hi / lo parts of channel group J of the unit
+template <bool BF16, int NBB, int WV, bool FR, bool X3 = false>
 __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
+  static_assert(!X3 || (!BF16 && !FR), "split-bf16: fp32 rows, weights in their own layout");
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
   constexpr int PF = 4;                                       // steps per batch and wave (their independent loads are issued together)
   constexpr int KMAX = 27;
@@ -40,7 +43,7 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)p.Cin * EB;
   const bool buf_ok = in_bytes > 0 && in_bytes + 2 * (int64_t)in_ld_b < 0xFFFFFFFFll;       // else: clamp + mask path
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, buf_ok ? (int)in_bytes : 0, 0x00020000);
-  const char* inb = (const char*)p.in; const char* Wb = (const char*)(FR ? p.w_frag : p.w);
+  const char* inb = (const char*)p.in; const char* Wb = (const char*)(X3 ? p.w_x3 : (FR ? p.w_frag : p.w));
   const int CBt = p.Cout / 32;
 
   f32x16 acc[NBB];
@@ -76,6 +79,8 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           if constexpr (FR) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk * CBt + col0 / 32 + nb) * nchunk + B.ch[u]) * NJ + j) * 64 + lane) * 16);
+          else if constexpr (X3) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk * p.Cout + col0 + nb * 32 + fi) * p.Cin + B.ch[u] * 32) * EB +
+                                                                                  ((j < 2 ? 2 * j : 4 + 2 * (j - 2)) + fh) * 16);
           else B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk * p.Cout + col0 + nb * 32 + fi) * p.Cin + B.ch[u] * 32) * EB + j * 32 + fh * 16);
     }
   };
@@ -108,6 +113,17 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
           }
         }
     }
+    if constexpr (X3) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+          u32x4 ah, al;
+          x3_split8(B.a[u][2 * J], B.a[u][2 * J + 1], ah, al);
+#pragma unroll
+          for (int nb = 0; nb < NBB; ++nb) mma16_x3(acc[nb], ah, al, B.b[u][nb][J], B.b[u][nb][2 + J]);
+        }
+    } else
 #pragma unroll
     for (int u = 0; u < PF; ++u)
 #pragma unroll
@@ -240,7 +256,14 @@ int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
     else k_conv_small<BF_, 1, 4, FR_><<<g, 256, 0, s>>>(p, ncb);                               \
   } while (0)
   const bool fr = p.w_frag != nullptr && ((uintptr_t)p.w_frag) % 16 == 0 && g_small_mode != 3;
+  // fp32 rows with split-bf16 weights (the bf16x3 mode; weights of >= 256 input channels come as two half-width convs: exact kernel)
+  const bool x3 = dtype == TL_F32 && p.w_x3 != nullptr && p.Cin < 256 && !p.in_scale && !p.in_relu;
   if (dtype == TL_BF16) { if (fr) TL_SMALL(true, true); else TL_SMALL(true, false); }
+  else if (x3) {
+    if (eight) k_conv_small<false, 1, 8, false, true><<<g, 512, 0, s>>>(p, ncb);
+    else if (two) k_conv_small<false, 2, 4, false, true><<<g, 256, 0, s>>>(p, ncb);
+    else k_conv_small<false, 1, 4, false, true><<<g, 256, 0, s>>>(p, ncb);
+  }
   else { if (fr) TL_SMALL(false, true); else TL_SMALL(false, false); }
 #undef TL_SMALL
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
