@@ -24,17 +24,61 @@ def _compute_streams(n):
     return _STREAMS[:n]
 
 
-def _to_device_async(batch, stream):
-    """Start the H2D copies of the tensors the forward needs on `stream` (non-blocking when the batch is pinned,
-    as the reference DataLoader's pin_memory=True makes it; util/train.py:140)."""
-    out = dict(batch)
-    with torch.cuda.stream(stream):
-        for k in _GPU_KEYS:
-            v = batch.get(k)
-            if torch.is_tensor(v) and not v.is_cuda:
-                out[k] = v.cuda(non_blocking=True)
-        ev = torch.cuda.Event(); ev.record(stream)
-    return out, ev
+class _H2DRing:
+    """Persistent device staging buffers for the tiles a loop has in flight.  `tensor.cuda()` per tile allocates on the copy stream and the
+    blocks come back through record_stream events, which in practice meant a hipMalloc / hipFree pair -- both synchronise the device -- per
+    tile and key: a loop over HOST-resident 40 m tiles took 36-51 ms per tile against 7.2 ms for device-resident ones (profiles/r5_final/
+    pcie_inclusive.txt).  Here every slot owns its buffers (grown on demand, kept for the life of the process); a slot is re-used for tile
+    k + depth only after the event that marks tile k's read-back (`release`)."""
+
+    def __init__(self, depth, stream):
+        self.depth, self.stream = depth, stream
+        self.slots = [dict() for _ in range(depth)]
+        self.free_ev = [None] * depth
+        self.i = 0
+
+    def stage(self, batch):
+        """-> (batch dict with the forward's tensors on the device, event of the copies, slot index or None when nothing was copied)"""
+        out = dict(batch)
+        todo = [k for k in _GPU_KEYS if torch.is_tensor(batch.get(k)) and not batch[k].is_cuda]
+        with torch.cuda.stream(self.stream):
+            if not todo:
+                ev = torch.cuda.Event(); ev.record(self.stream)
+                return out, ev, None
+            s = self.i % self.depth
+            self.i += 1
+            if self.free_ev[s] is not None:
+                self.stream.wait_event(self.free_ev[s])
+                self.free_ev[s] = None
+            slot = self.slots[s]
+            for k in todo:
+                v = batch[k]
+                n = v.shape[0]
+                buf = slot.get(k)
+                if buf is None or buf.shape[0] < n or buf.dtype != v.dtype or buf.shape[1:] != v.shape[1:]:
+                    buf = slot[k] = torch.empty((int(n * 1.2) + 64,) + tuple(v.shape[1:]), dtype=v.dtype, device="cuda")
+                view = buf[:n]
+                view.copy_(v, non_blocking=True)                       # asynchronous when the batch is pinned (the reference DataLoader's pin_memory=True)
+                view._tl_ring = True
+                out[k] = view
+            ev = torch.cuda.Event(); ev.record(self.stream)
+        return out, ev, s
+
+    def release(self, s, event):
+        if s is not None:
+            self.free_ev[s] = event
+
+
+_RINGS = {}
+
+
+def _h2d_ring(depth, stream):
+    key = (torch.cuda.current_device(), depth)
+    r = _RINGS.get(key)
+    if r is None:
+        r = _RINGS[key] = _H2DRing(depth, stream)
+    r.stream = stream
+    return r
 
 
 def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True, return_tile_rows=False,
@@ -59,10 +103,13 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     main_stream = torch.cuda.current_stream() if use_gpu else None
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
 
-    def read_back(pos, batch, gbatch, output, done):
+    def read_back(pos, batch, gbatch, output, done, slot=None):
         n0 = sum(len(o) for o in outs[0])
         _read_back_on(batch, gbatch, output, done)
         tile_rows.append((pos, sum(len(o) for o in outs[0]) - n0))
+        if slot is not None:                                           # the tile's staging slot may take the next host tile once this read-back has run
+            ev = torch.cuda.Event(); ev.record(rb_stream if done is not None else torch.cuda.current_stream())
+            ring.release(slot, ev)
 
     def _read_back_on(batch, gbatch, output, done):
         if done is not None:
@@ -73,7 +120,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
 
     def _read_back(batch, gbatch, output, done_on_other_stream=False):
         dev = output['offset_predictions'].device
-        if done_on_other_stream and gbatch['masks_inner'].is_cuda:
+        if done_on_other_stream and gbatch['masks_inner'].is_cuda and not getattr(gbatch['masks_inner'], "_tl_ring", False):
             gbatch['masks_inner'].record_stream(torch.cuda.current_stream())
         idx = torch.nonzero(gbatch['masks_inner'].to(dev)).squeeze(1)          # one small sync; 4-5 % of the rows survive
         ci = None
@@ -82,7 +129,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             """Inner rows of a per-point array: gathered on the device if it lives there, else on the host."""
             nonlocal ci
             if t.is_cuda:
-                if done_on_other_stream:
+                if done_on_other_stream and not getattr(t, "_tl_ring", False):
                     t.record_stream(torch.cuda.current_stream())       # allocated on a compute stream, read here on the read-back stream
                 return t.index_select(0, idx)
             if ci is None:
@@ -135,15 +182,16 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                 model.ensure_plan()                                        # on the caller's stream, which every compute stream waits for
             it = iter(dataloader)
             nxt = next(it, None)
-            staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+            ring = _h2d_ring(nf + 3, copy_stream) if use_gpu else None
+            staged = ring.stage(nxt) if (nxt is not None and use_gpu) else (nxt, None, None)
             pending = []                                                   # tiles whose results are still on the device, oldest first
             pos = -1
             while nxt is not None:
-                batch, (gbatch, ev) = nxt, staged
+                batch, (gbatch, ev, slot) = nxt, staged
                 pos += 1
                 gbatch['voxel_size'] = vs
                 nxt = next(it, None)
-                staged = _to_device_async(nxt, copy_stream) if (nxt is not None and use_gpu) else (nxt, None)
+                staged = ring.stage(nxt) if (nxt is not None and use_gpu) else (nxt, None, None)
                 cs = cstreams[pos % nf] if cstreams else None
                 if cs is not None:
                     cs.wait_stream(main_stream)                            # inputs produced on the caller's stream are visible
@@ -151,7 +199,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                     with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
                         if cs is not None:                                 # inputs allocated on the copy / tiler / caller's stream, consumed on this one
                             for v in gbatch.values():
-                                if torch.is_tensor(v) and v.is_cuda:
+                                if torch.is_tensor(v) and v.is_cuda and not getattr(v, "_tl_ring", False):
                                     v.record_stream(cs)
                         if ev is not None:
                             torch.cuda.current_stream().wait_event(ev)
@@ -167,11 +215,14 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                     if logger:
                         logger.info('Error in forward pass due to axis size collapse to zero during contraction of U-Net. '
                                     'If this does not happen too often, the results should not be influenced.')
+                    if slot is not None:
+                        e2 = torch.cuda.Event(); e2.record(cs if cs is not None else torch.cuda.current_stream())
+                        ring.release(slot, e2)
                     continue
                 if os.environ.get("TL_LOOP_PIPELINE", "1") == "0":           # A/B switch: read every tile back right away
-                    read_back(pos, batch, gbatch, output, None)
+                    read_back(pos, batch, gbatch, output, None, slot)
                     continue
-                pending.append((pos, batch, gbatch, output, done))
+                pending.append((pos, batch, gbatch, output, done, slot))
                 if len(pending) > nf:
                     read_back(*pending.pop(0))                             # the oldest tile comes home while nf younger ones compute
             for pnd in pending:
