@@ -668,11 +668,11 @@ def main():
             # one run carries them: the training step (config 3) and the 0.05 m stress tile (config 5)
             import types
             try:
-                ts = training_step_bench(types.SimpleNamespace(steps=5, warmup=2, dtype=args.dtype), 0, 1, None)
+                ts = training_step_bench(types.SimpleNamespace(steps=8, warmup=3, dtype=args.dtype), 0, 1, None)
                 res["training_step"] = {k: ts[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
                 if args.dtype == "bf16":
                     # the reference's own regime beside it: float16 autocast + GradScaler on the float16 training kernels
-                    t16 = training_step_bench(types.SimpleNamespace(steps=5, warmup=2, dtype="fp16"), 0, 1, None)
+                    t16 = training_step_bench(types.SimpleNamespace(steps=6, warmup=3, dtype="fp16"), 0, 1, None)
                     res["training_step"]["fp16_autocast_gradscaler"] = dict(ms_per_step=t16["ms_per_step"], value=t16["value"], unit=t16["unit"],
                                                                             gradscaler_skipped_steps=t16["config"]["gradscaler_skipped_steps"],
                                                                             gradscaler_final_scale=t16["config"]["gradscaler_final_scale"], last_losses=t16["config"]["last_losses"])
