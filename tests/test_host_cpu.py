@@ -330,3 +330,14 @@ def test_conv_epilogue_statistics_are_dropped_when_the_features_change_in_place(
     y.mul_(2.0)                                      # an in-place op between the conv and its BatchNorm
     assert get_stats(y) is None and get_stats(v) is None
     assert get_stats(torch.randn(4, 8)) is None
+
+
+def test_forward_arena_allocator_under_sanitizers(tmp_path):
+    """tl_forward's device-memory arena (csrc/tl_arena.h: best fit, coalescing, dry-run planning) is host-only code: random take / give
+    sequences against a brute-force model, compiled with AddressSanitizer + UBSan (the CPU build is where sanitizers can run)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "arena_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(root, "treelearn_amd", "csrc"), os.path.join(root, "tests", "tools", "arena_test.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "arena_test OK" in r.stdout, r.stdout + r.stderr
