@@ -18,6 +18,10 @@ def timeit(f, reps=30, warm=5):
     return e0.elapsed_time(e1) / reps
 
 
+if os.environ.get("VIEW_Q"):                              # dev build: a variant of the stream-q kernel for the 64 -> 64 shape (tl_conv_streamq.hip)
+    from treelearn_amd import _hip
+    _hip.lib().tl_dev_streamq_tm(int(os.environ["VIEW_Q"]), None)
+    print("stream-q variant", os.environ["VIEW_Q"])
 b = make_batch([make_tile(**CONFIGS["config2"], seed=0)])
 g = G.build_geometry(b["coords"].cuda().float(), b["batch_ids"].cuda().long(), 1, 0.1, 7, [500, 500, 1000])
 for li, C in ((1, 64), (2, 96)):

@@ -263,6 +263,12 @@ int dispatch(const ConvP& p, hipStream_t s) {
       if (nb == 3 && un == 4) return launch<true, 8, 3, 4, 1, 1, false, true>(p, s);
     }
   }
+  if constexpr (BF16 && K == 8) {
+    // the level-1 -> 2 strided conv (two output views, 1.7 of 8 taps present): two row blocks per wave -- half as many workgroups, each
+    // amortising its start (table, first gathers) and drain (the stores of two views) over 512 rows: 0.162 -> 0.124 ms with two views,
+    // 0.090 -> 0.086 with one; prefetch depth 4 / 6 / 8: no change; three or four row blocks: 0.128 (tools/dev_k8.py)
+    if (!p.one_hot && nb == 2 && un == 1 && g_stream_rb != 1) return launch<true, 8, 2, 1, 3, 2>(p, s);
+  }
   if constexpr (BF16 && K == 27) {
     if (g_stream_tm && nb == 2 && un == 2) return launch<true, 27, 2, 2, 3, 1, true>(p, s);
     if (g_stream_da && nb == 2 && un == 2) {                  // developer A/B of the prefetch depth on the 64->64 shape
