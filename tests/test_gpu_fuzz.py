@@ -1,0 +1,111 @@
+"""Randomised point clouds through the whole forward: shapes the synthetic forest generator never makes (thin slabs, single columns, blobs far
+from the origin, duplicated points, points on the borders of the voxel grid, batches of very different sizes).  Three checks per case:
+tl_forward == the Python-driven engine bit for bit (same launches), geometry == the numpy oracle bit for bit, and the fp32 / bf16x3 forward
+within the north star's 1e-3 of the CPU oracle's forward.  Reference path: tree_learn/model/tree_learn.py:87-167."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om, voxel as ov
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-3
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def _cloud(rng, kind, n):
+    if kind == "slab":                                     # one voxel thick in z
+        p = np.column_stack([rng.uniform(0, 14, n), rng.uniform(0, 9, n), rng.uniform(3.0, 3.09, n)])
+    elif kind == "column":                                 # a single vertical pole
+        p = np.column_stack([rng.uniform(5.0, 5.25, n), rng.uniform(7.0, 7.25, n), rng.uniform(0, 30, n)])
+    elif kind == "blobs":                                  # dense clusters, empty space between them
+        c = rng.uniform(0, 20, (6, 3)); c[:, 2] *= 0.5
+        p = c[rng.integers(0, 6, n)] + rng.normal(0, 0.35, (n, 3))
+    elif kind == "far":                                    # coordinates far from the origin and negative (the tile's minimum is subtracted)
+        p = rng.uniform(0, 8, (n, 3)) + np.array([-4321.7, 98765.4, -12.3])
+    elif kind == "dupes":                                  # many points per voxel, exact duplicates included
+        base = rng.uniform(0, 6, (max(n // 8, 1), 3))
+        p = np.concatenate([base[rng.integers(0, len(base), n - len(base))], base])
+    elif kind == "lattice":                                # points exactly on voxel borders (multiples of the voxel size)
+        p = rng.integers(0, 60, (n, 3)).astype(np.float64) * 0.1
+    else:                                                  # "sparse": isolated voxels, almost no neighbours
+        p = rng.uniform(0, 40, (n, 3)); p[:, 2] *= 0.5
+    return p.astype(np.float32)
+
+
+CASES = [("slab", 4000), ("column", 1500), ("blobs", 20000), ("far", 6000), ("dupes", 9000), ("lattice", 5000), ("sparse", 3000), ("blobs", 300)]
+
+
+def _model(dtype, seed=7):
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import random_state_dict
+    m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=dtype)
+    m.load_state_dict(random_state_dict(seed, channels=32, num_blocks=7), strict=True)
+    return m.cuda().eval()
+
+
+def _batch(clouds):
+    coords = np.concatenate(clouds)
+    bids = np.concatenate([np.full(len(c), i, np.int64) for i, c in enumerate(clouds)])
+    return dict(coords=torch.from_numpy(coords), input_feats=torch.ones(len(coords), 1), batch_ids=torch.from_numpy(bids), batch_size=len(clouds))
+
+
+def _run_both(model, batch):
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        assert model._executor(model.active_dtype(False)) is not None
+        a = model(gb, return_loss=False)
+        os.environ["TL_EXEC"] = "0"
+        try:
+            b = model(gb, return_loss=False)
+        finally:
+            del os.environ["TL_EXEC"]
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("case", range(len(CASES)), ids=[f"{k}_{n}" for k, n in CASES])
+def test_random_cloud_forward(case):
+    kind, n = CASES[case]
+    rng = np.random.default_rng(1000 + case)
+    batch = _batch([_cloud(rng, kind, n)])
+    ref = None
+    for dtype in (torch.bfloat16, torch.float32, "bf16x3"):
+        m = _model(dtype)
+        a, b = _run_both(m, batch)
+        for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+            same = (a[k] == b[k]) | (torch.isnan(a[k]) & torch.isnan(b[k]))
+            assert bool(same.all()), (kind, dtype, k, int((~same).sum()))
+        if dtype == torch.bfloat16:
+            continue
+        if ref is None:
+            sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+            ref = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 1, voxel_size=0.1, num_blocks=7,
+                             spatial_shape=[500, 500, 1000])
+        for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+            e = rel_err(a[k].cpu().numpy(), ref[k].numpy())
+            assert e < REL_TOL, (kind, dtype, k, e)
+
+
+def test_random_batch_of_three_unequal_clouds():
+    """Three clouds of very different sizes in one batch (tree_learn.py:129-167 voxelizes per batch entry and concatenates): geometry against
+    the numpy oracle bit for bit, forward against the oracle's."""
+    from treelearn_amd import geometry as G
+    rng = np.random.default_rng(77)
+    batch = _batch([_cloud(rng, "blobs", 12000), _cloud(rng, "column", 200), _cloud(rng, "slab", 2500)])
+    geom = G.build_geometry(batch["coords"].cuda(), batch["batch_ids"].cuda(), 3, 0.1, 7, [500, 500, 1000])
+    _, vc, v2p, _ = ov.voxelize(batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 3, 0.1)
+    assert np.array_equal(geom.levels[0].coords.cpu().numpy(), vc) and np.array_equal(geom.v2p.cpu().numpy(), v2p)
+    m = _model(torch.float32)
+    a, b = _run_both(m, batch)
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert torch.equal(a[k], b[k]), k
+    ref = om.forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, batch["coords"].numpy(), batch["input_feats"].numpy(),
+                     batch["batch_ids"].numpy(), 3, voxel_size=0.1, num_blocks=7, spatial_shape=[500, 500, 1000])
+    for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+        assert rel_err(a[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, k
