@@ -266,7 +266,10 @@ def training_step_bench(args, rank, world, dist):
     model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=cfg["voxel"], compute_dtype=dtype)
     model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
     model = model.cuda().train()
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3)
+    # torch's own AdamW in its single-kernel form (`fused=True`; the reference builds the optimizer from the config's kwargs, util/train.py:105-110,
+    # so `fused: true` in the yaml selects it there too): the for-each form is ~36 launches and 2.3 ms of a host-bound tail per step
+    fused = os.environ.get("TL_BENCH_ADAMW", "fused") == "fused"
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3, fused=fused)
     gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
     scaler = torch.amp.GradScaler("cuda", enabled=fp16)
@@ -315,7 +318,7 @@ def training_step_bench(args, rank, world, dist):
                 value=float(npts) / sec / 1e6, unit="Mpoints/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=sec * 1e3,
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                 config=dict(workload=f"config3: training step, batch of 2 crops of 40x40 m at 0.1 m ({n_pts} points), default 7-level 32-ch model "
-                                     f"(30.1 M params, random init), AdamW, grad-norm clip 1.0, " + {"bf16": "bf16 mixed precision (autocast-like)", "fp32": "fp32", "fp16":
+                                     f"(30.1 M params, random init), torch.optim.AdamW({'fused=True' if fused else 'for-each'}), grad-norm clip 1.0, " + {"bf16": "bf16 mixed precision (autocast-like)", "fp32": "fp32", "fp16":
                             "float16 autocast + GradScaler (the reference's regime, tools/training/train.py:32,40-44)"}.get(args.dtype, args.dtype),
                             points_per_step=n_pts, last_losses=vals, **(dict(gradscaler_skipped_steps=skipped[0], gradscaler_final_scale=scaler.get_scale()) if fp16 else {})),
                 roofline=dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None,

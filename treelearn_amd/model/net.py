@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import geometry as G
 from .. import spconv_compat as spconv
-from ..util.train import cuda_cast, point_wise_loss
+from ..util.train import cuda_cast, loss_mask_rows, point_wise_loss
 from .engine import InferencePlan
 from .unet import MLP, ResidualBlock, UBlock
 
@@ -132,11 +132,14 @@ class TreeLearn(nn.Module):
                 return dict(backbone_feats=bb, semantic_prediction_logits=logits, offset_predictions=offsets)
         # only the tensors the backbone reads cross PCIe here (the reference's cuda_cast also ships every label /
         # mask / centre tensor of the batch, ~80 MB per tile that inference never touches; util/train.py:28-43)
+        mask_rows = None
+        if return_loss and os.environ.get("TL_LOSS_ROWS", "1") != "0":
+            mask_rows = loss_mask_rows(batch['masks_sem'], batch['masks_off'])        # before anything is enqueued: no wait behind the forward
         backbone_output, v2p_map = self.forward_backbone(coords=batch['coords'], input_feats=batch['input_feats'],
                                                          batch_ids=batch['batch_ids'], batch_size=batch['batch_size'])
         output = self.forward_head(backbone_output, v2p_map)
         if return_loss:
-            output = self.get_loss(model_output=output, **batch)
+            output = self.get_loss(model_output=output, mask_rows=mask_rows, **batch)
         return output
 
     def _voxelize(self, coords, input_feats, batch_ids, batch_size, blocked=False, nn_table=False):
@@ -269,10 +272,10 @@ class TreeLearn(nn.Module):
         return output
 
     @cuda_cast
-    def get_loss(self, model_output, semantic_labels, offset_labels, masks_off, masks_sem, **kwargs):
+    def get_loss(self, model_output, semantic_labels, offset_labels, masks_off, masks_sem, mask_rows=None, **kwargs):
         semantic_loss, offset_loss = point_wise_loss(
             model_output['semantic_prediction_logits'].float(), model_output['offset_predictions'].float(),
-            masks_sem, masks_off, semantic_labels, offset_labels)
+            masks_sem, masks_off, semantic_labels, offset_labels, mask_rows=mask_rows)
         loss_dict = dict(semantic_loss=semantic_loss * LOSS_MULTIPLIER_SEMANTIC, offset_loss=offset_loss)
         loss = sum(v for v in loss_dict.values())
         return loss, loss_dict

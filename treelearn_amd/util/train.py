@@ -16,23 +16,39 @@ def cuda_cast(func):
 
 
 @cuda_cast
-def point_wise_loss(semantic_prediction_logits, offset_predictions, masks_sem, masks_off, semantic_labels, offset_labels, weights=None):
-    return point_wise_loss_impl(semantic_prediction_logits, offset_predictions, masks_sem, masks_off, semantic_labels, offset_labels, weights)
+def point_wise_loss(semantic_prediction_logits, offset_predictions, masks_sem, masks_off, semantic_labels, offset_labels, weights=None, mask_rows=None):
+    return point_wise_loss_impl(semantic_prediction_logits, offset_predictions, masks_sem, masks_off, semantic_labels, offset_labels, weights, mask_rows)
 
 
-def point_wise_loss_impl(logits, offsets, masks_sem, masks_off, semantic_labels, offset_labels, weights=None):
+def loss_mask_rows(masks_sem, masks_off):
+    """Row indices of the two loss masks.  They depend on the batch only, so `TreeLearn.forward` takes them BEFORE the network is enqueued: the
+    boolean indexing and the `mask.sum() == 0` tests of the reference's loss (util/train.py:147,153,159,163) each read a count back from the
+    device, i.e. wait for the whole forward and then drain the queue four to six times; taken up front the reads find an idle device (or,
+    for host-resident masks, no device at all) and the loss itself enqueues without a wait."""
+    rows = []
+    for m in (masks_sem, masks_off):
+        idx = m.nonzero(as_tuple=False).view(-1)
+        rows.append(idx if idx.is_cuda or not torch.cuda.is_available() else idx.cuda(non_blocking=True))
+    return tuple(rows)
+
+
+def point_wise_loss_impl(logits, offsets, masks_sem, masks_off, semantic_labels, offset_labels, weights=None, mask_rows=None):
     """Masked CE (sum / count) and masked mean L2 offset error; an empty mask yields `0 * sum`
-    so the graph stays connected (train.py:147-148,159-160)."""
-    n_sem = int(masks_sem.sum())
+    so the graph stays connected (train.py:147-148,159-160).  `mask_rows` = loss_mask_rows(masks_sem, masks_off): the masks as row lists
+    (`x[mask]` == `x.index_select(0, rows)`, same order, same values) -- no read-back between the forward and the loss."""
+    if mask_rows is None:
+        mask_rows = loss_mask_rows(masks_sem, masks_off)
+    sem_rows, off_rows = (r.to(logits.device) for r in mask_rows)
+    n_sem = sem_rows.numel()
     if n_sem == 0:
         semantic_loss = 0 * logits.sum()
     else:
-        ce = F.cross_entropy(logits[masks_sem], semantic_labels[masks_sem], reduction='sum' if weights is None else 'none')
+        ce = F.cross_entropy(logits.index_select(0, sem_rows), semantic_labels.index_select(0, sem_rows), reduction='sum' if weights is None else 'none')
         semantic_loss = (ce if weights is None else (ce * weights).sum()) / n_sem
-    if int(masks_off.sum()) == 0:
+    if off_rows.numel() == 0:
         offset_loss = 0 * offsets.sum()
     else:
-        offset_loss = (offsets[masks_off] - offset_labels[masks_off]).pow(2).sum(1).sqrt().mean()
+        offset_loss = (offsets.index_select(0, off_rows) - offset_labels.index_select(0, off_rows)).pow(2).sum(1).sqrt().mean()
     return semantic_loss, offset_loss
 
 
