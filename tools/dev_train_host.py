@@ -10,7 +10,9 @@ cfg = CONFIGS["config2"]
 batch = make_batch([make_tile(**cfg, seed=s) for s in (0, 1)])
 model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=torch.bfloat16)
 model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7)); model = model.cuda().train()
-opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3)
+fused = os.environ.get("TL_BENCH_ADAMW", "fused") == "fused"              # as bench.py: torch's single-kernel AdamW unless TL_BENCH_ADAMW=foreach
+opt = torch.optim.AdamW(model.parameters(), lr=3e-3, weight_decay=1e-3, fused=fused)
+print("AdamW:", "fused=True" if fused else "for-each")
 g = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 sync = torch.cuda.synchronize
 for it in range(5):

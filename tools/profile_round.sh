@@ -22,6 +22,7 @@ mkdir -p $O/c3; rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o
 python tools/trace_gaps.py $O/c3 > $O/config3_timeline.txt 2>&1
 find $O/c3 -name "*kernel_trace.csv" -delete
 python tools/dev_train_host.py > $O/config3_phases.txt 2>&1
+TL_BENCH_ADAMW=foreach python tools/dev_train_host.py >> $O/config3_phases.txt 2>&1
 python tools/dev_wgrad_dense.py > $O/wgrad_dense_vs_pair_list.txt 2>&1
 python tools/dev_conv_table.py > $O/conv_launch_table.txt 2>&1
 tail -c 400 $O/bench_unprofiled.json; ls $O/*
@@ -34,3 +35,5 @@ find $O/tr1 -name "*kernel_trace.csv" -delete
 python bench.py --dtype bf16x3 --no-cpu-baseline --no-power-probe --no-extra-workloads --tiles-in-flight 1 --steps 5 --warmup 2 --layer-table $O/layer_table_bf16x3.txt > $O/bench_bf16x3.json 2>> $O/bench_unprofiled.err
 python bench.py --dtype fp32 --no-cpu-baseline --no-power-probe --no-extra-workloads --tiles-in-flight 1 --steps 5 --warmup 2 --layer-table $O/layer_table_fp32.txt > $O/bench_fp32.json 2>> $O/bench_unprofiled.err
 python bench.py --tiles-in-flight 1 $Q --layer-table $O/layer_table_bf16.txt > /dev/null 2>> $O/bench_unprofiled.err
+python tools/dev_k8.py > $O/k8_table.txt 2>&1
+python tools/dev_geom_value.py > $O/geom_value.txt 2>&1
