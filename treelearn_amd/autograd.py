@@ -14,13 +14,41 @@ import torch
 from . import ops
 from .geometry import BlockedRulebook
 
-_packed_cache = {}          # id(parameter) -> (weakref to it, (version, dtype, device, data_ptr), packed); evicted when the parameter dies
+_packed_cache = {}          # id(parameter) -> (weakref to it, (epoch, version, dtype, device, data_ptr), packed); evicted when the parameter dies
+
+# The kernel-layout copies of a parameter are valid for ONE pack epoch.  `_version` alone is not enough: torch's single-kernel optimizers
+# (`fused=True`: torch._fused_adamw_ / _fused_sgd_ / _fused_adam_) update the parameters without bumping it, and a cache keyed on the version
+# would keep training on the weights of step 0.  A new epoch begins with every training forward of the model (`TreeLearn.forward_backbone`)
+# and at the end of every backward pass that went through one of the conv Functions below (`note_backward`), i.e. before any optimizer can
+# have run; within an epoch forward, input-gradient and weight-gradient launches of a layer share one packing.
+_pack_epoch = 0
+_epoch_queued = set()
+
+
+def new_pack_epoch():
+    global _pack_epoch
+    _pack_epoch += 1
+
+
+def note_backward():
+    """Called from the conv Functions' backward: once per backward pass, when it ends, the pack epoch advances."""
+    gid = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else -1
+    if gid in _epoch_queued:
+        return
+    def _cb(gid=gid):
+        _epoch_queued.discard(gid)
+        new_pack_epoch()
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_cb)
+        _epoch_queued.add(gid)
+    except RuntimeError:                       # not inside a backward pass (a Function's backward called by hand)
+        pass
 
 
 def _packed(weight, dtype):
     """[Cout,k,k,k,Cin] parameter -> [K,Cout,Cin] kernel layout, cached per parameter OBJECT (the weak reference guards against a
-    recycled id) and invalidated by in-place updates (optimizer steps bump `_version`) or a dtype / device change."""
-    key = (weight._version, dtype, weight.device, weight.data_ptr())
+    recycled id) for the current pack epoch; also invalidated by in-place updates that bump `_version` or a dtype / device change."""
+    key = (_pack_epoch, weight._version, dtype, weight.device, weight.data_ptr())
     hit = _packed_cache.get(id(weight))
     if hit is not None and hit[0]() is weight and hit[1] == key:
         return hit[2]
@@ -90,7 +118,7 @@ _dgrad_cache = {}           # id(parameter) -> (weakref, (version, dtype, device
 
 def _packed_dgrad(weight, dtype, flip):
     """W[k]^T (taps flipped for SubM) for the layer's input-gradient conv, cached like `_packed`."""
-    key = (weight._version, dtype, weight.device, weight.data_ptr(), bool(flip))
+    key = (_pack_epoch, weight._version, dtype, weight.device, weight.data_ptr(), bool(flip))
     hit = _dgrad_cache.get(id(weight))
     if hit is not None and hit[0]() is weight and hit[1] == key:
         return hit[2]
@@ -147,7 +175,7 @@ class PackPlan:
 
     def refresh(self):
         from . import _hip
-        sig = tuple(w._version for w in self.params)
+        sig = (_pack_epoch,) + tuple(w._version for w in self.params)
         if sig == self.sig:
             return
         L = _hip.lib()
@@ -155,8 +183,8 @@ class PackPlan:
                    "tl_pack_weights_batch")
         self.sig = sig
         for w, (pk, fr, dg, flip) in zip(self.params, self.out):
-            for cache, key, val in ((_packed_cache, (w._version, self.dtype, w.device, w.data_ptr()), pk),
-                                    (_dgrad_cache, (w._version, self.dtype, w.device, w.data_ptr(), flip), dg)):
+            for cache, key, val in ((_packed_cache, (_pack_epoch, w._version, self.dtype, w.device, w.data_ptr()), pk),
+                                    (_dgrad_cache, (_pack_epoch, w._version, self.dtype, w.device, w.data_ptr(), flip), dg)):
                 hit = cache.get(id(w))
                 if hit is None or hit[0]() is not w:
                     weakref.finalize(w, cache.pop, id(w), None)
@@ -211,7 +239,7 @@ _halves_cache = {}
 
 def _packed_halves(weight, dtype):
     """The two input-channel halves [K, Cout, Cin / 2] of a packed conv weight, cached like `_packed`."""
-    key = (weight._version, dtype, weight.device, weight.data_ptr())
+    key = (_pack_epoch, weight._version, dtype, weight.device, weight.data_ptr())
     hit = _halves_cache.get(id(weight))
     if hit is not None and hit[0]() is weight and hit[1] == key:
         return hit[2]

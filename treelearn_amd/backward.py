@@ -105,7 +105,8 @@ def _wgrad_param(x, grad_out, ref, K, weight):
 
 def _dgrad_weight(weight, ref, dtype):
     """[K]["Cout" = Cin]["Cin" = Cout] weights of the input-gradient conv: W[k]^T, taps flipped for SubM."""
-    from .autograd import _packed_dgrad
+    from .autograd import _packed_dgrad, note_backward
+    note_backward()                       # when this backward pass ends, the packed copies of the weights expire (autograd._pack_epoch)
     return _packed_dgrad(weight, dtype, ref.flip)
 
 

@@ -202,8 +202,10 @@ class TreeLearn(nn.Module):
             x = spconv.SparseConvTensor(vfeats, lv.row_coords(), list(lv.shape), batch_size, geometry=geom, level=0)
             prev = spconv.SparseConvolution.amp_dtype
             spconv.SparseConvolution.amp_dtype = None if dtype == torch.float32 else dtype
+            if torch.is_grad_enabled():
+                _ag.new_pack_epoch()                                  # the packed copies of the last step are stale whether or not `_version` says so (fused optimizers)
             if torch.is_grad_enabled() and os.environ.get("TL_PACK_BATCH", "1") != "0":
-                self._refresh_packed(dtype)                           # every conv weight packed in one launch (once per optimizer step)
+                self._refresh_packed(dtype)                           # every conv weight packed in one launch (once per training forward)
             try:                                                       # 16-bit: mixed precision as under the reference's autocast
                 x = self.output_layer(self.unet(self.input_conv(x)))
             finally:
