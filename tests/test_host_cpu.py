@@ -341,3 +341,25 @@ def test_forward_arena_allocator_under_sanitizers(tmp_path):
                            "-I", os.path.join(root, "treelearn_amd", "csrc"), os.path.join(root, "tests", "tools", "arena_test.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "arena_test OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/treelearn_hip.h must compile as C99 (what cgo / JNI / a ctypes generator would feed it to) and as
+    C++11, pedantic, without warnings, and a C program must be able to link every declared entry point against the built library."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    hdr = open(os.path.join(inc, "treelearn_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(tl_[a-z0-9_]+)\s*\(", hdr)))
+    src = tmp_path / "use.c"
+    src.write_text('#include "treelearn_hip.h"\n#include <stdio.h>\nint main(void) {\n  tl_forward_args a; tl_net_desc d; tl_conv_args c; (void)a; (void)d; (void)c;\n'
+                   + "".join(f"  printf(\"%p\\n\", (void*)(size_t)&{n});\n" for n in names) + "  return 0;\n}\n")
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc] + (["-x", "c++"] if cc == "g++" else []) +
+                           ["-fsyntax-only", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    import __graft_entry__
+    __graft_entry__.build()
+    lib = os.path.join(root, "treelearn_amd", "lib")
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-L", lib, "-ltreelearn_hip", "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-o", str(tmp_path / "use")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr                      # every declared function resolves against libtreelearn_hip.so
