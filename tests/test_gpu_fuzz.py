@@ -109,3 +109,45 @@ def test_random_batch_of_three_unequal_clouds():
                      batch["batch_ids"].numpy(), 3, voxel_size=0.1, num_blocks=7, spatial_shape=[500, 500, 1000])
     for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
         assert rel_err(a[k].cpu().numpy(), ref[k].numpy()) < REL_TOL, k
+
+
+@pytest.mark.parametrize("kind,n", [("blobs", 9000), ("slab", 3000), ("dupes", 5000)])
+def test_random_cloud_training_step_gradients(kind, n):
+    """One training-mode step (batch-statistics BatchNorm, loss, backward) on two random clouds with random labels and masks: the loss and
+    EVERY parameter's gradient against float64 autograd through the oracle, kink-pinned (the ReLU branches the HIP forward took are handed
+    to the float64 run, oracle.model.train_step_grads(relu_masks=...)).  Reference: tools/training/train.py:30-44."""
+    from treelearn_amd import autograd as ag
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import random_state_dict
+    rng = np.random.default_rng(500 + n)
+    clouds = [_cloud(rng, kind, n), _cloud(rng, "blobs", n // 3)]
+    batch = _batch(clouds)
+    N = batch["coords"].shape[0]
+    batch.update(semantic_labels=torch.from_numpy(rng.integers(0, 2, N)).long(), offset_labels=torch.from_numpy(rng.normal(0, 1, (N, 3)).astype(np.float32)),
+                 masks_sem=torch.from_numpy(rng.random(N) < 0.8), masks_off=torch.from_numpy(rng.random(N) < 0.4))
+    cfg = dict(channels=16, num_blocks=5)
+    sd = random_state_dict(11, **cfg)
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[512, 512, 512], voxel_size=0.1, **cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    ag.RELU_MASK_SINK = {}
+    try:
+        loss, _ = model(batch, return_loss=True)
+        sink = ag.RELU_MASK_SINK
+    finally:
+        ag.RELU_MASK_SINK = None
+    loss.backward()
+    mod_name = {m: k for k, m in model.named_modules()}
+    masks = {mod_name[m]: v.cpu() for m, v in sink.items()}
+    loss64, g64 = om.train_step_grads(sd, batch, 0.1, cfg["num_blocks"], [512, 512, 512], relu_masks=masks)
+    assert float(loss.detach()) == pytest.approx(loss64, rel=1e-4)
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    worst = (0.0, None)
+    for name, p in model.named_parameters():
+        b = g64[name].numpy().astype(np.float64)
+        if np.abs(b).max() <= 1e-9 * gmax:
+            continue
+        e = rel_err(p.grad.cpu().numpy().astype(np.float64), b)
+        worst = max(worst, (e, name))
+        assert e < 2e-4, (kind, name, e)
+    print(kind, "worst gradient tensor vs float64:", worst)
