@@ -336,3 +336,29 @@ def test_layer_used_directly_sees_an_update_that_leaves_the_version_alone():
     assert conv.weight._version == v
     y1 = run()
     assert torch.allclose(y1, 2.0 * y0, rtol=1e-5, atol=1e-6), float((y1 - 2.0 * y0).abs().max())
+
+
+def test_eval_plan_is_dropped_by_a_training_forward_in_eval_mode():
+    """Fine-tuning with the model kept in .eval() (frozen BatchNorm statistics) never calls train(), which is what normally drops the folded /
+    packed eval plan: a grad-enabled forward must drop it too, or the next no_grad forward answers with the weights from before the step."""
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    cfg = dict(channels=32, num_blocks=4)
+    batch = make_batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=1)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, **cfg)
+    model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+    model = model.cuda().eval()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    with torch.no_grad():
+        before = model(gb, return_loss=False)["semantic_prediction_logits"].clone()
+    assert model._plan is not None
+    loss, _ = model(gb, return_loss=True)                       # eval mode, grad enabled: the module-by-module path with running statistics
+    loss.backward(); opt.step()
+    with torch.no_grad():
+        after = model(gb, return_loss=False)["semantic_prediction_logits"]
+        fresh = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, **cfg)
+        fresh.load_state_dict(model.state_dict(), strict=True)
+        ref = fresh.cuda().eval()(gb, return_loss=False)["semantic_prediction_logits"]
+    assert not torch.equal(before, after)
+    assert torch.equal(after, ref)                              # the answer of a plan built from the updated weights

@@ -204,6 +204,8 @@ class TreeLearn(nn.Module):
             spconv.SparseConvolution.amp_dtype = None if dtype == torch.float32 else dtype
             if torch.is_grad_enabled():
                 _ag.new_pack_epoch()                                  # the packed copies of the last step are stale whether or not `_version` says so (fused optimizers)
+                self._plan = None                                     # ... and so is an eval plan once this step's optimizer has run (a model kept in .eval()
+                                                                      # while it is fine-tuned never passes through train(), which drops the plan otherwise)
             if torch.is_grad_enabled() and os.environ.get("TL_PACK_BATCH", "1") != "0":
                 self._refresh_packed(dtype)                           # every conv weight packed in one launch (once per training forward)
             try:                                                       # 16-bit: mixed precision as under the reference's autocast
