@@ -362,3 +362,58 @@ def test_eval_plan_is_dropped_by_a_training_forward_in_eval_mode():
         ref = fresh.cuda().eval()(gb, return_loss=False)["semantic_prediction_logits"]
     assert not torch.equal(before, after)
     assert torch.equal(after, ref)                              # the answer of a plan built from the updated weights
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fixed_modules_fine_tuning_step(dtype):
+    """The reference's `fixed_modules` (tree_learn.py:66-72, train() override :105-112): the named modules get no gradients and their
+    BatchNorms stay in eval mode while the rest trains.  One training step with input_conv / unet / output_layer fixed: their parameters and
+    running statistics are untouched, and the heads' loss and gradients equal a plain-torch float64 computation on the backbone features
+    the eval forward gives (the fixed backbone IS the eval backbone)."""
+    import copy
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    from treelearn_amd.util.train import point_wise_loss_impl
+    cfg = dict(channels=32, num_blocks=4)
+    fixed = ['input_conv', 'unet', 'output_layer']
+    batch = make_batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.10, seed=s) for s in (1, 2)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[256, 256, 512], voxel_size=0.1, fixed_modules=fixed, compute_dtype=dtype, **cfg)
+    model.load_state_dict(random_state_dict(5, **cfg), strict=True)
+    model = model.cuda()
+    model.eval()
+    with torch.no_grad():
+        feats = model(gb, return_loss=False)["backbone_feats"].double()          # eval backbone (running statistics everywhere)
+    model.train()
+    for name in fixed:
+        assert all(not m.training for m in getattr(model, name).modules() if isinstance(m, torch.nn.BatchNorm1d))
+    assert all(m.training for m in model.semantic_linear.modules() if isinstance(m, torch.nn.BatchNorm1d))
+    stats0 = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    heads = {n: copy.deepcopy(torch.nn.Sequential(*[m for m in getattr(model, n)])).double() for n in ("semantic_linear", "offset_linear")}
+    model.zero_grad()
+    loss, _ = model(gb, return_loss=True)
+    loss.backward()
+    for name, p in model.named_parameters():
+        if name.split(".")[0] in fixed:
+            assert p.grad is None, name
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    for k, v in model.state_dict().items():
+        if k in stats0:
+            same = torch.equal(v, stats0[k])
+            assert same == (k.split(".")[0] in fixed), k                             # fixed: untouched; heads: updated
+    # plain torch, float64, on the eval backbone's features
+    logits = heads["semantic_linear"](feats); offs = heads["offset_linear"](feats)
+    sem, off = point_wise_loss_impl(logits, offs, gb["masks_sem"], gb["masks_off"], gb["semantic_labels"], gb["offset_labels"].double())
+    from treelearn_amd.model.net import LOSS_MULTIPLIER_SEMANTIC
+    ref_loss = sem * LOSS_MULTIPLIER_SEMANTIC + off
+    ref_loss.backward()
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    assert float(loss.detach()) == pytest.approx(float(ref_loss.detach()), rel=tol)
+    for n in ("semantic_linear", "offset_linear"):
+        for (pn, p), (_, q) in zip(getattr(model, n).named_parameters(), heads[n].named_parameters()):
+            b = q.grad
+            if float(b.abs().max()) < 1e-9:
+                continue                                                             # a Linear bias in front of a BatchNorm: zero gradient
+            e = float((p.grad.double() - b).abs().max() / b.abs().max())
+            assert e < tol, (n, pn, e)
