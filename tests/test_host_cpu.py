@@ -363,3 +363,42 @@ def test_public_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-L", lib, "-ltreelearn_hip", "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-o", str(tmp_path / "use")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr                      # every declared function resolves against libtreelearn_hip.so
+
+
+def test_load_checkpoint_handles_mismatched_missing_and_unexpected_keys(tmp_path):
+    """reference tree_learn/util/train.py:65-102: a `.pth` of {'net', 'optimizer', 'epoch'}; keys whose size differs from the model's are
+    dropped (pretraining with another input width), missing / unexpected keys are reported, the optimizer state is restored, the return
+    value is epoch + 1 (1 when the file has no epoch); a DataParallel-style wrapper (`.module`) is looked through."""
+    import logging
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import random_state_dict
+    from treelearn_amd.util.train import load_checkpoint
+    cfg = dict(channels=16, num_blocks=3)
+    sd = random_state_dict(3, **cfg)
+    src = {k: v.clone() for k, v in sd.items()}
+    src["input_conv.0.weight"] = torch.zeros(16, 3, 3, 3, 7)                   # another input width: must be skipped, not raise
+    del src["semantic_linear.3.bias"]                                           # missing in the file
+    src["some.other.key"] = torch.zeros(1)                                      # unexpected in the file
+    model = TreeLearn(use_feats=False, use_coords=False, spatial_shape=[64, 64, 64], voxel_size=0.1, **cfg)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    keep = model.state_dict()["input_conv.0.weight"].clone(); keep_bias = model.state_dict()["semantic_linear.3.bias"].clone()
+    f = str(tmp_path / "epoch_7.pth")
+    torch.save(dict(net=src, optimizer=opt.state_dict(), epoch=7), f)
+    msgs = []
+    log = logging.getLogger("tl_test_ckpt"); log.setLevel(logging.INFO)
+    h = logging.Handler(); h.emit = lambda r: msgs.append(r.getMessage()); log.addHandler(h)
+    opt2 = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    class Wrapped:                                                              # DataParallel-like
+        module = model
+    assert load_checkpoint(f, log, Wrapped(), optimizer=opt2, strict=False) == 8
+    new = model.state_dict()
+    assert torch.equal(new["input_conv.0.weight"], keep) and torch.equal(new["semantic_linear.3.bias"], keep_bias)
+    assert torch.equal(new["unet.blocks.block0.conv_branch.2.weight"], sd["unet.blocks.block0.conv_branch.2.weight"])
+    text = "\n".join(msgs)
+    assert "size mismatch: input_conv.0.weight" in text and "missing keys in source state_dict: input_conv.0.weight, semantic_linear.3.bias" in text and "unexpected key in source state_dict: some.other.key" in text
+    assert len(opt2.state_dict()["state"]) == len(opt.state_dict()["state"]) > 0
+    torch.save(dict(net=sd), f)
+    assert load_checkpoint(f, None, model) == 1 and model._plan is None
