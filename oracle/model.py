@@ -148,7 +148,7 @@ def get_loss(model_output, semantic_labels, offset_labels, masks_off, masks_sem)
 from treelearn_amd.synth import random_state_dict, state_dict_manifest  # noqa: E402,F401
 
 
-def train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype=torch.float64, relu_masks=None):
+def train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype=torch.float64, relu_masks=None, use_coords=False, use_feats=False):
     """Loss and the gradient of every parameter for one training-mode forward (batch-statistics BatchNorm), by torch autograd
     through this restatement in `dtype` (float64: a round-off-free second opinion next to the reference-generated golden).
     Reference: the step body of tools/training/train.py:30-44 up to `.backward()`.  Returns (loss, {name: grad}).
@@ -158,17 +158,17 @@ def train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype=tor
     global RELU_MASKS
     RELU_MASKS = relu_masks
     try:
-        return _train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype)
+        return _train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype, use_coords, use_feats)
     finally:
         RELU_MASKS = None
 
 
-def _train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype):
+def _train_step_grads(sd, batch, voxel_size, num_blocks, spatial_shape, dtype, use_coords=False, use_feats=False):
     p = {k: (v.detach().to(dtype).requires_grad_(True) if (v.is_floating_point() and not k.endswith(("running_mean", "running_var")))
              else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
     T = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))                # noqa: E731
     vfeats, vcoords, v2p, sshape = voxel.voxelize(T(batch["coords"]).numpy(), T(batch["input_feats"]).numpy(), T(batch["batch_ids"]).numpy(),
-                                                  int(batch["batch_size"]), voxel_size, False, False, 3)
+                                                  int(batch["batch_size"]), voxel_size, use_coords, use_feats, 3)
     if spatial_shape is not None:
         sshape = np.asarray(spatial_shape, np.int64)
     levels = build_levels(vcoords, sshape, num_blocks)

@@ -151,3 +151,53 @@ def test_random_cloud_training_step_gradients(kind, n):
         worst = max(worst, (e, name))
         assert e < 2e-4, (kind, name, e)
     print(kind, "worst gradient tensor vs float64:", worst)
+
+
+@pytest.mark.parametrize("use_coords,use_feats", [(True, False), (False, True), (True, True)])
+def test_random_cloud_with_voxel_features(use_coords, use_feats):
+    """`use_coords` / `use_feats` (tree_learn.py:129-167: the voxel features are the mean of the first <= 3 points' coordinates / features
+    instead of ones): eval forward in fp32 and bf16x3 against the oracle, and one training step's gradients against float64, on a cloud with
+    many points per voxel and random point features."""
+    from treelearn_amd import autograd as ag
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import random_state_dict
+    rng = np.random.default_rng(900 + 2 * use_coords + use_feats)
+    batch = _batch([_cloud(rng, "dupes", 6000), _cloud(rng, "blobs", 2500)])
+    N = batch["coords"].shape[0]
+    batch["input_feats"] = torch.from_numpy(rng.normal(0, 1, (N, 1)).astype(np.float32))
+    batch.update(semantic_labels=torch.from_numpy(rng.integers(0, 2, N)).long(), offset_labels=torch.from_numpy(rng.normal(0, 1, (N, 3)).astype(np.float32)),
+                 masks_sem=torch.from_numpy(rng.random(N) < 0.7), masks_off=torch.from_numpy(rng.random(N) < 0.5))
+    cfg = dict(channels=16, num_blocks=4)
+    sd = random_state_dict(13, **cfg)
+    ref = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 2, voxel_size=0.1, num_blocks=4,
+                     use_coords=use_coords, use_feats=use_feats, spatial_shape=[512, 512, 512])
+    for dtype in (torch.float32, "bf16x3"):
+        m = TreeLearn(use_feats=use_feats, use_coords=use_coords, spatial_shape=[512, 512, 512], voxel_size=0.1, compute_dtype=dtype, **cfg)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            out = m(batch, return_loss=False)
+        for k in ("backbone_feats", "semantic_prediction_logits", "offset_predictions"):
+            e = rel_err(out[k].cpu().numpy(), ref[k].numpy())
+            assert e < REL_TOL, (dtype, k, e)
+    m = TreeLearn(use_feats=use_feats, use_coords=use_coords, spatial_shape=[512, 512, 512], voxel_size=0.1, **cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    ag.RELU_MASK_SINK = {}
+    try:
+        loss, _ = m(batch, return_loss=True)
+        sink = ag.RELU_MASK_SINK
+    finally:
+        ag.RELU_MASK_SINK = None
+    loss.backward()
+    mod_name = {mod: k for k, mod in m.named_modules()}
+    masks = {mod_name[mod]: v.cpu() for mod, v in sink.items()}
+    loss64, g64 = om.train_step_grads(sd, batch, 0.1, 4, [512, 512, 512], relu_masks=masks, use_coords=use_coords, use_feats=use_feats)
+    assert float(loss.detach()) == pytest.approx(loss64, rel=1e-4)
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    for name, p in m.named_parameters():
+        b = g64[name].numpy().astype(np.float64)
+        if np.abs(b).max() <= 1e-9 * gmax:
+            continue
+        e = rel_err(p.grad.cpu().numpy().astype(np.float64), b)
+        assert e < 2e-4, (name, e)
