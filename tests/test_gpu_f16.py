@@ -220,3 +220,51 @@ def test_f16_training_step_close_to_fp32_step():
         assert all(bool(torch.isfinite(v).all()) for v in g.values()), dt
     print("worst gradient cosine vs the fp32 step:", {str(k): round(v, 5) for k, v in res.items()})
     assert res[torch.float16] >= 0.98 and res[torch.float16] >= res[torch.bfloat16] - 5e-3
+
+
+def test_16bit_training_step_with_voxel_features_on_the_block_local_level():
+    """Mixed-precision training keeps level 1 in the block-local row order; with `use_coords` / `use_feats` the voxel-mean features come back
+    in that order too and the input conv is a real 4 -> 32 conv (not the ones table).  One step in float16 and bf16 against the fp32 step
+    (canonical order) of the same model on a tile large enough for the block-local path."""
+    import torch
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    b = make_batch([make_tile(extent=14.0, voxel=0.1, n_trees=8, fill=0.10, seed=s) for s in (3, 4)])
+    g = torch.Generator().manual_seed(0)
+    b["input_feats"] = torch.randn(b["coords"].shape[0], 1, generator=g)
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+    def step(dt, vf=True):
+        m = TreeLearn(use_feats=vf, use_coords=vf, spatial_shape=[500, 500, 1000], voxel_size=0.1)
+        m.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
+        m = m.cuda().train()
+        if dt is None:
+            loss, _ = m(gb, return_loss=True)
+        else:
+            with torch.autocast("cuda", dtype=dt):
+                loss, _ = m(gb, return_loss=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().double().flatten() for n, p in m.named_parameters() if p.grad is not None}, m
+
+    l32, g32, _ = step(None)
+    for dt in (torch.float16, torch.bfloat16):
+        from treelearn_amd import autograd as ag
+        ag.RELU_MASK_SINK = {}                                  # (switches the `_last_geom` test hook on)
+        try:
+            l, gr, m = step(dt)
+        finally:
+            ag.RELU_MASK_SINK = None
+        assert m._last_geom.blocked, "the tile is large enough for the block-local level-1 path"
+        assert abs(l - l32) <= 3e-2 * abs(l32), (dt, l, l32)
+        nmax = max(float(v.norm()) for v in g32.values())
+        cos = lambda a, b_: min((float((a[k] * b_[k]).sum() / (a[k].norm() * b_[k].norm())), k) for k in b_ if float(b_[k].norm()) > 1e-3 * nmax)   # noqa: E731
+        worst = cos(gr, g32)
+        # the yardstick: the same step of the same net on all-ones voxel features (the reference's default), against ITS fp32 step
+        if dt == torch.float16:
+            l32o, g32o, _ = step(None, False)
+        lo, go, _ = step(dt, False)
+        nmax_o = max(float(v.norm()) for v in g32o.values())
+        base = min((float((go[k] * g32o[k]).sum() / (go[k].norm() * g32o[k].norm())), k) for k in g32o if float(g32o[k].norm()) > 1e-3 * nmax_o)
+        print(dt, "loss", l, "fp32", l32, "worst gradient cosine", worst, "| all-ones features:", base)
+        assert worst[0] >= base[0] - 0.05, (dt, worst, base)
