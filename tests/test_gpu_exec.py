@@ -174,3 +174,37 @@ def test_exec_config2_full_tile():
     out_c, out_p, ex = _both(m, gb)
     _assert_equal(out_c, out_p)
     assert ex.last["blocked"] and ex.last["level_n"][0] > 1_800_000
+
+
+def test_model_with_a_live_executor_can_be_copied_and_pickled():
+    """copy.deepcopy / pickle / torch.save of a model that has run (eval plan, C-side executor handles, arenas): the copy carries the
+    parameters only and rebuilds its own plan -- same outputs, and neither object's destruction touches the other's handles."""
+    import copy, gc, io, pickle
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=2)])
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        ref = m(gb, return_loss=False)
+    assert m._plan is not None and m._plan._exec is not None and m._plan._exec._ctx
+    c = copy.deepcopy(m)
+    assert c._plan is None and c.training == m.training
+    r = pickle.loads(pickle.dumps(m))
+    buf = io.BytesIO(); torch.save(m, buf); buf.seek(0)
+    t = torch.load(buf, weights_only=False)
+    with torch.no_grad():
+        for other in (c, r.cuda(), t.cuda()):
+            out = other(gb, return_loss=False)
+            _assert_equal(out, ref)
+    assert c._plan is not m._plan and c._plan._exec is not m._plan._exec
+    del m, r, t
+    gc.collect(); torch.cuda.synchronize()
+    with torch.no_grad():
+        _assert_equal(c(gb, return_loss=False), ref)             # the copy lives on after the original (and its executor) are gone
+    with torch.enable_grad():                                    # a training model with a pack plan copies too
+        c.train()
+        loss, _ = c(gb, return_loss=True)
+        loss.backward()
+        d = copy.deepcopy(c)
+        assert getattr(d, "_pack_plan", None) is None
+        loss2, _ = d(gb, return_loss=True)
+    assert float(loss2.detach()) == float(loss.detach())

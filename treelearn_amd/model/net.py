@@ -22,6 +22,10 @@ from .unet import MLP, ResidualBlock, UBlock
 LOSS_MULTIPLIER_SEMANTIC = 50          # tree_learn.py:9
 
 
+def _drop_plan_after_load(module, incompatible):
+    module.invalidate_plan()                       # (a module-level function, not a lambda: the model stays picklable)
+
+
 class TreeLearn(nn.Module):
     def __init__(self, channels=32, num_blocks=7, kernel_size=3, dim_coord=3, dim_feat=1, fixed_modules=[],
                  use_feats=True, use_coords=False, spatial_shape=None, max_num_points_per_voxel=3, voxel_size=0.1,
@@ -53,7 +57,7 @@ class TreeLearn(nn.Module):
         for name in fixed_modules:
             for param in getattr(self, name).parameters():
                 param.requires_grad = False
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plan())
+        self.register_load_state_dict_post_hook(_drop_plan_after_load)
 
     def init_weights(self):
         for m in self.modules():
@@ -88,6 +92,27 @@ class TreeLearn(nn.Module):
             plan = self._pack_plan = PackPlan(convs, dtype) if convs else None
         if plan is not None:
             plan.refresh()
+
+    # Derived state (the eval plan with its packed weights, C-side executor handles and arenas; the training pack plan; side streams) belongs
+    # to THIS object and to the device memory it was built on: a copy or a pickle of the model carries the parameters only and rebuilds the rest
+    # on its first forward.  (Copying it would hand one `tl_exec*` to two owners and leave the copy's descriptors pointing at the original's
+    # tensors; pickling it fails on the ctypes pointers.)
+    _DERIVED = ("_plan", "_pack_plan", "_geom_stream", "_conv_modules", "_last_geom")
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in self._DERIVED:
+            if k in st:
+                st[k] = None
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in self._DERIVED else copy.deepcopy(v, memo)
+        return new
 
     def invalidate_plan(self):
         """Drop the folded-BN / packed-weight cache (call after mutating parameters in place)."""
