@@ -38,7 +38,8 @@ def _cloud(rng, kind, n):
     return p.astype(np.float32)
 
 
-CASES = [("slab", 4000), ("column", 1500), ("blobs", 20000), ("far", 6000), ("dupes", 9000), ("lattice", 5000), ("sparse", 3000), ("blobs", 300)]
+CASES = [("slab", 4000), ("column", 1500), ("blobs", 20000), ("far", 6000), ("dupes", 9000), ("lattice", 5000), ("sparse", 3000), ("blobs", 300),
+         ("dupes", 1), ("lattice", 2), ("sparse", 17)]                     # one point; two points; a handful of isolated voxels
 
 
 def _model(dtype, seed=7):

@@ -201,6 +201,7 @@ class InferencePlan:
         """`x3` (fp32 only): the "bf16x3" parity-fast mode -- fp32 storage and epilogues, every conv weight also packed in its split-bf16 form
         so that the kernels of the large levels contract hi / lo bf16 parts on the bf16 matrix cores (tl_conv_args.weight_x3)."""
         self.dtype = dtype
+        self.device = model.input_conv[0].weight.device            # a plan belongs to one device (net._plan_ok: a replica on another device builds its own)
         self.x3 = bool(x3) and dtype == torch.float32
         self.preact = os.environ.get("TL_ENGINE", "preact") != "prologue"
         prev, ops.PACK_X3 = ops.PACK_X3, self.x3

@@ -68,7 +68,8 @@ class TreeLearn(nn.Module):
                 m.init_weights()
 
     def _plan_ok(self, dtype):
-        return self._plan is not None and self._plan.dtype == dtype and self._plan.x3 == (self.split_bf16 and dtype == torch.float32)
+        return (self._plan is not None and self._plan.dtype == dtype and self._plan.x3 == (self.split_bf16 and dtype == torch.float32)
+                and getattr(self._plan, "device", None) == self.input_conv[0].weight.device)
 
     def ensure_plan(self):
         """Build the fused inference plan (folded BatchNorms, packed weights) now, on the current stream.  Callers that spread
