@@ -409,7 +409,7 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()                                     # device_count() does not create a HIP context
-    if have < n:
+    if have < n and os.environ.get("TL_BENCH_SHARE_GPU") != "1":
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node; one GPU per rank is required "
               f"(ranks never share a device).  Run with --gpus {max(have, 1)} or on a node with {n} GPUs.", file=sys.stderr)
         return 2
@@ -459,13 +459,23 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.set_num_threads(max(1, host_cores() // int(os.environ.get("LOCAL_WORLD_SIZE", world))))     # ranks share the host-core quota
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # TEST switches (tests/test_gpu_configs.py): TL_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and TL_BENCH_BACKEND=gloo replaces RCCL (which
+    # refuses two ranks on one device), so that a 1-GPU box can run the whole N > 1 flow of this file -- barriers, max-over-ranks timing, the
+    # sharded plot's collectives, rank 0's line.  Numbers from such a run mean nothing and say so (`config.test_mode`).
+    share = os.environ.get("TL_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("TL_BENCH_BACKEND", "nccl")
+    if share:
+        local = 0
     if torch.cuda.device_count() <= local:                               # counting devices does not initialise the GPU
         sys.exit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible (one GPU per rank, no sharing)")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("TL_BENCH_FORCE_DIST") == "1":          # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from treelearn_amd import ops
     from treelearn_amd.model import TreeLearn
@@ -616,6 +626,9 @@ def main():
                                         f"{n_pts} points/tile, 7-level 32-ch sparse U-Net fwd (30.1 M params, random init), 1 tile per GPU",
                                points_per_tile=n_pts, tiles_per_step=world, tiles_in_flight=nfl),
                    roofline=roof)
+        if share or backend != "nccl":
+            res["config"]["test_mode"] = f"ranks share GPU 0 / backend {backend}: a plumbing test of the N > 1 flow, not a measurement"
+
         if nfl > 1:                                                    # the same forward strictly one tile after the other, for reference
             with torch.no_grad():
                 for _ in range(2): step()

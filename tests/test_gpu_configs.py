@@ -747,3 +747,30 @@ def test_bench_prints_one_json_line_last(flags):
     assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
     if env.get("TL_BENCH_FORCE_DIST") == "1":
         assert d["sharded_plot"]["value"] > 0 and d["sharded_plot"]["collectives_per_plot"] == 2
+
+
+def test_bench_two_ranks_flow_on_one_gpu():
+    """The N > 1 flow of bench.py -- launcher environment, one process per rank, barrier + max-over-ranks timing, the sharded plot's two
+    collectives across ranks, rank 0 alone printing the ONE JSON line -- on a 1-GPU box: two ranks share GPU 0 over gloo (RCCL refuses two
+    ranks on one device; TL_BENCH_SHARE_GPU / TL_BENCH_BACKEND are test switches and the line says so).  What an 8-GPU node changes is the
+    backend and the device index, nothing else in this file."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TL_BENCH_SHARE_GPU="1", TL_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-fp32-mode", "--no-power-probe"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["tiles_per_step"] == 2
+    assert d["rccl_world"] == 2 and "test_mode" in d["config"]
+    sp = d["sharded_plot"]
+    assert sp["tiles"] == 16 and sp["collectives_per_plot"] == 2 and sp["gathered_rows"] > 0 and sp["value"] > 0
+    # the spawning form (no launcher): `python bench.py --gpus 2` starts its own two ranks and relays rank 0's line
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp32-mode",
+                         "--no-power-probe", "--no-sharded-plot"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-3000:]
+    last = r2.stdout.strip().splitlines()[-1]
+    assert json.loads(last)["n_gpus"] == 2
