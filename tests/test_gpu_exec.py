@@ -208,3 +208,40 @@ def test_model_with_a_live_executor_can_be_copied_and_pickled():
         assert getattr(d, "_pack_plan", None) is None
         loss2, _ = d(gb, return_loss=True)
     assert float(loss2.detach()) == float(loss.detach())
+
+
+def test_exec_called_from_several_python_threads():
+    """Host threads: ctypes releases the GIL inside tl_forward, so two Python threads may be inside it at once.  Forwards on the SAME stream share
+    one context (read-back buffer, arena) and are serialised by its lock; forwards on different streams have their own.  Every result equals
+    the single-threaded one."""
+    import threading
+    from treelearn_amd.synth import make_tile
+    tiles = [_batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=s)]) for s in (11, 12, 13)]
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        refs = [m(t, return_loss=False) for t in tiles]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k, stream):
+        try:
+            with torch.no_grad():
+                for it in range(6):
+                    i = (k + it) % len(tiles)
+                    with torch.cuda.stream(stream):
+                        out = m(tiles[i], return_loss=False)
+                    stream.synchronize()
+                    for key in ("semantic_prediction_logits", "offset_predictions", "backbone_feats"):
+                        if not torch.equal(out[key], refs[i][key]):
+                            errors.append((k, it, key))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    shared = torch.cuda.Stream()
+    for streams in ([shared, shared, shared], [torch.cuda.Stream() for _ in range(3)]):
+        for st in set(streams):
+            st.wait_stream(torch.cuda.current_stream())
+        th = [threading.Thread(target=worker, args=(k, streams[k])) for k in range(3)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not errors, errors[:5]

@@ -10,6 +10,7 @@ features) on the pre-activated engine with every developer switch at its default
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -90,8 +91,8 @@ class Executor:
     def __del__(self):
         try:
             L = _hip.lib()
-            for ex, _ in self._ctx.values():
-                L.tl_exec_destroy(ex)
+            for c in self._ctx.values():
+                L.tl_exec_destroy(c[0])
         except Exception:                                        # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -107,14 +108,14 @@ class Executor:
             ex = _hip.lib().tl_exec_create()
             if not ex:
                 raise RuntimeError("tl_exec_create failed")
-            c = self._ctx[key] = [ex, None]
+            c = self._ctx[key] = [ex, None, threading.Lock()]          # handle, arena, and a lock: one forward at a time per (device, stream) context
         return c
 
     def profile(self, enable):
         """Live per-launch HIP-event timing of the following forwards (bench.py's roofline pass)."""
         self.profiling = bool(enable)
-        for ex, _ in self._ctx.values():
-            _hip.lib().tl_exec_profile(ex, int(self.profiling))
+        for c in self._ctx.values():
+            _hip.lib().tl_exec_profile(c[0], int(self.profiling))
 
     def profile_read(self, dev=None, stream=None):
         """Launch records of the last profiled forward on the current stream: list of dicts (level, kind, K, Cin, Cout, n_out, n_in, residual, esize,
@@ -162,15 +163,16 @@ class Executor:
         if use_side:
             from ..geometry import _side_stream
             a.side_stream = _side_stream(dev).cuda_stream
-        for attempt in range(4):
-            if ctx[1] is None:
-                ctx[1] = torch.empty(max(1 << 20, int(N * 1536)), dtype=torch.uint8, device=dev)      # first guess: ~1.5 KB per point
-            a.arena = ctx[1].data_ptr(); a.arena_bytes = ctx[1].numel()
-            rc = L.tl_forward(ctx[0], ctypes.byref(self.desc), ctypes.byref(a), stream.cuda_stream)
-            if rc != _hip.TL_ERR_ARENA:
-                break
-            ctx[1] = None                                          # grow: the exact figure when the level counts were known, a guess before that
-            ctx[1] = torch.empty(int(a.needed_bytes * 1.15) + (1 << 20), dtype=torch.uint8, device=dev)
+        with ctx[2]:                                                   # (ctypes releases the GIL: two Python threads on one stream would share read-back buffer and arena)
+            for attempt in range(4):
+                if ctx[1] is None:
+                    ctx[1] = torch.empty(max(1 << 20, int(N * 1536)), dtype=torch.uint8, device=dev)      # first guess: ~1.5 KB per point
+                a.arena = ctx[1].data_ptr(); a.arena_bytes = ctx[1].numel()
+                rc = L.tl_forward(ctx[0], ctypes.byref(self.desc), ctypes.byref(a), stream.cuda_stream)
+                if rc != _hip.TL_ERR_ARENA:
+                    break
+                ctx[1] = None                                          # grow: the exact figure when the level counts were known, a guess before that
+                ctx[1] = torch.empty(int(a.needed_bytes * 1.15) + (1 << 20), dtype=torch.uint8, device=dev)
         if rc == _hip.TL_ERR_REACH_ZERO:
             raise ValueError("sparse conv output spatial shape reach zero!!! (a level of the tile is empty or its spatial shape collapsed)")
         if rc == _hip.TL_ERR_EXTENT:
