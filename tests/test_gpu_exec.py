@@ -245,3 +245,25 @@ def test_exec_called_from_several_python_threads():
         for t in th: t.start()
         for t in th: t.join()
         assert not errors, errors[:5]
+
+
+def test_eval_forward_under_inference_mode(monkeypatch):
+    """`torch.inference_mode()` instead of `torch.no_grad()` around the evaluation call (tensors without version counters): both launch paths,
+    same outputs; and a plan built inside inference mode keeps serving calls outside it."""
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=5)])
+    m = _model(torch.bfloat16)
+    with torch.inference_mode():
+        a = m(gb, return_loss=False)                      # the plan (packed weights, folded BatchNorms) is built in here
+    with torch.no_grad():
+        b = m(gb, return_loss=False)
+    _assert_equal(a, b)
+    monkeypatch.setenv("TL_EXEC", "0")
+    m2 = _model(torch.bfloat16)
+    with torch.inference_mode():
+        c = m2(gb, return_loss=False)
+    _assert_equal(a, c)
+    m3 = _model(torch.float32)
+    with torch.inference_mode():
+        d = m3(gb, return_loss=False)
+    assert torch.isfinite(d["semantic_prediction_logits"]).all()
