@@ -267,3 +267,24 @@ def test_eval_forward_under_inference_mode(monkeypatch):
     with torch.inference_mode():
         d = m3(gb, return_loss=False)
     assert torch.isfinite(d["semantic_prediction_logits"]).all()
+
+
+def test_models_come_and_go_without_leaking_device_memory():
+    """Ten models in a row, each built, run (plan, executor, arenas) and dropped: the caching allocator's live bytes return to where they were
+    (the plan <-> executor link is a weak reference, `tl_exec_destroy` runs from the executor's finaliser)."""
+    import gc
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=6)])
+    gc.collect(); torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    seen = []
+    for i in range(10):
+        m = _model(torch.bfloat16, seed=20 + i)
+        with torch.no_grad():
+            m(gb, return_loss=False)
+        torch.cuda.synchronize()
+        del m
+        gc.collect()
+        seen.append(torch.cuda.memory_allocated() - base)
+    assert max(seen[2:]) <= seen[1] + (1 << 20), seen       # no growth from model to model
+    assert seen[-1] < (8 << 20), seen                        # and (almost) nothing left behind
