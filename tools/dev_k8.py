@@ -50,7 +50,8 @@ for li in range(4):
     cat = torch.empty(lv.n, 2 * ci, device="cuda", dtype=torch.bfloat16); act = torch.empty_like(cat)
     sc, sh = torch.rand(ci, device="cuda") + 0.5, torch.randn(ci, device="cuda")
     gb = (nx.n * co * 2 + lv.n * ci * 2 + lv.n * 4) / 1e9
-    for name, kw, two in (("default(up), 1 view", {}, False), ("default(up), 2 views", {}, True), ("up=0, 1 view", {"up": 0}, False), ("up=0 direct_oh=0, 1 view", {"up": 0, "direct_oh": 0}, False)):
+    upv = [("default(up), 1 view", {}, False), ("default(up), 2 views", {}, True), ("up=0, 1 view", {"up": 0}, False), ("up=0 direct_oh=0, 1 view", {"up": 0, "direct_oh": 0}, False)]
+    for name, kw, two in upv:
         tune(**kw)
         o2 = (act[:, ci:], sc, sh, True) if two else None
         f = lambda: ops.conv_fwd(x, w, lv.inv, lv.n, out=cat[:, ci:], out2=o2, one_hot=True, scatter=lv.child)

@@ -126,6 +126,8 @@ int tl_launch_conv_up(const ConvP& p, const int32_t* child, hipStream_t s) {
   auto big = [&](int64_t rows, int64_t ld) { return (rows - 1) * ld * 2 + 512 >= 0x7FFFFFFFll; };
   if (big(p.n_in, p.in_ld) || big(p.n_out, p.out_ld) || (p.out2 && big(p.n_out, p.out2_ld)) || (p.out3 && big(p.n_out, p.out3_ld)) || (int64_t)8 * p.n_in * 4 >= 0x7FFFFFFFll)
     return TL_ERR_UNSUPPORTED;
-  if (p.Cin == 96 && p.Cout == 64) return launch_up<3, 2, 8>(p, child, s);      // 96 KB of weights resident
+  // 96 KB of weights resident; twelve waves (three per SIMD) beside them: 0.055-0.059 / 0.104 ms (one / two views) with 8 waves, 0.050 / 0.100 with
+  // 12; 10 and 13 waves -- an uneven load on the four SIMDs -- are slower than 8 (0.060 / 0.121, 0.066 / 0.127)
+  if (p.Cin == 96 && p.Cout == 64) return launch_up<3, 2, 12>(p, child, s);
   return TL_ERR_UNSUPPORTED;
 }
