@@ -38,6 +38,7 @@ for li in range(4):
     variants = [("default, 2 views", {}, True), ("default, 1 view", {}, False), ("direct=0, 2 views", {"direct": 0}, True),
                 ("direct=0 streamq=0, 2 views", {"direct": 0, "streamq": 0}, True)]
     variants.append(("one row block per wave, 2 views", {"stream_rb": 1}, True))
+    variants.append(("streamq=0, two row blocks, 2 views", {"direct": 0, "streamq": 0, "stream_rb": 2}, True))
     for name, kw, two in variants:
         tune(**kw)
         f = (lambda: ops.conv_fwd(x, w, lv.child, nx.n, out=out, out2=(out2, sc, sh, True))) if two else (lambda: ops.conv_fwd(x, w, lv.child, nx.n, out=out))
