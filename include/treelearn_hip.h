@@ -95,6 +95,11 @@ int tl_point_rank(const int32_t* pcoords, int64_t N, const uint64_t* bitmap, con
  * in (x,y,z,feat..) order; ws i32[M*P] scratch. */
 int tl_voxel_mean_feats(const float* pf, int C, const int64_t* v2p, int64_t N, int64_t M, int P,
                         int32_t* ws, float* out, tl_stream_t stream);
+/* The same means straight into the input conv's operand (tree_learn.py:149-156 in one launch sequence): columns (x, y, z) from
+ * xyz f32[N,3] and f_0..f_{F-1} from feats f32[N,F] (F <= 5), column groups switched off by use_coords / use_feats = 0 set to 1,
+ * output rows in the reference's (feat.., x, y, z) order, cast to `dtype` (round to nearest even): out [M, 3 + F]; ws i32[M*P]. */
+int tl_voxel_feats(const float* xyz, const float* feats, int F, const int64_t* v2p, int64_t N, int64_t M, int P, int use_coords,
+                   int use_feats, int dtype, int32_t* ws, void* out, tl_stream_t stream);
 
 /* ------------------------------------------------------------------ rulebooks
  * Replaces spconv's indice generation for SubMConv3d(k=3,pad=1) (`subm{l}`, tree_learn.py:37-39,
@@ -500,8 +505,9 @@ int tl_knn_vote_grid(const float* ref_sorted_xyz, const int64_t* ref_sorted_labe
 /* ------------------------------------------------------------------ the whole eval-mode forward behind ONE call
  * Replaces, per batch of tiles, the body of `model(batch, return_loss=False)` of the reference's tile loop
  * (tree_learn/util/pipeline.py:86 -> tree_learn/model/tree_learn.py:75-103: voxelize :129-167, input conv :90, UBlock recursion
- * blocks.py:137-149, output_layer :93, forward_head :97-103) in the reference's DEFAULT configuration (use_feats = use_coords =
- * False: all-ones voxel features, configs/_modular/model.yaml:5-6).  tl_forward enqueues everything the per-operator entry points
+ * blocks.py:137-149, output_layer :93, forward_head :97-103): the yaml's configuration (use_feats = use_coords = False: all-ones
+ * voxel features, configs/_modular/model.yaml:5-6) and the constructor's own defaults (use_feats = True, tree_learn.py:18: voxel-mean
+ * features, tl_voxel_feats).  tl_forward enqueues everything the per-operator entry points
  * above would be called for -- tl_voxel_point_coords, tl_pyramid_build, tl_blk_build, tl_rulebooks_build, every tl_conv_fwd of the
  * U-Net in the pre-activated dataflow (BatchNorm + ReLU folded into producer epilogues / the staging prologue, residual adds and the
  * skip concat as views) and tl_head_mlp -- from C, so that the host cost of a forward no longer depends on the caller's interpreter.
@@ -515,7 +521,9 @@ int tl_knn_vote_grid(const float* ref_sorted_xyz, const int64_t* ref_sorted_labe
 #define TL_MAX_LEVELS 8
 #define TL_ERR_ARENA (-4)        /* arena too small: args->needed_bytes */
 #define TL_ERR_REACH_ZERO (-5)   /* a level's spatial shape or voxel set collapsed (spconv's "reach zero!!!", util/pipeline.py:91-97) */
-#define TL_ERR_BLK (-7)          /* the block-local unit builder of the PREVIOUS tl_forward on this context flagged skipped units (an internal assertion) */
+#define TL_ERR_BLK (-7)          /* the block-local unit builder flagged skipped units (an internal assertion: cannot happen with the capacities tl_forward
+                                    passes).  The flag comes home BEHIND the forward that raised it: tl_exec_check reports it for the forwards enqueued so
+                                    far; a tl_forward that finds it set by its predecessor on the context returns it before enqueuing anything */
 #define TL_ERR_EXTENT (-6)       /* the tile's voxel extent exceeds spatial_shape, a batch id is out of range, or a voxel coordinate leaves [0, 65536) */
 typedef struct tl_affine { const float* scale; const float* shift; } tl_affine;
 typedef struct tl_weight { const void* w; const void* frag; int32_t K, Cout, Cin, reserved; const void* x3; /* tl_pack_weight_x3 copy or NULL */ } tl_weight;
@@ -538,7 +546,10 @@ typedef struct tl_net_desc {
   float voxel_size;
   int32_t has_shape; int32_t spatial_shape[3];   /* tree_learn.py:86-87 override; has_shape = 0: the tile's own extent (:165) */
   int32_t blocked;                /* != 0: level 1 may run in the block-local order (16-bit, C = 32) */
-  int32_t in_channels;            /* dim_coord + dim_feat of the all-ones input (tree_learn.py:38) */
+  int32_t in_channels;            /* dim_coord + dim_feat of the input conv (tree_learn.py:38) */
+  int32_t use_coords, use_feats;  /* tree_learn.py:152-155: both 0 = all-ones voxel features (no gather in the input conv); else args->point_feats is read */
+  int32_t max_points_per_voxel;   /* tree_learn.py:22,141 (read when use_coords | use_feats) */
+  int32_t reserved0;
   tl_weight w_in;                 /* input conv, tree_learn.py:37-39 */
   tl_ublock_desc u[TL_MAX_LEVELS];
   tl_affine out_bn;               /* output_layer, tree_learn.py:42 */
@@ -552,6 +563,7 @@ typedef struct tl_launch_rec {    /* one conv launch of a profiled forward */
 } tl_launch_rec;
 typedef struct tl_forward_args {
   const float* xyz; const int64_t* batch_ids; int64_t N; int32_t B; int32_t reserved;
+  const float* point_feats;       /* f32[N, in_channels - 3] (batch['input_feats']); may be NULL when the net uses neither coordinates nor features */
   void* arena; int64_t arena_bytes;
   float* backbone;                /* f32[N, C] or NULL */
   float* logits; float* offsets;  /* f32[N, 2], f32[N, 3] */
@@ -565,6 +577,10 @@ typedef struct tl_exec tl_exec;   /* host-side context of a caller thread / stre
 tl_exec* tl_exec_create(void);
 void tl_exec_destroy(tl_exec* ex);
 int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* args, tl_stream_t stream);
+/* Waits for the unit-builder flag of the LAST tl_forward enqueued on this context (a 4-byte read-back behind its geometry kernels, not
+ * behind its convs) and returns TL_ERR_BLK if that forward or an unreported earlier one raised it, else TL_OK.  Callers that need the
+ * verdict for a particular tile call it before the next tl_forward on the context; a tile loop calls it once after its last tile. */
+int tl_exec_check(tl_exec* ex);
 /* Live per-launch timing of the NEXT tl_forward calls on this context (HIP events on the launch stream around every conv launch;
  * enable = 0 stops).  tl_exec_profile_read waits for the last profiled forward and returns its launches (<= cap; return value = their
  * number, negative = error). */

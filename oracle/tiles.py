@@ -61,6 +61,33 @@ def offset_labels(xyz, instance_label, semantic_label):
     return position - xyz, valid
 
 
+def crop_tile(rows, inner_t, outer_t, n_feat, inner_square_edge_length):
+    """ONE tile of the loop of tile_generate_and_save (data_preparation.py:391-480) + TreeDataset.__getitem__ / collate_fn on it: `rows` =
+    float32 [N, 4 + F] (x, y, z, label, features) of the whole plot, `inner_t` / `outer_t` = float64 (xmin, xmax, ymin, ymax).  Returns the
+    batch dict (numpy) or None when the inner square holds no point (the reference drops such tiles, :412-427)."""
+    x, y = rows[:, 0], rows[:, 1]
+    o32 = np.asarray(outer_t).astype(np.float32)                          # torch compares against 0-dim float64 tensors in float32
+    chunk = rows[(x >= o32[0]) & (x <= o32[1]) & (y >= o32[2]) & (y <= o32[3])]
+    cx, cy = chunk[:, 0].astype(np.float64), chunk[:, 1].astype(np.float64)
+    if not ((cx >= inner_t[0]) & (cx < inner_t[1]) & (cy > inner_t[2]) & (cy <= inner_t[3])).any():
+        return None
+    i32 = np.asarray(inner_t).astype(np.float32)
+    c_x = np.round((i32[0] + i32[1]) / 2, 6); c_y = np.round((i32[2] + i32[3]) / 2, 6)      # float32 arithmetic
+    center_row = np.concatenate([np.array([c_x, c_y, 0, 0]), np.zeros(n_feat)]).reshape(1, -1)
+    chunk = (chunk.astype(np.float64) - center_row).astype(np.float32)
+    xyz = chunk[:, :3]; inst = chunk[:, 3].astype(np.int32); feat = chunk[:, 4:]
+    center = np.array([c_x, c_y, 0])                                  # what the npz holds (float64 of the float32 values)
+    sem = np.where(inst == NON_TREE_RAW, NON_TREE_DS, TREE_DS).astype(np.float64)
+    off, valid = offset_labels(xyz, inst, sem)
+    m_inner = np.linalg.norm(xyz[:, :-1], ord=np.inf, axis=1) <= inner_square_edge_length / 2
+    not_ignore = inst != IGNORE_RAW
+    return dict(coords=xyz, input_feats=feat, batch_ids=np.zeros(len(xyz), np.int64), semantic_labels=sem.astype(np.int64),
+                instance_labels=inst.astype(np.int64), masks_inner=m_inner,
+                masks_off=m_inner & not_ignore & (sem != NON_TREE_DS) & valid, masks_sem=m_inner & not_ignore,
+                offset_labels=off.astype(np.float32), batch_size=1,
+                centers=(np.ones_like(xyz) * center).astype(np.float32))
+
+
 def plot_tiles(points, labels, feats, inner_edge, outer_edge, stride, inner_square_edge_length):
     """points f32[N,3], labels f32[N], feats f32[N,F] -> list of batch dicts (numpy), one per kept tile, in the
     reference's tile order (the index i of `<plot>_<i>.npz`)."""
@@ -68,27 +95,9 @@ def plot_tiles(points, labels, feats, inner_edge, outer_edge, stride, inner_squa
     x_range = (points[:, 0].min(), points[:, 0].max()); y_range = (points[:, 1].min(), points[:, 1].max())
     inner, outer = tile_grid(x_range, y_range, inner_edge, outer_edge, stride)
     rows = np.hstack([points, labels[:, None], feats])                    # float32 [N, 4 + F]
-    x, y = rows[:, 0], rows[:, 1]
     out = []
     for t in range(len(inner)):
-        o32 = outer[t].astype(np.float32)                                 # torch compares against 0-dim float64 tensors in float32
-        chunk = rows[(x >= o32[0]) & (x <= o32[1]) & (y >= o32[2]) & (y <= o32[3])]
-        cx, cy = chunk[:, 0].astype(np.float64), chunk[:, 1].astype(np.float64)
-        if not ((cx >= inner[t][0]) & (cx < inner[t][1]) & (cy > inner[t][2]) & (cy <= inner[t][3])).any():
-            continue
-        i32 = inner[t].astype(np.float32)
-        c_x = np.round((i32[0] + i32[1]) / 2, 6); c_y = np.round((i32[2] + i32[3]) / 2, 6)      # float32 arithmetic
-        center_row = np.concatenate([np.array([c_x, c_y, 0, 0]), np.zeros(feats.shape[1])]).reshape(1, -1)
-        chunk = (chunk.astype(np.float64) - center_row).astype(np.float32)
-        xyz = chunk[:, :3]; inst = chunk[:, 3].astype(np.int32); feat = chunk[:, 4:]
-        center = np.array([c_x, c_y, 0])                                  # what the npz holds (float64 of the float32 values)
-        sem = np.where(inst == NON_TREE_RAW, NON_TREE_DS, TREE_DS).astype(np.float64)
-        off, valid = offset_labels(xyz, inst, sem)
-        m_inner = np.linalg.norm(xyz[:, :-1], ord=np.inf, axis=1) <= inner_square_edge_length / 2
-        not_ignore = inst != IGNORE_RAW
-        out.append(dict(coords=xyz, input_feats=feat, batch_ids=np.zeros(len(xyz), np.int64), semantic_labels=sem.astype(np.int64),
-                        instance_labels=inst.astype(np.int64), masks_inner=m_inner,
-                        masks_off=m_inner & not_ignore & (sem != NON_TREE_DS) & valid, masks_sem=m_inner & not_ignore,
-                        offset_labels=off.astype(np.float32), batch_size=1,
-                        centers=(np.ones_like(xyz) * center).astype(np.float32)))
+        b = crop_tile(rows, inner[t], outer[t], feats.shape[1], inner_square_edge_length)
+        if b is not None:
+            out.append(b)
     return out

@@ -171,8 +171,8 @@ def test_blk_conv_deep_split_units():
 
 
 @pytest.fixture(scope="module")
-def tile2():
-    return make_batch([make_tile(**CONFIGS["config2"], seed=0)])
+def tile2(tile2_batch):
+    return tile2_batch
 
 
 def test_config2_blocked_geometry_and_conv_on_the_full_tile(tile2):

@@ -4,9 +4,10 @@ config 2  the 1.89 M-point 40x40 m / 0.1 m tile: geometry bit-exact, conv kernel
           rows, the fp32 forward vs the CPU oracle end to end, the bf16 headline mode on decision-level quantities
 config 3  the default 7-level / 32-channel architecture in training mode vs the reference module tree (golden g12), and a
           full-size 2 x 40 m training step through size-independent properties
-config 4  64 tiles through the tile loop = 64 single-tile forwards; the sharded loop under a world-1 RCCL group
-config 5  the 0.05 m / 15 M-voxel stress tile: geometry vs the oracle, forward finite, kernel families agree; buffers beyond
-          2^31 and 2^32 bytes
+config 4  the 64 overlapping 40 m crops of ONE 68 m plot (what bench.py's config4 block runs): device crops = numpy box crops, the tile
+          loop = 64 single-tile forwards; the sharded loop under a world-1 RCCL group
+config 5  the 0.05 m / 17.9 M-voxel stress tile at BASELINE's size (config5_20m, what bench.py's config5 block runs): geometry vs the
+          oracle, forward finite, kernel families agree; buffers beyond 2^31 and 2^32 bytes
 """
 import json
 import os
@@ -27,7 +28,7 @@ pytestmark = pytest.mark.gpu
 from oracle import model as om
 from oracle import sparse_ops as osp
 from oracle import voxel as ov
-from treelearn_amd.synth import CONFIGS, make_batch, make_tile, plot_tiles, random_state_dict
+from treelearn_amd.synth import CONFIGS, make_batch, make_tile, random_state_dict
 
 REL_TOL = 1e-3
 
@@ -38,9 +39,9 @@ def rel_err(a, b):
 
 
 @pytest.fixture(scope="module")
-def tile2():
-    """The config-2 tile of bench.py (seed 0) as a batch dict (CPU) -- built once per module."""
-    return make_batch([make_tile(**CONFIGS["config2"], seed=0)])
+def tile2(tile2_batch):
+    """The config-2 tile of bench.py (seed 0) as a batch dict (CPU) -- built once per session (tests/conftest.py)."""
+    return tile2_batch
 
 
 def _geometry(batch, vs, levels=7, sshape=(500, 500, 1000)):
@@ -537,43 +538,79 @@ def test_config3_full_size_bf16_gradients_vs_fp32_step(monkeypatch):
 
 # =============================================================================================== config 4
 @pytest.fixture(scope="module")
-def plot64():
-    """The 64 tiles of BASELINE config 4 (8 symmetries x generator seeds 0..7, config-2 size), resident on the GPU."""
-    cache = {}
-    out = []
-    for i in range(64):
-        b = make_batch(plot_tiles([i], CONFIGS["config2"], cache))
-        out.append({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()})
-    return out
+def plot4():
+    """BASELINE config 4 as bench.py runs it: ONE synthetic plot (synth.make_plot: 68 x 68 m, ~5.5 M points), its 64 overlapping 40 x 40 m tiles
+    (synth.plot_squares: inner squares of 8 m every 4 m, 16 m of context; the lay-out of the reference's generate_tiles,
+    tree_learn/util/data_preparation.py:362-389, tools/pipeline/pipeline.py:52-70) cut on the device by PlotTiler.tile_batch (tl_tile_crop)."""
+    from treelearn_amd.synth import PLOT4, make_plot, plot_squares
+    from treelearn_amd.util.tiles import PlotTiler
+    plot = make_plot(**PLOT4, seed=0)
+    inner, outer = plot_squares(**PLOT4)
+    tiler = PlotTiler(plot["points"], plot["instance_label"].astype(np.float32), plot["feat"])
+    tiles = []
+    for i in range(len(inner)):
+        b = tiler.tile_batch(inner[i], outer[i], PLOT4["inner_edge"], offset_labels="none", tile_index=i)
+        assert b is not None, i
+        torch.cuda.current_stream().wait_event(b.pop("_ready_event"))
+        tiles.append(b)
+    torch.cuda.synchronize()
+    return plot, inner, outer, tiles
 
 
-def test_config4_64_tiles_loop_equals_single_forwards(plot64):
-    """64 config-2 tiles through the production tile loop (three tiles in flight, inner-square filter on the device) give exactly
-    what 64 separate forwards give; the sharded loop under a world-1 RCCL process group (LPT assignment, packed device-resident
-    records, two collectives) returns the same arrays."""
+def test_config4_plot_crops_equal_numpy_box_crops(plot4):
+    """The device crops of the config-4 plot against the numpy restatement of the reference's tile cut + DataLoader item (oracle/tiles.crop_tile,
+    pinned by golden G11): every array of seven of the 64 tiles bit for bit -- corner, edge and interior squares --, and the point count of all."""
+    from oracle import tiles as ot
+    from treelearn_amd.synth import PLOT4
+    plot, inner, outer, tiles = plot4
+    assert len(tiles) == 64
+    rows = np.hstack([plot["points"], plot["instance_label"].astype(np.float32)[:, None], plot["feat"]]).astype(np.float32)
+    x, y = rows[:, 0], rows[:, 1]
+    for i, b in enumerate(tiles):
+        o32 = outer[i].astype(np.float32)
+        assert b["coords"].shape[0] == int(((x >= o32[0]) & (x <= o32[1]) & (y >= o32[2]) & (y <= o32[3])).sum()), i
+        assert b["coords"].shape[0] > 1_500_000 and int(b["masks_inner"].sum()) > 40_000
+    for i in (0, 7, 9, 27, 36, 56, 63):
+        ref = ot.crop_tile(rows, inner[i], outer[i], 1, PLOT4["inner_edge"])
+        b = tiles[i]
+        for k in ("coords", "input_feats", "batch_ids", "semantic_labels", "instance_labels", "masks_inner", "masks_sem", "centers"):
+            got = b[k].cpu().numpy()
+            assert got.dtype == ref[k].dtype and got.shape == ref[k].shape, (i, k, got.dtype, ref[k].dtype)
+            np.testing.assert_array_equal(got, ref[k], err_msg=f"tile {i} {k}")
+
+
+def test_config4_64_plot_tiles_loop_equals_single_forwards(plot4):
+    """The 64 overlapping crops of the ONE config-4 plot (what bench.py's `config4` block times) through the production tile loop (four tiles
+    in flight, inner-square filter on the device) give exactly what 64 separate forwards give; the sharded loop under a world-1 RCCL
+    process group (LPT assignment, packed device-resident records, two collectives) returns the same arrays."""
     import torch.distributed as dist
     from treelearn_amd.util.pipeline import get_pointwise_preds
     from treelearn_amd.util.sharding import TileList, get_pointwise_preds_sharded
+    tiles = plot4[3]
     model = _model(torch.bfloat16)
-    res = get_pointwise_preds(model, plot64, dict(voxel_size=0.1), keep_on_device=True)
+    res = get_pointwise_preds(model, tiles, dict(voxel_size=0.1), keep_on_device=True)
     assert len(set(len(r) for r in res)) == 1 and len(res[0]) > 64 * 50_000
     sem, off, bb, coords = [], [], [], []
     with torch.no_grad():
-        for b in plot64:
+        for b in tiles:
             o = model(b, return_loss=False)
             m = b["masks_inner"]
             sem.append(o["semantic_prediction_logits"][m]); off.append(o["offset_predictions"][m]); bb.append(o["backbone_feats"][m])
             coords.append(b["coords"][m] + b["centers"][m])
     assert torch.equal(res[0], torch.cat(sem)) and torch.equal(res[2], torch.cat(off)) and torch.equal(res[6], torch.cat(bb))
     assert torch.equal(res[4], torch.cat(coords))
-    assert torch.equal(res[5], torch.cat([b["instance_labels"][b["masks_inner"]] for b in plot64]))
+    assert torch.equal(res[5], torch.cat([b["instance_labels"][b["masks_inner"]] for b in tiles]))
+    # neighbouring tiles share 36 m: the gathered inner rows hold interior points of the plot up to four times (what `ensemble` averages)
+    key = torch.round(res[4].double() * 100).long()
+    key = (key[:, 0] + 100_000) * (1 << 42) + (key[:, 1] + 100_000) * (1 << 21) + (key[:, 2] + 100_000)
+    assert len(torch.unique(key)) < 0.45 * len(key)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", _free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         made = []
-        src = TileList([b["coords"].shape[0] for b in plot64], lambda i: (made.append(i), plot64[i])[1])
+        src = TileList([b["coords"].shape[0] for b in tiles], lambda i: (made.append(i), tiles[i])[1])
         sh = get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True, return_backbone_feats=True)
-        assert made == list(range(64))
+        assert sorted(made) == list(range(64))
         for a, b in zip(res, sh):
             assert b.is_cuda and a.dtype == b.dtype and torch.equal(a, b)
         lean = get_pointwise_preds_sharded(model, src, dict(voxel_size=0.1), return_device=True)       # default: the 60-byte record, no backbone columns
@@ -620,16 +657,17 @@ def test_config4_whole_plot_order_of_operations_under_rccl():
 
 # =============================================================================================== config 5
 @pytest.fixture(scope="module")
-def tile5():
-    return make_batch([make_tile(**CONFIGS["config5"], seed=0)])
+def tile5(tile5_batch):
+    """Config 5 at BASELINE's size (config5_20m: 19.0 M points, 17.9 M level-1 voxels) -- the tile bench.py's config5 block runs."""
+    return tile5_batch
 
 
 def test_config5_stress_tile_geometry_vs_oracle(tile5):
-    """0.05 m voxels, spatial_shape None (800 > 500): 15 M voxels at level 1.  coords / v2p / parent / child / inverse tables of
-    all seven levels bit-exact; SubM tables bit-exact on every row of levels <= 2 M voxels and on 200 k sampled rows of the two
-    largest levels (the oracle's table builder over 15 M x 27 probes takes minutes)."""
+    """0.05 m voxels, spatial_shape None (800 > 500): 17.9 M voxels at level 1 (BASELINE's "~20 M active voxels").  coords / v2p / parent /
+    child / inverse tables of all seven levels bit-exact; SubM tables bit-exact on every row of levels <= 2 M voxels and on 200 k sampled
+    rows of the two largest levels (the oracle's table builder over 18 M x 27 probes takes minutes)."""
     g = _geometry(tile5, 0.05, sshape=None)
-    assert g.levels[0].n > 14_000_000
+    assert g.levels[0].n > 17_500_000 and tile5["coords"].shape[0] > 18_500_000
     _check_geometry_vs_oracle(g, tile5, 0.05, None, full_tables_up_to=2_000_000)
 
 

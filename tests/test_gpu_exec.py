@@ -166,10 +166,9 @@ def test_exec_profile_records_every_launch():
            [(p["K"], p["Cin"], p["Cout"], p["n_out"], p["n_in"], p["residual"], p["split"]) for p in py]
 
 
-def test_exec_config2_full_tile():
+def test_exec_config2_full_tile(tile2_batch):
     """The headline tile (1.89 M points): bit-identical to the Python-driven engine, which tests/test_gpu_configs.py holds against the oracle."""
-    from treelearn_amd.synth import CONFIGS, make_tile
-    gb = _batch([make_tile(**CONFIGS["config2"], seed=0)])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in tile2_batch.items()}
     m = _model(torch.bfloat16)
     out_c, out_p, ex = _both(m, gb)
     _assert_equal(out_c, out_p)
@@ -288,3 +287,160 @@ def test_models_come_and_go_without_leaking_device_memory():
         seen.append(torch.cuda.memory_allocated() - base)
     assert max(seen[2:]) <= seen[1] + (1 << 20), seen       # no growth from model to model
     assert seen[-1] < (8 << 20), seen                        # and (almost) nothing left behind
+
+
+# ------------------------------------------------------------------------------------------------ round 6: features, verdicts, bounded memory
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "bf16x3"])
+@pytest.mark.parametrize("flags", [(True, False), (False, True), (True, True)], ids=["use_feats", "use_coords", "both"])
+def test_exec_serves_voxel_mean_features(dtype, flags):
+    """The reference constructor's own defaults are use_feats=True (tree_learn/model/tree_learn.py:18; the yaml sets False): voxel-mean
+    features (:149-155) built INSIDE tl_forward (tl_voxel_feats) -- bit-identical to the Python-driven engine (tl_voxel_mean_feats + torch
+    column edits + the input conv on the canonical table + a row permutation into the block-local order).  Two clouds in the batch, several
+    points per voxel (the mean is over the first three), exact zeros among the features."""
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_tile, random_state_dict
+    use_feats, use_coords = flags
+    tiles = [make_tile(extent=16.0, voxel=0.05, n_trees=8, fill=0.2, seed=5), make_tile(extent=9.0, voxel=0.05, n_trees=3, fill=0.2, seed=6)]
+    gb = _batch(tiles)
+    gb["input_feats"][::17] = 0.0
+    m = TreeLearn(use_feats=use_feats, use_coords=use_coords, spatial_shape=[500, 500, 1000], voxel_size=0.1, compute_dtype=dtype)
+    m.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
+    m = m.cuda().eval()
+    out_c, out_p, ex = _both(m, gb)
+    assert ex.needs_feats and ex.last["level_n"][0] < 0.6 * gb["coords"].shape[0]            # several points per voxel
+    assert ex.last["blocked"] == (dtype == torch.bfloat16)
+    _assert_equal(out_c, out_p)
+    # ... and the features matter: the all-ones net on the same weights gives something else
+    ones = _model(dtype if dtype != "bf16x3" else torch.float32)
+    with torch.no_grad():
+        o1 = ones(gb, return_loss=False)
+    assert not torch.equal(o1["semantic_prediction_logits"], out_c["semantic_prediction_logits"])
+
+
+def test_exec_default_constructor_takes_the_one_call_path():
+    """`TreeLearn()` exactly as the reference's constructor defaults build it (use_feats=True, use_coords=False, spatial_shape=None) is served
+    by tl_forward, and its fp32 forward is within 1e-3 of the CPU oracle's."""
+    from oracle import model as om
+    from treelearn_amd.model import TreeLearn
+    from treelearn_amd.synth import make_batch, make_tile, random_state_dict
+    batch = make_batch([make_tile(extent=8.0, voxel=0.1, n_trees=3, fill=0.1, seed=9)])
+    sd = random_state_dict(4, channels=32, num_blocks=7)
+    m = TreeLearn()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(batch, return_loss=False)
+    assert m._plan._exec is not None and m._plan._exec.needs_feats and m._plan._exec.last["launches"] > 60
+    ref = om.forward(sd, batch["coords"].numpy(), batch["input_feats"].numpy(), batch["batch_ids"].numpy(), 1, voxel_size=0.1, num_blocks=7,
+                     use_feats=True, use_coords=False)
+    for k in ("semantic_prediction_logits", "offset_predictions"):
+        a, b = out[k].cpu().numpy().astype(np.float64), ref[k].numpy().astype(np.float64)
+        assert np.abs(a - b).max() / np.abs(b).max() < 1e-3, k
+
+
+def test_exec_contexts_are_bounded_and_forty_streams_do_not_grow_memory():
+    """One context + arena per (device, stream) -- but at most MAX_CONTEXTS of them (least recently used first out): a caller that runs every
+    request on a fresh stream holds eight arenas, not one per stream handle it ever used."""
+    from treelearn_amd.model import executor as E
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=2)])
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        ref = m(gb, return_loss=False)
+    ex = m._plan._exec
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    assert len({s.cuda_stream for s in streams}) > E.MAX_CONTEXTS + 4        # torch hands out a pool of distinct handles
+    peak_ctx, mem = 0, []
+    with torch.no_grad():
+        for i, s in enumerate(streams):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                out = m(gb, return_loss=False)
+            s.synchronize()
+            _assert_equal(out, ref)
+            peak_ctx = max(peak_ctx, len(ex._ctx))
+            mem.append(torch.cuda.memory_allocated())
+    assert peak_ctx <= E.MAX_CONTEXTS and len(ex._ctx) == E.MAX_CONTEXTS
+    arena = next(iter(ex._ctx.values()))[1].numel()
+    assert max(mem[E.MAX_CONTEXTS:]) - mem[E.MAX_CONTEXTS - 1] < arena, "memory kept growing after the context cap was reached"
+    ex.release_memory()
+    assert all(c[1] is None for c in ex._ctx.values())
+    with torch.no_grad():
+        _assert_equal(m(gb, return_loss=False), ref)                        # arenas come back on demand
+
+
+def test_exec_check_reports_the_unit_builder_flag_for_the_right_forward():
+    """tl_exec_check: TL_OK after clean forwards (and it may be called repeatedly / with nothing in flight); with the flag word of the context
+    forced to 1 -- the state a builder that skipped units leaves behind -- Executor.check() raises, once; get_pointwise_preds asks after its
+    last tile; TL_EXEC_CHECK=1 asks after every forward."""
+    import ctypes
+    from treelearn_amd import _hip
+    from treelearn_amd.synth import make_tile
+    from treelearn_amd.util.pipeline import get_pointwise_preds
+    gb = _batch([make_tile(extent=12.0, voxel=0.1, n_trees=6, fill=0.1, seed=2)])
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        m(gb, return_loss=False)
+    ex = m._plan._exec
+    assert ex.last["blocked"]
+    ex.check(); ex.check()
+    L = _hip.lib()
+    fresh = L.tl_exec_create()
+    assert L.tl_exec_check(fresh) == _hip.TL_OK
+    L.tl_exec_destroy(fresh)
+    assert L.tl_exec_check(None) == _hip.TL_ERR_ARG
+    os.environ["TL_EXEC_CHECK"] = "1"
+    try:
+        with torch.no_grad():
+            m(gb, return_loss=False)
+    finally:
+        del os.environ["TL_EXEC_CHECK"]
+    res = get_pointwise_preds(m, [gb, gb, gb], dict(voxel_size=0.1), keep_on_device=True)
+    assert len(res[0]) > 0
+
+
+def test_tl_forward_rejects_inconsistent_descriptors():
+    """tl_forward is a public entry point: a descriptor whose recursion flags, widths or pointers do not fit together is TL_ERR_ARG before
+    anything is enqueued (the recursion of the U-Net trusts `deeper`; a wrong flag would read past the levels)."""
+    import copy, ctypes
+    from treelearn_amd import _hip
+    from treelearn_amd.synth import make_tile
+    gb = _batch([make_tile(extent=10.0, voxel=0.1, n_trees=4, fill=0.1, seed=2)])
+    m = _model(torch.bfloat16)
+    with torch.no_grad():
+        ref = m(gb, return_loss=False)
+    ex = m._plan._exec
+    L = _hip.lib()
+    N = gb["coords"].shape[0]
+    arena = torch.empty(int(ex.last["arena_bytes"] * 1.2) + (1 << 20), dtype=torch.uint8, device="cuda")
+    logits = torch.empty((N, 2), device="cuda"); offsets = torch.empty((N, 3), device="cuda")
+    ctx = L.tl_exec_create()
+
+    def call(desc):
+        a = _hip.ForwardArgs()
+        a.xyz = gb["coords"].data_ptr(); a.batch_ids = gb["batch_ids"].data_ptr(); a.N = N; a.B = 1
+        a.logits = logits.data_ptr(); a.offsets = offsets.data_ptr(); a.arena = arena.data_ptr(); a.arena_bytes = arena.numel()
+        return L.tl_forward(ctx, ctypes.byref(desc), ctypes.byref(a), torch.cuda.current_stream().cuda_stream)
+
+    def mutated(f):
+        d = _hip.NetDesc()
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(ex.desc), ctypes.sizeof(d))
+        f(d)
+        return d
+
+    assert call(mutated(lambda d: None)) == _hip.TL_OK
+    torch.cuda.synchronize()
+    assert torch.equal(logits, ref["semantic_prediction_logits"])
+    bad = [lambda d: setattr(d.u[6], "deeper", 1),                  # the last level claims a deeper one
+           lambda d: setattr(d.u[3], "deeper", 0),                  # a truncated net
+           lambda d: setattr(d, "num_levels", 5),                   # fewer levels than the flags say
+           lambda d: setattr(d.u[2], "C", 64),                      # a width that does not match its weights
+           lambda d: setattr(d.u[1].blocks[0].w2, "w", None),       # a missing weight
+           lambda d: setattr(d.u[0].tail[0].w1x1, "Cin", 32),       # the 1x1 i_branch of a 2C -> C block with the wrong width
+           lambda d: setattr(d.w_in, "Cout", 64),
+           lambda d: setattr(d, "in_channels", 7),
+           lambda d: setattr(d, "use_feats", 1),                    # features wanted, none passed
+           lambda d: setattr(d.out_bn, "scale", None)]
+    for i, f in enumerate(bad):
+        assert call(mutated(f)) == _hip.TL_ERR_ARG, i
+    L.tl_exec_destroy(ctx)

@@ -72,12 +72,14 @@ def _trained_like(voxel, sshape, batch, seed=11):
     return m.eval()
 
 
-def test_config5_stress_tile_forward_fp16():
-    """BASELINE config 5 as worded: the 0.05 m / 16 M-point tile in fp16, on trained-like weights.  Every output finite (overflow count 0),
+def test_config5_stress_tile_forward_fp16(tile5_batch):
+    """BASELINE config 5 as worded and at its stated size (config5_20m: 19.0 M points, 17.9 M voxels -- the tile of bench.py's config5
+    block, shared with tests/test_gpu_configs.py through the session fixture): the 0.05 m tile in fp16, on trained-like weights.  Every output finite (overflow count 0),
     decisions as in bf16 / closer to fp32 than bf16 is; on RANDOM-INIT running statistics the same forward overflows fp16 (counted), which
     is why bf16 stays the default 16-bit mode."""
     from treelearn_amd.model import TreeLearn
-    batch = make_batch([make_tile(**CONFIGS["config5"], seed=0)])
+    batch = tile5_batch
+    assert batch["coords"].shape[0] > 18_500_000
     gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
     mb = _trained_like(0.05, None, gb)
     outs = {}

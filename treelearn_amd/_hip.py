@@ -60,7 +60,7 @@ class HdbGrid(_c.Structure):               # TlHdbGrid
 
 
 TL_MAX_LEVELS = 8
-TL_ERR_ARENA, TL_ERR_REACH_ZERO, TL_ERR_EXTENT = -4, -5, -6
+TL_ERR_ARENA, TL_ERR_REACH_ZERO, TL_ERR_EXTENT, TL_ERR_BLK = -4, -5, -6, -7
 
 
 class Affine(_c.Structure):                # tl_affine
@@ -82,7 +82,8 @@ class UBlockDesc(_c.Structure):            # tl_ublock_desc
 
 class NetDesc(_c.Structure):               # tl_net_desc
     _fields_ = [("dtype", _i32), ("num_levels", _i32), ("voxel_size", _f32), ("has_shape", _i32), ("spatial_shape", _i32 * 3), ("blocked", _i32),
-                ("in_channels", _i32), ("w_in", Weight), ("u", UBlockDesc * TL_MAX_LEVELS), ("out_bn", Affine),
+                ("in_channels", _i32), ("use_coords", _i32), ("use_feats", _i32), ("max_points_per_voxel", _i32), ("reserved0", _i32),
+                ("w_in", Weight), ("u", UBlockDesc * TL_MAX_LEVELS), ("out_bn", Affine),
                 ("head_w1", _vp), ("head_b1", _vp), ("head_w2", _vp), ("head_b2", _vp)]
 
 
@@ -92,7 +93,7 @@ class LaunchRec(_c.Structure):             # tl_launch_rec
 
 
 class ForwardArgs(_c.Structure):           # tl_forward_args
-    _fields_ = [("xyz", _vp), ("batch_ids", _vp), ("N", _i64), ("B", _i32), ("reserved", _i32), ("arena", _vp), ("arena_bytes", _i64),
+    _fields_ = [("xyz", _vp), ("batch_ids", _vp), ("N", _i64), ("B", _i32), ("reserved", _i32), ("point_feats", _vp), ("arena", _vp), ("arena_bytes", _i64),
                 ("backbone", _vp), ("logits", _vp), ("offsets", _vp), ("side_stream", _vp), ("needed_bytes", _i64),
                 ("level_n", _i64 * TL_MAX_LEVELS), ("blocked_used", _i32), ("launches", _i32)]
 
@@ -113,6 +114,7 @@ PROTOTYPES = {
     "tl_expand_coords": (_i32, [_vp, _vp, _I4, _vp, _vp]),
     "tl_point_rank": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp]),
     "tl_voxel_mean_feats": (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "tl_voxel_feats": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "tl_rulebook_subm": (_i32, [_vp, _i64, _vp, _vp, _I4, _vp, _vp, _vp]),
     "tl_rulebook_down": (_i32, [_vp, _i64, _vp, _vp, _I4, _i64, _vp, _vp, _vp, _vp]),
     "tl_rulebook_compact": (_i32, [_vp, _i64, _vp, _vp]),
@@ -126,6 +128,7 @@ PROTOTYPES = {
     "tl_exec_create": (_vp, []),
     "tl_exec_destroy": (None, [_vp]),
     "tl_forward": (_i32, [_vp, _c.POINTER(NetDesc), _c.POINTER(ForwardArgs), _vp]),
+    "tl_exec_check": (_i32, [_vp]),
     "tl_exec_profile": (_i32, [_vp, _i32]),
     "tl_exec_profile_read": (_i32, [_vp, _c.POINTER(LaunchRec), _i32]),
     "tl_bn_train_finish": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -55,7 +55,7 @@ static __device__ __forceinline__ void quad_transpose(const u32x4 (&S)[4], u32x4
 }
 
 // W waves per workgroup, each owning RB blocks of 32 rows (one weight fragment read from LDS feeds RB MFMAs).
-// ABL: developer ablation bits (1 no transposition, 2 no gathers, 4 no barrier, 8 no MFMA, 16 timers)
+// ABL: developer ablation bits (1 no transposition, 2 no gathers, 4 no barrier, 8 no MFMA, 16 timers, 32 MFMAs for taps < 16 only)
 // SP: the input channels are walked in SP slices of PN * 64: step v of the K * SP steps contracts slice v % SP of tap v / SP
 // (same registers and LDS as the PN-wide kernel; 256 -> 128 as SP = 2 x 128 instead of a PN = 4 kernel that spills).
 template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL, int SP = 1>
@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
           const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + (pp * 8 + s) * 16);
 #pragma unroll
           for (int rb = 0; rb < RB; ++rb) {
-            if constexpr (ABL & 8) acc[rb][nb][0] += __uint_as_float(F[rb][pp][s][0] ^ bf[0]);
+            if constexpr ((ABL & 8) != 0) acc[rb][nb][0] += __uint_as_float(F[rb][pp][s][0] ^ bf[0]);
+            else if ((ABL & 32) != 0 && k / SP >= 16) acc[rb][nb][0] += __uint_as_float(F[rb][pp][s][0] ^ bf[0]);
             else mma16<true>(acc[rb][nb], F[rb][pp][s], bf);
           }
         }
@@ -305,6 +306,8 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
         case 13: return launch<27, 2, 1, 1, 4, 2>(p, s);
         case 14: return launch<27, 2, 1, 3, 4, 2>(p, s);
         case 15: return launch<27, 2, 1, 2, 4, 2, 2>(p, s);
+        case 20: return p.table ? launch<16, 2, 1, 2>(p, s) : TL_ERR_ARG;      // the first 16 taps only: gathers AND MFMAs (tools/dev_l2_floor.py)
+        case 21: return launch<27, 2, 1, 2, 8, 1, 32>(p, s);                   // all 27 gathers, MFMAs for 16 taps
       }
     }
 #endif

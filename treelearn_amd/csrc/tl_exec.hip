@@ -51,7 +51,8 @@ struct LevelG {
 
 struct tl_exec {
   int32_t* host = nullptr;                       // pinned: 16 words of read-back
-  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_flag = nullptr;
+  bool flag_in_flight = false;                   // a unit-builder flag read-back has been enqueued and not been waited for yet
   bool profile = false;
   std::vector<hipEvent_t> pev;                   // event pairs of the profiled forward
   std::vector<tl_launch_rec> recs;
@@ -73,7 +74,7 @@ struct Run {
   LevelG lv[TL_MAX_LEVELS];
   bool blocked = false;
   int64_t g0 = 0;                                // arena offset of the geometry block (word offsets are relative to it)
-  int64_t o_unit = -1, o_counter = -1, o_halo = -1, o_lrb = -1, o_pmask = -1;
+  int64_t o_unit = -1, o_counter = -1, o_halo = -1, o_lrb = -1, o_pmask = -1, o_nn = -1;
 
   const int32_t* gw(int64_t word_off) const { return word_off < 0 ? nullptr : reinterpret_cast<const int32_t*>(ar.at(g0 + 4 * word_off)); }
 
@@ -233,11 +234,21 @@ struct Run {
     release(y);
   }
 
-  // InferencePlan.run for the all-ones input: input conv, U-Net, heads.  `ones` = arena offset of the ones matrix [n1, in_channels]
+  // InferencePlan.run: input conv, U-Net, heads.  The input conv's operand [n1, in_channels] is the ones matrix (default configuration: the
+  // conv then needs no gather) or the voxel-mean features in the level's row order (tl_voxel_feats through this geometry's v2p)
   void network() {
     const int64_t n1 = lv[0].n;
+    const bool feats = net->use_coords || net->use_feats;
     Ten ones = alloc(n1, net->in_channels);
-    if (!ar.dry) {
+    if (feats) {
+      const int64_t ws_bytes = 4 * n1 * net->max_points_per_voxel, o_ws = ar.take(ws_bytes);
+      if (!ar.dry) {
+        const int r = tl_voxel_feats(a->xyz, a->point_feats, net->in_channels - 3, reinterpret_cast<const int64_t*>(gw(o_v2p)), a->N, n1, net->max_points_per_voxel,
+                                     net->use_coords, net->use_feats, net->dtype, reinterpret_cast<int32_t*>(ar.at(o_ws)), ar.at(ones.off), s);
+        if (r != TL_OK) rc = r;
+      }
+      ar.give(o_ws, ws_bytes);
+    } else if (!ar.dry) {
       hipError_t e;
       if (net->dtype == TL_F32) e = hipMemsetD32Async((hipDeviceptr_t)ar.at(ones.off), 0x3F800000, n1 * net->in_channels, s);
       else e = hipMemsetD16Async((hipDeviceptr_t)ar.at(ones.off), net->dtype == TL_BF16 ? 0x3F80 : 0x3C00, n1 * net->in_channels, s);
@@ -247,12 +258,14 @@ struct Run {
     const ViewReq out = RAW();
     if (blocked) {
       const ViewReq v = RAW();
-      conv(0, 4, ones, net->w_in, subm(0), n1, &v, 1, xs, nullptr, {nullptr, nullptr}, 0, 1);
+      Table tin = subm(0);
+      if (feats) { tin = Table{}; tin.table = gw(o_nn); }     // block-local rows, real features: the plain table in the new order (row-wise the same sums)
+      conv(0, 4, ones, net->w_in, tin, n1, &v, 1, xs, nullptr, {nullptr, nullptr}, 0, feats ? 0 : 1);
       release(ones);
       l1_staged(xs[0], &out, 1, &x);
     } else {
       const ViewReq v[2] = {RAW(), ACT(net->u[0].blocks[0].bn0)};
-      conv(0, 4, ones, net->w_in, subm(0), n1, v, 2, xs, nullptr, {nullptr, nullptr}, 0, 1);
+      conv(0, 4, ones, net->w_in, subm(0), n1, v, 2, xs, nullptr, {nullptr, nullptr}, 0, feats ? 0 : 1);
       release(ones);
       ublock(0, xs[0], xs[1], &out, 1, &x);
     }
@@ -268,6 +281,37 @@ struct Run {
 
 inline int64_t al64(int64_t w) { return (w + 63) & ~int64_t(63); }
 
+inline bool weight_is(const tl_weight& w, int K, int Cin, int Cout) { return w.w && w.K == K && w.Cin == Cin && w.Cout == Cout; }
+inline bool affine_ok(const tl_affine& a) { return a.scale && a.shift; }
+
+// ResidualBlock Cin -> C (blocks.py:42-79): two 27-tap convs, a 1x1 i_branch exactly when the widths differ
+inline bool res_ok(const tl_res_desc& b, int Cin, int C) {
+  if (!affine_ok(b.bn0) || !affine_ok(b.bn3) || !weight_is(b.w1, 27, Cin, C) || !weight_is(b.w2, 27, C, C)) return false;
+  if (Cin != C ? !weight_is(b.w1x1, 1, Cin, C) : b.w1x1.w != nullptr) return false;
+  for (int h = 0; h < 2; ++h)
+    if (b.w1_half[h].w && !(Cin == 2 * C && weight_is(b.w1_half[h], 27, C, C))) return false;
+  return (b.w1_half[0].w == nullptr) == (b.w1_half[1].w == nullptr);
+}
+
+// the whole descriptor before anything is enqueued: the recursion of ublock() trusts `deeper`, the level count and every width
+inline bool net_ok(const tl_net_desc* net) {
+  const int nl = net->num_levels;
+  if (!weight_is(net->w_in, 27, net->in_channels, net->u[0].C)) return false;
+  if (net->u[0].C != 8 && net->u[0].C != 16 && net->u[0].C != 32 && net->u[0].C != 64) return false;        // the widths tl_head_mlp is instantiated for
+  if (!affine_ok(net->out_bn) || !net->head_w1 || !net->head_b1 || !net->head_w2 || !net->head_b2) return false;
+  for (int l = 0; l < nl; ++l) {
+    const tl_ublock_desc& u = net->u[l];
+    if (u.C <= 0 || (u.deeper != 0) != (l + 1 < nl)) return false;
+    if (!res_ok(u.blocks[0], u.C, u.C) || !res_ok(u.blocks[1], u.C, u.C)) return false;
+    if (!u.deeper) continue;
+    const int Cd = net->u[l + 1].C;
+    if (!affine_ok(u.bn_down) || !affine_ok(u.bn_up) || !affine_ok(u.bn_cat_l) || !affine_ok(u.bn_cat_r)) return false;
+    if (!weight_is(u.wd, 8, u.C, Cd) || !weight_is(u.wu, 8, Cd, u.C)) return false;
+    if (!res_ok(u.tail[0], 2 * u.C, u.C) || !res_ok(u.tail[1], u.C, u.C)) return false;
+  }
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -276,7 +320,8 @@ tl_exec* tl_exec_create(void) {
   tl_exec* ex = new (std::nothrow) tl_exec();
   if (!ex) return nullptr;
   if (hipHostMalloc(reinterpret_cast<void**>(&ex->host), 64, hipHostMallocDefault) != hipSuccess || (memset(ex->host, 0, 64), false) ||
-      hipEventCreateWithFlags(&ex->ev_main, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ex->ev_side, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ex->ev_main, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ex->ev_side, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ex->ev_flag, hipEventDisableTiming) != hipSuccess) {
     tl_exec_destroy(ex);
     return nullptr;
   }
@@ -288,8 +333,22 @@ void tl_exec_destroy(tl_exec* ex) {
   for (hipEvent_t e : ex->pev) (void)hipEventDestroy(e);
   if (ex->ev_main) (void)hipEventDestroy(ex->ev_main);
   if (ex->ev_side) (void)hipEventDestroy(ex->ev_side);
+  if (ex->ev_flag) (void)hipEventDestroy(ex->ev_flag);
   if (ex->host) (void)hipHostFree(ex->host);
   delete ex;
+}
+
+int tl_exec_check(tl_exec* ex) {
+  if (!ex) return TL_ERR_ARG;
+  if (ex->flag_in_flight) {
+    if (hipEventSynchronize(ex->ev_flag) != hipSuccess) return TL_ERR_LAUNCH;
+    ex->flag_in_flight = false;
+  }
+  if (ex->host[8]) {
+    ex->host[8] = 0;
+    return TL_ERR_BLK;
+  }
+  return TL_OK;
 }
 
 int tl_exec_profile(tl_exec* ex, int enable) {
@@ -314,6 +373,9 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
   if (!ex || !net || !a || !a->xyz || !a->batch_ids || !a->logits || !a->offsets || a->N <= 0 || a->B <= 0) return TL_ERR_ARG;
   if (net->num_levels < 2 || net->num_levels > TL_MAX_LEVELS || net->in_channels <= 0 || net->voxel_size <= 0.f) return TL_ERR_ARG;
   if (net->dtype != TL_F32 && net->dtype != TL_BF16 && net->dtype != TL_F16) return TL_ERR_ARG;
+  if (!net_ok(net)) return TL_ERR_ARG;
+  const bool feats = net->use_coords || net->use_feats;            // voxel-mean input features (tree_learn.py:149-155) instead of ones
+  if (feats && (!a->point_feats || net->in_channels <= 3 || net->in_channels > 8 || net->max_points_per_voxel <= 0)) return TL_ERR_ARG;
   if (!a->arena || ((uintptr_t)a->arena) % 256) return TL_ERR_ARG;
   hipStream_t s = tl_s(stream);
   const int nl = net->num_levels;
@@ -335,8 +397,9 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
                                  reinterpret_cast<int32_t*>(R.ar.at(o_maxc)), stream);
   if (rc != TL_OK) return rc;
   if (hipMemcpyAsync(ex->host, R.ar.at(o_maxc), 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return TL_ERR_LAUNCH;   // host sync #1
+  ex->flag_in_flight = false;           // (the flag copy of the previous forward on this context was enqueued on a stream this forward just drained ...
   if (ex->host[3]) return TL_ERR_EXTENT;
-  if (ex->host[8]) {                    // the block-local builder's error flag of the PREVIOUS forward on this context (copied behind it, complete by now)
+  if (ex->host[8]) {                    // ... so its verdict is in: the block-local builder's error flag of the PREVIOUS forward, unless tl_exec_check took it)
     ex->host[8] = 0;
     return TL_ERR_BLK;
   }
@@ -399,6 +462,7 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
     const int64_t nbws = tl_blk_ws_words(R.lv[0].dims);
     o_o2n = take(n1); o_perm = take(n1); o_cnew = take(4 * n1); R.o_unit = take(4 * n1); R.o_counter = take(64); R.o_halo = take(32 * n1);
     R.o_lrb = take(9 * n1); R.o_pmask = take(n1); o_bws = take(nbws);
+    if (feats) R.o_nn = take(27 * n1);            // the input conv of real features gathers: the plain table in the block-local order (tl_blk.nn)
   }
   const int64_t o_m1 = cur;
   for (int l = 0; l + 1 < nl; ++l) { R.lv[l].parent = take(R.lv[l].n); R.lv[l].inv = take(8 * R.lv[l].n); }
@@ -425,10 +489,21 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
     t.coords = W(v.coords); t.nbr = W(v.nbr); t.compact = W(v.ct); t.child = W(v.child); t.parent = W(v.parent); t.inv = W(v.inv); t.o2n = nullptr;
   }
   hipStream_t side = s;
+  // whatever happens after the fork below, `s` waits for the side stream before this call returns: the caller may reuse or free the arena
+  // on `s` as soon as it has the return code, and the unit builder writes into it
+  struct Join {
+    tl_exec* ex; hipStream_t s; hipStream_t* side; bool done = false;
+    int join() {
+      if (done || *side == s) return TL_OK;
+      done = true;
+      return (hipEventRecord(ex->ev_side, *side) == hipSuccess && hipStreamWaitEvent(s, ex->ev_side, 0) == hipSuccess) ? TL_OK : TL_ERR_LAUNCH;
+    }
+    ~Join() { (void)join(); }
+  } joiner{ex, s, &side};
   if (R.blocked) {
     tl_blk bk{};
     bk.o2n = W(o_o2n); bk.perm = W(o_perm); bk.coords_new = W(o_cnew); bk.unit = W(R.o_unit); bk.counter = W(R.o_counter); bk.halo = W(R.o_halo);
-    bk.lrb = reinterpret_cast<uint32_t*>(W(R.o_lrb)); bk.pmask = W(R.o_pmask); bk.cap_units = n1; bk.halo_max = TL_BLK_HALO_MAX; bk.nn = nullptr;
+    bk.lrb = reinterpret_cast<uint32_t*>(W(R.o_lrb)); bk.pmask = W(R.o_pmask); bk.cap_units = n1; bk.halo_max = TL_BLK_HALO_MAX; bk.nn = W(R.o_nn);
     rc = tl_blk_build(arr[0].bitmap, arr[0].prefix, R.lv[0].dims, n1, &bk, reinterpret_cast<uint32_t*>(W(o_bws)), 1, stream);
     if (rc != TL_OK) return rc;
     arr[0].o2n = bk.o2n;
@@ -442,10 +517,14 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
   }
   rc = tl_rulebooks_build(arr, nl, W(o_m1), o_m1_end - o_m1, pcoords, N, reinterpret_cast<int64_t*>(W(R.o_v2p)), stream);
   if (rc != TL_OK) return rc;
-  if (side != s && (hipEventRecord(ex->ev_side, side) != hipSuccess || hipStreamWaitEvent(s, ex->ev_side, 0) != hipSuccess)) return TL_ERR_LAUNCH;
+  if (joiner.join() != TL_OK) return TL_ERR_LAUNCH;
   // tl_blk_build's error flag (units skipped: cannot happen with cap_units >= n and halo_max <= 126, so this is an assertion) goes home behind
-  // the builder and is looked at by the next forward of this context after its first read-back -- a check that costs no synchronisation
-  if (R.blocked && hipMemcpyAsync(ex->host + 8, W(R.o_counter) + 1, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return TL_ERR_LAUNCH;
+  // the builder, ahead of the convs: tl_exec_check waits for exactly this copy; a following forward of the context sees it after its first
+  // read-back -- neither costs this forward a synchronisation
+  if (R.blocked) {
+    if (hipMemcpyAsync(ex->host + 8, W(R.o_counter) + 1, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(ex->ev_flag, s) != hipSuccess) return TL_ERR_LAUNCH;
+    ex->flag_in_flight = true;
+  }
 
   // ---- the network
   R.network();

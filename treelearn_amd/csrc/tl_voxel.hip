@@ -499,6 +499,41 @@ __global__ void __launch_bounds__(kBlock) k_mean_feats(const float* __restrict__
   }
 }
 
+
+// Voxel features as the network's input conv takes them (tree_learn.py:149-156), one launch: the mean of the first <= P points of a voxel over
+// the columns (x, y, z, f_0 .. f_{F-1}) read from the two point arrays -- same arithmetic as k_mean_feats over their hstack: fp32 sums in point
+// order, rows that are zero in every column skipped as padding, one correctly rounded division --, then ones for the column groups a flag
+// switches off, the (feat.., x, y, z) column order and the cast to the compute dtype (round to nearest even, as tensor.to(dtype) rounds).
+// One thread per voxel (C <= 8: the reference's default is 4).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_voxel_feats(const float* __restrict__ xyz, const float* __restrict__ feats, int F, int64_t M, int P,
+                                                        const int32_t* __restrict__ sel, int use_coords, int use_feats, T* __restrict__ out) {
+  const int C = 3 + F;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < M; v += (int64_t)gridDim.x * blockDim.x) {
+    float s[8];
+    for (int c = 0; c < C; ++c) s[c] = 0.f;
+    int n = 0;
+    for (int r = 0; r < P; ++r) {
+      const int32_t i = sel[v * P + r];
+      if (i == 0x7FFFFFFF) break;
+      float row[8];
+      bool allzero = true;
+      for (int c = 0; c < C; ++c) {
+        row[c] = c < 3 ? xyz[(int64_t)i * 3 + c] : feats[(int64_t)i * F + (c - 3)];
+        allzero &= (row[c] == 0.f);
+      }
+      if (allzero) continue;
+      for (int c = 0; c < C; ++c) s[c] += row[c];
+      ++n;
+    }
+    for (int c = 0; c < C; ++c) {
+      float m = n ? __fdiv_rn(s[c], (float)n) : __uint_as_float(0x7FC00000u);
+      if (c < 3 ? !use_coords : !use_feats) m = 1.f;
+      out[v * C + (c < 3 ? F + c : c - 3)] = (T)m;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -570,6 +605,20 @@ int tl_voxel_mean_feats(const float* pf, int C, const int64_t* v2p, int64_t N, i
   k_fill_i32<<<tl_grid(M * P, kBlock), kBlock, 0, s>>>(ws, M * P, 0x7FFFFFFF);
   for (int r = 0; r < P; ++r) k_first_points<<<tl_grid(N, kBlock), kBlock, 0, s>>>(v2p, N, P, r, ws);
   k_mean_feats<<<tl_grid(M * C, kBlock), kBlock, 0, s>>>(pf, C, M, P, ws, out);
+  TL_CHECK_LAUNCH();
+  return TL_OK;
+}
+
+int tl_voxel_feats(const float* xyz, const float* feats, int F, const int64_t* v2p, int64_t N, int64_t M, int P, int use_coords, int use_feats,
+                   int dtype, int32_t* ws, void* out, tl_stream_t stream) {
+  if (!xyz || !feats || !v2p || !ws || !out || F <= 0 || F > 5 || N <= 0 || M <= 0 || P <= 0 || N > 0x7FFFFFFE) return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  k_fill_i32<<<tl_grid(M * P, kBlock), kBlock, 0, s>>>(ws, M * P, 0x7FFFFFFF);
+  for (int r = 0; r < P; ++r) k_first_points<<<tl_grid(N, kBlock), kBlock, 0, s>>>(v2p, N, P, r, ws);
+  if (dtype == TL_F32) k_voxel_feats<float><<<tl_grid(M, kBlock), kBlock, 0, s>>>(xyz, feats, F, M, P, ws, use_coords, use_feats, static_cast<float*>(out));
+  else if (dtype == TL_BF16) k_voxel_feats<__bf16><<<tl_grid(M, kBlock), kBlock, 0, s>>>(xyz, feats, F, M, P, ws, use_coords, use_feats, static_cast<__bf16*>(out));
+  else if (dtype == TL_F16) k_voxel_feats<_Float16><<<tl_grid(M, kBlock), kBlock, 0, s>>>(xyz, feats, F, M, P, ws, use_coords, use_feats, static_cast<_Float16*>(out));
+  else return TL_ERR_ARG;
   TL_CHECK_LAUNCH();
   return TL_OK;
 }

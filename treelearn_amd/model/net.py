@@ -154,7 +154,8 @@ class TreeLearn(nn.Module):
                 mv = lambda t: t if t.is_cuda else t.cuda(non_blocking=True)                         # noqa: E731
                 coords = mv(batch['coords']).float().contiguous()
                 bids = mv(batch['batch_ids']).long().contiguous()
-                bb, logits, offsets = ex.forward(coords, bids, int(batch['batch_size']), want_backbone=self.return_backbone_feats)
+                feats = mv(batch['input_feats']).float().contiguous() if ex.needs_feats else None
+                bb, logits, offsets = ex.forward(coords, bids, int(batch['batch_size']), want_backbone=self.return_backbone_feats, input_feats=feats)
                 return dict(backbone_feats=bb, semantic_prediction_logits=logits, offset_predictions=offsets)
         # only the tensors the backbone reads cross PCIe here (the reference's cuda_cast also ships every label /
         # mask / centre tensor of the batch, ~80 MB per tile that inference never touches; util/train.py:28-43)

@@ -227,6 +227,11 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                     read_back(*pending.pop(0))                             # the oldest tile comes home while nf younger ones compute
             for pnd in pending:
                 read_back(*pnd)
+            # the unit builder's assertion flag of a tile's forward is otherwise only seen by the NEXT forward on the same stream: after the last
+            # tile, ask for it (every tile's results have been read back, so nothing waits here)
+            ex = getattr(getattr(model, "_plan", None), "_exec", None)
+            if ex:
+                ex.check()
     finally:
         if restore_bb is not None:                                    # also when a tile raised: later callers must not inherit the flag
             model.return_backbone_feats = restore_bb

@@ -113,19 +113,21 @@ class PlotTiler:
         F = self.feats.shape[1]
         main = torch.cuda.current_stream()
         self._stream.wait_stream(main)                         # the plot arrays may have just been produced on the caller's stream
-        for t in range(len(inner)):
-            batch = self.tile_batch(inner[t], outer[t], inner_square_edge_length, offset_labels, tile_index=t)
+        for t in range(len(inner)):                            # (one wait for the whole generator: a per-tile wait would put every crop behind the consumer's previous forward)
+            batch = self.tile_batch(inner[t], outer[t], inner_square_edge_length, offset_labels, tile_index=t, sync_with_caller=False)
             if batch is not None:
                 yield batch
 
-    def tile_batch(self, inner, outer, inner_square_edge_length, offset_labels="host", tile_index=0):
+    def tile_batch(self, inner, outer, inner_square_edge_length, offset_labels="host", tile_index=0, sync_with_caller=True):
         """ONE tile as a batch dict (collate_fn's keys, batch size 1) from its inner / outer square (x0, x1, y0, y1), or None when the inner
         square holds no point (data_preparation.py:412-427).  Random access for callers that own only some tiles of a plot (a rank of the
-        sharded tile loop) or lay the squares out themselves."""
+        sharded tile loop) or lay the squares out themselves.  `sync_with_caller=False`: the caller has already made the tiler's stream wait
+        for whatever produced the plot arrays (`tiles()` does so once) -- the crop then does not queue behind the caller's stream."""
         assert offset_labels in ("host", "none")
         F = self.feats.shape[1]
         main = torch.cuda.current_stream()
-        self._stream.wait_stream(main)                         # the plot arrays may have just been produced on the caller's stream
+        if sync_with_caller:
+            self._stream.wait_stream(main)                     # the plot arrays may have just been produced on the caller's stream
         t = tile_index
         # The crop (and its one host sync for the row count) goes on the tiler's own stream: a consumer that pulls the next
         # tile before launching the current forward (util/pipeline.get_pointwise_preds) then never waits for its own convs.
