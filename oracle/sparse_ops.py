@@ -3,7 +3,7 @@
 (i)  rulebook form  -- gather rows -> mm with W[tap] -> index_add  (scales to full tiles)
 (ii) dense form     -- scatter into a dense grid, torch.nn.functional.conv3d /
                        conv_transpose3d, sample at the active sites (small tiles only)
-(i) == (ii) is checked in tests/test_oracle.py; the identities are SURVEY.md Appendix B.
+(i) == (ii) is checked in tests/test_host_cpu.py (test_oracle_sparse_equals_dense); the identities are SURVEY.md Appendix B.
 
 Weights are in the reference's state-dict layout [Cout, kx, ky, kz, Cin]
 (tree_learn/util/train.py:70-72 comment; spconv SubMConv3d/SparseConv3d `.weight`).
