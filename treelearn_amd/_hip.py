@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtreelearn_hip.so")
 
 TL_F32, TL_BF16, TL_F16 = 0, 1, 2
-TL_ERR_UNSUPPORTED = -3
+TL_OK, TL_ERR_ARG, TL_ERR_UNSUPPORTED = 0, -1, -3
 TL_EPI_NONE, TL_EPI_STATS, TL_EPI_BN_BWD = 0, 1, 2
 # opt-in, developer build only: the window form of the 27-tap bf16 convs (csrc/tl_conv_win.hip) for levels of >= 65536 voxels; measured
 # at parity with the register-gather kernels on the config-2 tile, so the release library does not carry it

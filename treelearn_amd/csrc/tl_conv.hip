@@ -470,6 +470,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     const int rc = L_blk(p, s);
     if (rc != TL_ERR_UNSUPPORTED) return rc;
   }
+  if (has_blk && a->dtype == TL_F32 && p.w_x3 && g_blk && !train) {             // bf16x3 on block-local rows: the staged-unit kernel for fp32 rows
+    const int rc = tl_launch_conv_blk_x3(p, s);
+    if (rc != TL_ERR_UNSUPPORTED) return rc;
+  }
   if (!a->table && a->K != 1) return TL_ERR_UNSUPPORTED;       // block-local rows without a shape the staged-unit kernel serves
   if (a->table_scatter && p.one_hot && g_up && !train && dt == TL_BF16 && vec_ok && out_vec &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {

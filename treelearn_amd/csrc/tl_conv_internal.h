@@ -340,6 +340,9 @@ int tl_launch_conv_up(const ConvP& p, const int32_t* child, hipStream_t s);   //
 
 // tl_conv_blk.hip
 int tl_launch_conv_blk(const ConvP& p, hipStream_t s);                  // 16-bit, 27 taps, 32 -> 32: rows in block-local order, staged units
+#ifndef TL_F16_BUILD
+int tl_launch_conv_blk_x3(const ConvP& p, hipStream_t s);               // fp32 rows, split-bf16 contraction (bf16x3), 27 taps, 32 -> 32: staged units, two 16-channel launches
+#endif
 
 // tl_conv_stream.hip
 int tl_launch_conv_stream(const ConvP& p, int dtype, hipStream_t s);   // per-wave register gathers, weights streamed through LDS per tap

@@ -444,7 +444,11 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
 
   // ---- phase C: the geometry block (word offsets, 64-word aligned -- the layout of geometry.build_geometry step 3)
   const int64_t n1 = R.lv[0].n;
-  R.blocked = net->blocked && net->dtype != TL_F32 && net->u[0].C == 32 && net->u[0].deeper && net->u[0].tail[0].w1_half[0].w && net->u[0].tail[0].w1_half[1].w &&
+  // fp32 rows take the block-local order only in the parity-fast mode: every 27-tap conv of level 1 then needs its split-bf16 weights
+  const tl_ublock_desc& u0 = net->u[0];
+  const bool x3_l1 = u0.blocks[0].w1.x3 && u0.blocks[0].w2.x3 && u0.blocks[1].w1.x3 && u0.blocks[1].w2.x3 && u0.tail[0].w1_half[0].x3 && u0.tail[0].w1_half[1].x3 &&
+                     u0.tail[0].w2.x3 && u0.tail[1].w1.x3 && u0.tail[1].w2.x3;
+  R.blocked = net->blocked && (net->dtype != TL_F32 || x3_l1) && u0.C == 32 && u0.deeper && u0.tail[0].w1_half[0].w && u0.tail[0].w1_half[1].w &&
               n1 >= kBlkMinRows && n1 <= kBlkMaxRows;
   a->blocked_used = R.blocked;
   int64_t cur = 0;

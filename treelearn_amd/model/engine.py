@@ -66,7 +66,7 @@ class _Res:
         # conv runs as its two input-channel halves -- the second launch takes the first one's result as its residual
         w = cb[2].weight
         self.w1_halves = None
-        if w.shape[-1] == 64 and w.shape[0] == 32 and dtype != torch.float32:
+        if w.shape[-1] == 64 and w.shape[0] == 32 and (dtype != torch.float32 or ops.PACK_X3):
             self.w1_halves = (ops.pack_weight(w[..., :32], dtype), ops.pack_weight(w[..., 32:], dtype))
 
     def run(self, x_raw, x_act, nbr, n, views):
@@ -222,8 +222,10 @@ class InferencePlan:
         self.b2 = torch.cat([model.semantic_linear[3].bias.detach().float(), model.offset_linear[3].bias.detach().float()]).contiguous()
 
     def supports_blocked(self):
-        """Level 1 may live in the block-local row order (geometry.BlockedRulebook): the pre-activated 16-bit engine of a 32-channel net."""
-        return self.preact and self.dtype != torch.float32 and self.unet.C == 32 and os.environ.get("TL_BLK", "1") != "0"
+        """Level 1 may live in the block-local row order (geometry.BlockedRulebook): the pre-activated engine of a 32-channel net in a 16-bit
+        dtype or in the parity-fast mode (fp32 rows, split-bf16 contraction: tl_conv_blk_x3.hip; TL_BLK_X3=0 keeps that mode on the gather kernels)."""
+        ok_dtype = self.dtype != torch.float32 or (self.x3 and os.environ.get("TL_BLK_X3", "1") != "0")
+        return self.preact and ok_dtype and self.unet.C == 32 and os.environ.get("TL_BLK", "1") != "0"
 
     def run(self, voxel_feats, geom: TileGeometry, want_backbone=True, all_ones=False):
         """`all_ones`: the caller built voxel_feats as ones (use_feats = False, use_coords = False): the input conv then needs no gather."""
