@@ -373,14 +373,18 @@ def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
     model.load_state_dict(random_state_dict(7, channels=32, num_blocks=7), strict=True)
     gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
     if trained_like:
-        # "trained-like" weights: the synthetic ones with every BatchNorm's running statistics re-estimated on this tile (two
-        # training-mode forwards, untimed).  A random-init net with arbitrary running statistics reaches 1e5 > fp16's 65504 in places;
-        # a trained net's activations are O(1), which is what fp16 inference presumes (the reference relies on it under autocast)
+        # "trained-like" weights: the synthetic ones with every BatchNorm's running statistics set to this tile's statistics (one
+        # training-mode forward at momentum 1, untimed).  A random-init net with arbitrary running statistics reaches 1e5 > fp16's 65504 in
+        # places; a trained net's activations are O(1), which is what fp16 inference presumes (the reference relies on it under autocast)
         model.compute_dtype = torch.bfloat16
         model = model.cuda().train()
+        bns = [m_ for m_ in model.modules() if isinstance(m_, torch.nn.BatchNorm1d)]
+        for m_ in bns:
+            m_.momentum = 1.0
         with torch.no_grad():
-            for _ in range(2):
-                model(gb, return_loss=False)
+            model(gb, return_loss=False)
+        for m_ in bns:
+            m_.momentum = 0.1
         model.compute_dtype = dtype
     model = model.cuda().eval()
 
@@ -411,7 +415,7 @@ def forward_block(workload, dtype_name, steps, warmup, nfl, trained_like=False):
         f, b, _ = conv_work(m); fl += f; by += b
     ach = by / (ms * 1e-3) / 1e9
     out = dict(value=n_pts / sec / 1e6, unit="Mpoints/s", ms_per_step=sec * 1e3, steps=steps, warmup=warmup, dtype=dtype_name, tiles_in_flight=nfl,
-               weights="synthetic, BatchNorm running statistics re-estimated on the tile (trained-like)" if trained_like else "synthetic random init",
+               weights="synthetic, BatchNorm running statistics = the tile's batch statistics (trained-like)" if trained_like else "synthetic random init",
                nonfinite_outputs=nonfinite, active_voxels=(model._plan._exec.last["level_n"][0] if getattr(model._plan, "_exec", None) else None),
                peak_hbm_gb=(torch.cuda.max_memory_allocated() - mem0) / 1e9,
                workload=f"{workload}: single {cfg['extent']:.0f}x{cfg['extent']:.0f} m tile, voxel {cfg['voxel']} m, {n_pts} points, {model.num_blocks}-level 32-ch sparse U-Net fwd",

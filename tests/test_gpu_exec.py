@@ -308,7 +308,7 @@ def test_exec_serves_voxel_mean_features(dtype, flags):
     m = m.cuda().eval()
     out_c, out_p, ex = _both(m, gb)
     assert ex.needs_feats and ex.last["level_n"][0] < 0.6 * gb["coords"].shape[0]            # several points per voxel
-    assert ex.last["blocked"] == (dtype == torch.bfloat16)
+    assert ex.last["blocked"] == (dtype != torch.float32)      # (16-bit and the parity-fast mode run level 1 in the block-local order)
     _assert_equal(out_c, out_p)
     # ... and the features matter: the all-ones net on the same weights gives something else
     ones = _model(dtype if dtype != "bf16x3" else torch.float32)

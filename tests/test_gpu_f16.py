@@ -60,15 +60,21 @@ def test_conv_fwd_f16_vs_oracle(cin, cout, K, n_out, one_hot):
 
 
 def _trained_like(voxel, sshape, batch, seed=11):
-    """Synthetic weights with BatchNorm statistics re-estimated on the tile (a random-init net with arbitrary running statistics
-    saturates and reaches 1e5 in places; re-estimated ones keep activations O(1) like a trained net's)."""
+    """Synthetic weights with every BatchNorm's running statistics SET to the statistics of this tile (one training-mode forward with
+    momentum 1: running = batch statistics, what a converged net has seen of such data).  A random-init net with arbitrary running
+    statistics saturates and reaches 1e5 in places -- and so does one whose statistics were only blended towards the data (two passes at
+    the default momentum 0.1 leave 81 % of the arbitrary initial values: 845 of 95 M outputs overflow fp16 on the 19 M-point tile)."""
     from treelearn_amd.model import TreeLearn
     m = TreeLearn(use_feats=False, use_coords=False, spatial_shape=sshape, voxel_size=voxel, compute_dtype=torch.bfloat16)
     m.load_state_dict(random_state_dict(seed, channels=32, num_blocks=7), strict=True)
     m = m.cuda().train()
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)]
+    for mod in bns:
+        mod.momentum = 1.0
     with torch.no_grad():
-        for _ in range(2):
-            m(batch, return_loss=False)                       # module-by-module path, batch statistics -> the running statistics move
+        m(batch, return_loss=False)                           # module-by-module path, batch statistics -> the running statistics
+    for mod in bns:
+        mod.momentum = 0.1
     return m.eval()
 
 

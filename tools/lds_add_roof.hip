@@ -28,9 +28,8 @@ __global__ void __launch_bounds__(512) k(const int* __restrict__ rows, int iters
   for (int i = 0; i < 16; ++i) { c[0][i] = 0.f; c[1][i] = 0.f; }
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
-  const int* rw = rows + (blockIdx.x * 8 + wv) * 32 * 64;          // per wave: 64 tile-taps x 32 compacted rows -> output row in the unit
+  const int salt = rows[(blockIdx.x * 8 + wv) & 1023];            // (one load per wave, outside the loop: the row pattern is arithmetic)
   for (int it = 0; it < iters; ++it) {
-    const int* r = rw + (it & 63) * 32;
     if (MODE == 2 || MODE == 3) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -45,7 +44,7 @@ __global__ void __launch_bounds__(512) k(const int* __restrict__ rows, int iters
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const int m = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-          const int orow = r[m];                                    // (scalar-ish: 2 distinct rows per instruction)
+          const int orow = (it * 37 + salt + m * 5) & 255;          // 32 distinct output rows of the unit per compacted tile, 2 per instruction
           float* dst = acc + orow * 64 + nb * 32 + (lane & 31);
           const float v = (MODE == 3) ? c[nb][g] : 1.0f;
           if (MODE == 1) *(volatile float*)dst = v;
@@ -93,11 +92,11 @@ int main() {
     // clock: the MFMA run is 8 x 32 cycles per item per SIMD, waves / 4 waves per SIMD
     const double mfma_cycles = 8.0 * 32.0 * iters * (waves / 4.0);
     const double ghz = mfma_cycles / (ms[2] * 1e-3) / 1e9;
-    for (int m = 0; m < 4; ++m)
-      printf("  %-52s %8.3f ms = %7.1f cycles per item per wave at the MFMA run's %.2f GHz (%.1f per CU-wide item set of 4 SIMDs)\n", names[m], ms[m],
-             ms[m] * 1e-3 * ghz * 1e9 / iters / (waves / 4.0), ghz, ms[m] * 1e-3 * ghz * 1e9 / iters / (waves / 4.0));
+    for (int m = 0; m < 4; ++m)                                     // CU time per item: the four SIMDs of a CU work on four items at once
+      printf("  %-52s %8.3f ms = %7.1f cycles of CU time per (tile, tap) item at the MFMA run's %.2f GHz (= %.1f x the item's 8 MFMAs)\n", names[m], ms[m],
+             ms[m] * 1e-3 * ghz * 1e9 / iters / waves, ghz, ms[m] / ms[2]);
   }
-  printf("reading: a present-pairs kernel at level 2 saves 0.40 x 8 MFMAs = 102 SIMD-cycles per dense (tile, tap) and pays the `add` line per COMPACTED\n"
-         "(tile, tap), 0.60 of them -- if add >= 170 cycles per item per wave the scatter alone costs what the skipped MFMAs save.\n");
+  printf("reading: a present-pairs kernel at level 2 saves 0.40 of the dense form's MFMAs (26 of 64 cycles of CU time per dense (tile, tap)) and pays the\n"
+         "`add` line for 0.60 of them -- it loses as soon as `add` exceeds 43 cycles of CU time per item (0.67 x the item's MFMAs).\n");
   return 0;
 }
