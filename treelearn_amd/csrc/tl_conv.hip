@@ -400,6 +400,7 @@ int tl_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
   if (!strcmp(key, "streamq")) { g_streamq = (int)value; return TL_OK; }
   if (!strcmp(key, "stream_rb")) return tl_stream_set_rb((int)value);
+  if (!strcmp(key, "x3_chunks")) return tl_conv_blk_x3_set_chunks((int)value);
   if (!strcmp(key, "small_rows")) { g_small_rows = value; return TL_OK; }
   if (!strcmp(key, "small_mode")) { g_small_mode = (int)value; return TL_OK; }
   if (!strcmp(key, "head_mode")) { g_head_mode = (int)value; return TL_OK; }

@@ -43,6 +43,7 @@ static __device__ __forceinline__ uint32_t rb_word(const RbRow& r, int w) { retu
 struct X3P {                                   // what differs between the two launches of one conv
   int slice;                                   // 16-channel slice of the 32 input channels this launch contracts (weights' J)
   int part;                                    // != 0: add the sums already in `out` (the previous slice's launch)
+  int chunk, nchunks;                          // this launch serves chunk `chunk` of `nchunks` of every XCD's range of units
 };
 
 // RES: fp32 residual; NV: output views; the last launch of a conv carries RES / NV / affines, the first one NV = 1 raw.
@@ -96,7 +97,9 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk_x3(ConvP p, X3P xp) {
   const int nunits = p.blk_counter[0];
   const int q8 = (nunits + 7) >> 3;
   const int xcd = (int)blockIdx.x & 7, wgx = (int)blockIdx.x >> 3;
-  const int ulo = xcd * q8, uhi = ulo + q8 < nunits ? ulo + q8 : nunits;
+  const int xlo = xcd * q8, xhi = xlo + q8 < nunits ? xlo + q8 : nunits;
+  const int qc = (q8 + xp.nchunks - 1) / xp.nchunks;
+  const int ulo = xlo + xp.chunk * qc, uhi = ulo + qc < xhi ? ulo + qc : xhi;
   const int nw = ((int)gridDim.x >> 3) * W;
   const int u0 = ulo + wgx * W + wv;
   const i32x4* units = reinterpret_cast<const i32x4*>(p.blk_unit);
@@ -366,6 +369,8 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk_x3(ConvP p, X3P xp) {
   }
 }
 
+int g_x3_chunks = 2;
+
 template <int W, bool RES, int NV>
 int launch_x3(const ConvP& p, const X3P& xp, hipStream_t s) {
   constexpr size_t lds = (size_t)WS_B + AFF_B + (size_t)W * STAGE_B;
@@ -389,16 +394,30 @@ int tl_launch_conv_blk_x3(const ConvP& p, hipStream_t s) {
   if (big(p.in_ld) || big(p.out_ld) || (p.out2 && big(p.out2_ld)) || (p.res && big(p.res_ld))) return TL_ERR_UNSUPPORTED;
   auto al16 = [](const void* q, int64_t ld) { return ((uintptr_t)q) % 16 == 0 && ld % 4 == 0; };
   if (!al16(p.in, p.in_ld) || !al16(p.out, p.out_ld) || (p.out2 && !al16(p.out2, p.out2_ld)) || (p.res && !al16(p.res, p.res_ld)) || ((uintptr_t)p.w_x3) % 16) return TL_ERR_UNSUPPORTED;
-  // launch 1: input channels 0..15 -> raw sums in `out`
+  // launch A: input channels 0..15 -> raw sums in `out`;  launch B: input channels 16..31, + the sums of launch A, + the residual, -> the
+  // requested views.  The rows are served in `nchunks` chunks, A and B of a chunk back to back, so that B finds A's sums (128 B per row) in the
+  // memory-side cache instead of HBM (tl_set_tuning "x3_chunks"; large levels only: every launch stages its 54 KB of weights per workgroup)
   ConvP a = p;
   a.res = nullptr; a.res_ld = 0; a.out_scale = a.out_shift = nullptr; a.out_relu = 0; a.out2 = nullptr; a.out2_scale = a.out2_shift = nullptr; a.out2_relu = 0;
-  int rc = launch_x3<8, false, 1>(a, X3P{0, 0}, s);
-  if (rc != TL_OK) return rc;
-  // launch 2: input channels 16..31, + the sums of launch 1, + the residual, -> the requested views
   ConvP b = p;
   b.in = static_cast<const float*>(p.in) + 16;
   if (p.in_scale) { b.in_scale = p.in_scale + 16; b.in_shift = p.in_shift + 16; }
-  const X3P xb{1, 1};
-  if (p.res) return p.out2 ? launch_x3<8, true, 2>(b, xb, s) : launch_x3<8, true, 1>(b, xb, s);
-  return p.out2 ? launch_x3<8, false, 2>(b, xb, s) : launch_x3<8, false, 1>(b, xb, s);
+  int nchunks = 1;
+  if (g_x3_chunks > 0) {                                      // at least g_x3_chunks, and no chunk's sums above ~120 MB (the memory-side cache holds 256 MB)
+    const int64_t by_size = (p.n_out * 128 + (120ll << 20) - 1) / (120ll << 20);
+    nchunks = (int)(by_size > g_x3_chunks ? by_size : g_x3_chunks);
+    if (nchunks > 32) nchunks = 32;
+    while (nchunks > 1 && p.n_out / nchunks < 400000) --nchunks;
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    int rc = launch_x3<8, false, 1>(a, X3P{0, 0, c, nchunks}, s);
+    if (rc != TL_OK) return rc;
+    const X3P xb{1, 1, c, nchunks};
+    if (p.res) rc = p.out2 ? launch_x3<8, true, 2>(b, xb, s) : launch_x3<8, true, 1>(b, xb, s);
+    else rc = p.out2 ? launch_x3<8, false, 2>(b, xb, s) : launch_x3<8, false, 1>(b, xb, s);
+    if (rc != TL_OK) return rc;
+  }
+  return TL_OK;
 }
+
+int tl_conv_blk_x3_set_chunks(int n) { g_x3_chunks = n; return TL_OK; }

@@ -29,7 +29,7 @@ __device__ unsigned long long g_tmd[8];   // developer timing mode (ABL bit 16):
 // X3 (fp32 storage only): split-bf16 contraction (tl_conv_internal.h: mma16_x3) on weights in the tl_pack_weight_x3 form
 template <bool BF16, int K, int NB, int UN, int G, int WAVES, int ABL = 0, bool CT = false, bool TR = false, bool OH = false, bool X3 = false>
 __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles, int walk) {
-  static_assert(!X3 || (!BF16 && !OH && !TR), "the split-bf16 contraction: fp32 rows, inference");
+  static_assert(!X3 || (!BF16 && !TR), "the split-bf16 contraction: fp32 rows, inference");
   constexpr bool TM = (ABL & 16) != 0;
   [[maybe_unused]] unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
   auto tick = [&](int seg) __attribute__((always_inline)) {
@@ -162,6 +162,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
       for (int c = 0; c < UN; ++c)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) a1[c][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(base1 + c * UB + j * 32), 0, 0));
+      if constexpr (X3) {
+        // fp32 rows, split-bf16 contraction: the one gathered row is split into its hi | lo halves ONCE, then routed to its tap like the
+        // 16-bit form (the gather form of the parity-fast mode splits eight gathered rows per output row, seven of them absent)
+        u32x4 ah1[UN][2], al1[UN][2];
+#pragma unroll
+        for (int c = 0; c < UN; ++c)
+#pragma unroll
+          for (int J = 0; J < 2; ++J) x3_split8(a1[c][2 * J], a1[c][2 * J + 1], ah1[c][J], al1[c][J]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const bool mine = mytap == k;
+#pragma unroll
+          for (int c = 0; c < UN; ++c)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+              u32x4 avh, avl;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { avh[q] = mine ? ah1[c][J][q] : 0u; avl[q] = mine ? al1[c][J][q] : 0u; }
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) {
+                const char* wb = wl + ((k * UN + c) * COUT + nb * 32) * UB;
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(wb + (((2 * J + fh) ^ swz) * 16));
+                const u32x4 blo = *reinterpret_cast<const u32x4*>(wb + (((4 + 2 * J + fh) ^ swz) * 16));
+                mma16_x3(acc[nb], avh, avl, bh, blo);
+              }
+            }
+        }
+      } else
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const bool mine = mytap == k;
@@ -542,6 +570,10 @@ int dispatch(const ConvP& p, hipStream_t s) {
     if (nb == 2 && un == 4) return launch<true, 1, 2, 4, 1, 16>(p, s);
     if (nb == 3 && un == 6) return launch<true, 1, 3, 6, 1, 8>(p, s);
     if (nb == 4 && un == 8) return launch<true, 1, 4, 8, 1, 8>(p, s);
+  }
+  if constexpr (!BF16 && K == 8) {
+    // ... and the same conv in the parity-fast mode (fp32 rows, split-bf16 weights: 64 KB resident + twelve epilogue buffers)
+    if (p.one_hot && p.w_x3 && p.epi_mode == TL_EPI_NONE && nb == 1 && un == 2) return launch<false, 8, 1, 2, G, 12, 0, false, false, true, true>(p, s);
   }
   // 16-wave workgroups (bf16 only: 128 VGPRs suffice) when the weights leave room for 16 epilogue buffers
 #define TL_D(NB_, UN_)                                                                                               \

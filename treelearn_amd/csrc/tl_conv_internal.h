@@ -342,6 +342,7 @@ int tl_launch_conv_up(const ConvP& p, const int32_t* child, hipStream_t s);   //
 int tl_launch_conv_blk(const ConvP& p, hipStream_t s);                  // 16-bit, 27 taps, 32 -> 32: rows in block-local order, staged units
 #ifndef TL_F16_BUILD
 int tl_launch_conv_blk_x3(const ConvP& p, hipStream_t s);               // fp32 rows, split-bf16 contraction (bf16x3), 27 taps, 32 -> 32: staged units, two 16-channel launches
+int tl_conv_blk_x3_set_chunks(int n);
 #endif
 
 // tl_conv_stream.hip
