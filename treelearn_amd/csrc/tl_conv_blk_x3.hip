@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(W * 64) k_conv_blk_x3(ConvP p, X3P xp) {
   }
 }
 
-int g_x3_chunks = 2;
+int g_x3_chunks = 0;          // tl_set_tuning("x3_chunks"): 0 = one chunk (default: chunking measured slower, profiles/r6_x3/x3_blk.txt)
 
 template <int W, bool RES, int NV>
 int launch_x3(const ConvP& p, const X3P& xp, hipStream_t s) {
@@ -395,8 +395,9 @@ int tl_launch_conv_blk_x3(const ConvP& p, hipStream_t s) {
   auto al16 = [](const void* q, int64_t ld) { return ((uintptr_t)q) % 16 == 0 && ld % 4 == 0; };
   if (!al16(p.in, p.in_ld) || !al16(p.out, p.out_ld) || (p.out2 && !al16(p.out2, p.out2_ld)) || (p.res && !al16(p.res, p.res_ld)) || ((uintptr_t)p.w_x3) % 16) return TL_ERR_UNSUPPORTED;
   // launch A: input channels 0..15 -> raw sums in `out`;  launch B: input channels 16..31, + the sums of launch A, + the residual, -> the
-  // requested views.  The rows are served in `nchunks` chunks, A and B of a chunk back to back, so that B finds A's sums (128 B per row) in the
-  // memory-side cache instead of HBM (tl_set_tuning "x3_chunks"; large levels only: every launch stages its 54 KB of weights per workgroup)
+  // requested views.  Optionally (tl_set_tuning "x3_chunks" > 0) the rows are served in chunks, A and B of a chunk back to back, so that B
+  // would find A's sums (128 B per row) in the memory-side cache -- measured on the config-2 level (237 MB of sums): 0.354 ms unchunked,
+  // 0.362 / 0.368 / 0.398 with 2 / 3 / 4 chunks (every launch stages its 54 KB of weights per workgroup and drains 256 workgroups): off.
   ConvP a = p;
   a.res = nullptr; a.res_ld = 0; a.out_scale = a.out_shift = nullptr; a.out_relu = 0; a.out2 = nullptr; a.out2_scale = a.out2_shift = nullptr; a.out2_relu = 0;
   ConvP b = p;
