@@ -70,6 +70,12 @@ int tl_voxel_point_coords(const float* xyz, const int64_t* batch_ids, int64_t N,
                           uint32_t* ws_minmax, int32_t* pcoords, int32_t* maxc, tl_stream_t stream);
 
 /* Occupancy bitmap of the level-1 grid.  dims = {B, X, Y, Z}; bitmap u64[B*X*Y*ceil(Z/64)] (zeroed here). */
+/* The same for ONE tile (B = 1, what the tile loop's forward passes: tree_learn/util/pipeline.py:83-88), without same-address atomics: the
+ * per-workgroup coordinate maxima are written as rows of `maxc_parts` i32[TL_POINT_COORDS_MAX_PARTS][4] = (max x, max y, max z, error
+ * flag); *n_parts (host) rows are valid and the caller folds them (max / or) after its read-back.  ws: u32[6 * 256].  pcoords as above. */
+#define TL_POINT_COORDS_MAX_PARTS 1024
+int tl_voxel_point_coords_one(const float* xyz, const int64_t* batch_ids, int64_t N, float voxel_size, uint32_t* ws, int32_t* pcoords,
+                              int32_t* maxc_parts, int* n_parts, tl_stream_t stream);
 int tl_bitmap_from_points(const int32_t* pcoords, int64_t N, const int32_t dims[4], uint64_t* bitmap, tl_stream_t stream);
 
 /* Occupancy of the stride-2 coarse grid (SparseConv3d k=2 s=2 output set, reference
@@ -146,6 +152,9 @@ typedef struct tl_level {
    * by rows of this level -- child (entries), parent / inv (index) and, on level 1, v2p (entries) -- are then written in that order.
    * With o2n set, coords / nbr / compact of the level may be NULL (the block-local conv kernel needs none of them). */
   const int32_t* o2n;
+  /* optional: the inverse table of this level in its packed form i32[n] = (parent row << 3) | tap, -1 = no parent -- 4 B per row instead of the
+   * 32 B of the one-hot `inv` (tl_conv_args.table_one_hot = 2 reads it).  With inv_packed set, `inv` may be NULL; `parent` may always be NULL. */
+  int32_t* inv_packed;
 } tl_level;
 
 /* coords + every rulebook of every level + (v2p != NULL) the point -> voxel map, in one call.  parent / inv arrays that lie
@@ -223,7 +232,9 @@ typedef struct tl_conv_args {
    * read B operands straight from global memory (the small-level kernel) then load 1 KB contiguous per instruction */
   const void* weight_frag;
   /* != 0: every output row has at most ONE valid table entry (SparseInverseConv3d: the row's parent through its own
-   * octant tap).  Kernels may then gather that single row once and route it to its tap instead of issuing K gathers. */
+   * octant tap).  Kernels may then gather that single row once and route it to its tap instead of issuing K gathers.
+   * 2: `table` is the PACKED form i32[n_out] = (input row << 3) | tap, -1 = none (tl_level.inv_packed; K = 8) -- served by the gather-once
+   * kernels only (16-bit and bf16x3, 64 -> 32): any other shape returns TL_ERR_UNSUPPORTED rather than misreading the table. */
   int32_t table_one_hot;
   /* optional column form of `table` (tl_rulebook_compact; K must be 27), NULL if absent */
   const int32_t* table_compact;

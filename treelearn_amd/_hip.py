@@ -47,7 +47,7 @@ class TileBox(_c.Structure):               # tl_tile_box
 class Level(_c.Structure):                 # tl_level
     _fields_ = [("dims", _c.c_int32 * 4), ("n", _c.c_int64), ("bitmap", _c.c_void_p), ("prefix", _c.c_void_p), ("coords", _c.c_void_p),
                 ("nbr", _c.c_void_p), ("compact", _c.c_void_p), ("child", _c.c_void_p), ("parent", _c.c_void_p), ("inv", _c.c_void_p),
-                ("o2n", _c.c_void_p)]
+                ("o2n", _c.c_void_p), ("inv_packed", _c.c_void_p)]
 
 
 class Blk(_c.Structure):                   # tl_blk
@@ -107,6 +107,7 @@ PROTOTYPES = {
     "tl_error_string": (_c.c_char_p, [_i32]),
     "tl_set_tuning": (_i32, [_c.c_char_p, _i64]),
     "tl_voxel_point_coords": (_i32, [_vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "tl_voxel_point_coords_one": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _c.POINTER(_i32), _vp]),
     "tl_bitmap_from_points": (_i32, [_vp, _i64, _I4, _vp, _vp]),
     "tl_bitmap_down": (_i32, [_vp, _I4, _I3, _vp, _I4, _vp]),
     "tl_scan_ws_words": (_i64, [_i64]),

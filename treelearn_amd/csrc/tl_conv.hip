@@ -379,6 +379,9 @@ extern int g_win_rows, g_win_ct;                  // tl_conv_win.hip
 static int64_t g_win_min_rows = 65536;            // below this a 512-row tiling leaves most CUs idle
 #endif
 
+// (tl_exec.hip: may the forward hand the level-1 inverse conv its packed table?  Developer switches can take the gather-once kernel away.)
+bool tl_conv_one_hot_direct_enabled() { return g_direct && g_direct_oh; }
+
 extern "C" {
 
 int tl_set_tuning(const char* key, int64_t value) {
@@ -442,7 +445,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
   p.out3 = a->out3; p.out3_ld = a->out3_ld; p.out3_scale = a->out3_scale; p.out3_shift = a->out3_shift; p.out3_relu = a->out3_relu;
   if ((a->out2_scale == nullptr) != (a->out2_shift == nullptr) || (a->out3_scale == nullptr) != (a->out3_shift == nullptr)) return TL_ERR_ARG;
   p.nblk = (int)tl_cdiv(a->n_out, TM);
-  p.dbg = g_dbg; p.one_hot = a->table_one_hot && a->table != nullptr;
+  p.dbg = g_dbg; p.one_hot = a->table != nullptr ? a->table_one_hot : 0;
   p.blk_unit = has_blk ? a->blk_unit : nullptr; p.blk_counter = a->blk_counter; p.blk_halo = a->blk_halo; p.blk_lrb = a->blk_lrb;
   p.blk_pmask = a->K == 27 ? a->blk_pmask : nullptr;
   p.epi_mode = a->epi_mode; p.red_part = a->red_part; p.red_nparts = a->red_nparts; p.bn_x = a->bn_x; p.bn_x_ld = a->bn_x_ld;
@@ -459,6 +462,13 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     if (a->red_nparts) *a->red_nparts = 0;
   }
   hipStream_t s = tl_s(stream);
+  if (p.one_hot == 2) {
+    // packed one-hot table (tl_level.inv_packed): only the gather-once form of the direct kernel decodes it (16-bit, or fp32 rows with split-bf16
+    // weights; 8 taps, 64 -> 32) -- everything else would read it as an [8][n] table
+    const bool shape = a->K == 8 && a->Cin == 64 && a->Cout == 32 && !train && !a->in_scale && !a->in_relu && g_direct && g_direct_oh;
+    if (!shape || !(dt == TL_BF16 || (dt == TL_F32 && p.w_x3))) return TL_ERR_UNSUPPORTED;
+    return L_direct(p, dt, s);
+  }
   const bool vec_ok = (a->in_ld % 8 == 0) && (((uintptr_t)a->in) % 16 == 0) && (((uintptr_t)a->weight) % 16 == 0);
   const bool out_vec = (a->out_ld % 8 == 0) && (((uintptr_t)a->out) % 16 == 0) &&
                        (!a->out2 || (a->out2_ld % 8 == 0 && ((uintptr_t)a->out2) % 16 == 0)) && (!a->out3 || (a->out3_ld % 8 == 0 && ((uintptr_t)a->out3) % 16 == 0));

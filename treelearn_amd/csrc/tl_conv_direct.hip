@@ -122,7 +122,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_conv_direct(ConvP p, int ntiles,
       const int64_t row = (int64_t)tile * 32 + fi;
       const bool rvalid = row < p.n_out;
       if constexpr (K == 27 && CT) decode_ctab(p.ctab, p.n_out, row, rvalid, idx);
-      else {
+      else if (OH && p.one_hot == 2) {                            // packed one-hot table: ONE word per row = (input row << 3) | tap
+        const int v = rvalid ? p.table[row] : -1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) idx[k] = (v >= 0 && (v & 7) == k) ? (v >> 3) : -1;
+      } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) idx[k] = rvalid ? ((p.table && !(ABL & 8)) ? p.table[(int64_t)k * p.n_out + row] : (int)row) : -1;
       }
@@ -615,6 +619,7 @@ extern "C" int tl_dev_direct_tm(unsigned long long* out8) {          // read and
 // scratch within LDS, input view below 4 GB.  Returns TL_ERR_UNSUPPORTED when the shape is not covered.
 int tl_launch_conv_direct(const ConvP& p, int dtype, hipStream_t s) {
   if (p.in_scale || p.in_relu) return TL_ERR_UNSUPPORTED;
+  if (p.one_hot == 2 && !(p.K == 8 && p.Cin == 64 && p.Cout == 32 && p.epi_mode == TL_EPI_NONE && (dtype == TL_BF16 || p.w_x3))) return TL_ERR_UNSUPPORTED;
   const int eb = dtype == TL_BF16 ? 2 : 4;
   if (dtype == TL_BF16 && p.Cin == 4 && p.Cout == 32 && p.K <= 28 && p.table && p.in_ld % 4 == 0 && (int64_t)p.n_in * p.in_ld * 2 < 0xFFFF0000ll) {
     const int ntiles = (int)tl_cdiv(p.n_out, 32);

@@ -19,6 +19,7 @@ namespace {
 constexpr int64_t kCompactMinRows = 65536;      // geometry.COMPACT_MIN_ROWS: levels from this size on also get the column form of their rulebook
 constexpr int64_t kBlkMinRows = 16384;          // geometry.BLK_MIN_ROWS / BLK_MAX_ROWS: the level-1 sizes that go into the block-local order
 constexpr int64_t kBlkMaxRows = (1 << 25) - 64;
+constexpr size_t kHostBytes = 64 + (size_t)TL_POINT_COORDS_MAX_PARTS * 16;
 
 struct Ten {                                     // an activation matrix [n, C] (or a column view of a wider one)
   int64_t off = -1;                              // arena offset of the element [0, 0]
@@ -44,13 +45,13 @@ struct Table {
 struct LevelG {
   int32_t dims[4];
   int64_t n = 0;
-  int64_t coords = -1, nbr = -1, ct = -1, child = -1, parent = -1, inv = -1;     // word offsets into the geometry block, -1 = absent
+  int64_t coords = -1, nbr = -1, ct = -1, child = -1, inv = -1, invp = -1;       // word offsets into the geometry block, -1 = absent (no `parent`: the forward never reads it)
 };
 
 }  // namespace
 
 struct tl_exec {
-  int32_t* host = nullptr;                       // pinned: 16 words of read-back
+  int32_t* host = nullptr;                       // pinned: 16 words of read-back + TL_POINT_COORDS_MAX_PARTS rows of per-workgroup extents
   hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_flag = nullptr;
   bool flag_in_flight = false;                   // a unit-builder flag read-back has been enqueued and not been waited for yet
   bool profile = false;
@@ -100,7 +101,13 @@ struct Run {
     return t;
   }
   Table down(int li) const { Table t; t.table = gw(lv[li].child); return t; }
-  Table up(int li) const { Table t; t.table = gw(lv[li].inv); t.scatter = gw(lv[li].child); t.one_hot = 1; return t; }
+  Table up(int li) const {
+    Table t;
+    t.scatter = gw(lv[li].child);
+    if (lv[li].invp >= 0) { t.table = gw(lv[li].invp); t.one_hot = 2; }       // packed: (parent << 3) | tap per row
+    else { t.table = gw(lv[li].inv); t.one_hot = 1; }
+    return t;
+  }
 
   // one tl_conv_fwd launch, arguments as ops.conv_fwd fills them; `outs` receives the result matrices in the order of `views`
   void conv(int level, int kind, const Ten& x, const tl_weight& w, const Table& tb, int64_t n_out, const ViewReq* views, int nviews, Ten* outs,
@@ -319,7 +326,7 @@ extern "C" {
 tl_exec* tl_exec_create(void) {
   tl_exec* ex = new (std::nothrow) tl_exec();
   if (!ex) return nullptr;
-  if (hipHostMalloc(reinterpret_cast<void**>(&ex->host), 64, hipHostMallocDefault) != hipSuccess || (memset(ex->host, 0, 64), false) ||
+  if (hipHostMalloc(reinterpret_cast<void**>(&ex->host), kHostBytes, hipHostMallocDefault) != hipSuccess || (memset(ex->host, 0, kHostBytes), false) ||
       hipEventCreateWithFlags(&ex->ev_main, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ex->ev_side, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ex->ev_flag, hipEventDisableTiming) != hipSuccess) {
     tl_exec_destroy(ex);
@@ -390,13 +397,22 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
   R.ar.base = static_cast<char*>(a->arena); R.ar.cap = a->arena_bytes; R.ar.dry = false;
 
   // ---- phase A: per-point voxel coordinates + grid extent (geometry.build_geometry step 1; tree_learn.py:133-135)
-  const int64_t o_pc = R.ar.take(16 * N), o_maxc = R.ar.take(16), o_mm = R.ar.take(24 * (int64_t)a->B);
+  const bool one = a->B == 1;                         // one tile: the atomic-free form, per-workgroup extents folded here after the read-back
+  const int64_t o_pc = R.ar.take(16 * N), o_maxc = R.ar.take(one ? 16 * TL_POINT_COORDS_MAX_PARTS : 16), o_mm = R.ar.take(one ? 24 * 256 : 24 * (int64_t)a->B);
   if (R.ar.peak > R.ar.cap) { a->needed_bytes = R.ar.peak * 3; return TL_ERR_ARENA; }        // (a first guess; the exact figure follows once the counts are known)
   int32_t* pcoords = reinterpret_cast<int32_t*>(R.ar.at(o_pc));
-  int rc = tl_voxel_point_coords(a->xyz, a->batch_ids, N, a->B, net->voxel_size, reinterpret_cast<uint32_t*>(R.ar.at(o_mm)), pcoords,
-                                 reinterpret_cast<int32_t*>(R.ar.at(o_maxc)), stream);
+  int rc, n_parts = 0;
+  if (one) rc = tl_voxel_point_coords_one(a->xyz, a->batch_ids, N, net->voxel_size, reinterpret_cast<uint32_t*>(R.ar.at(o_mm)), pcoords,
+                                          reinterpret_cast<int32_t*>(R.ar.at(o_maxc)), &n_parts, stream);
+  else rc = tl_voxel_point_coords(a->xyz, a->batch_ids, N, a->B, net->voxel_size, reinterpret_cast<uint32_t*>(R.ar.at(o_mm)), pcoords,
+                                  reinterpret_cast<int32_t*>(R.ar.at(o_maxc)), stream);
   if (rc != TL_OK) return rc;
-  if (hipMemcpyAsync(ex->host, R.ar.at(o_maxc), 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return TL_ERR_LAUNCH;   // host sync #1
+  if (one) {
+    if (hipMemcpyAsync(ex->host + 16, R.ar.at(o_maxc), 16 * (size_t)n_parts, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return TL_ERR_LAUNCH;   // host sync #1
+    for (int j = 0; j < 4; ++j) ex->host[j] = 0;
+    for (int q = 0; q < n_parts; ++q)
+      for (int j = 0; j < 4; ++j) ex->host[j] = ex->host[j] > ex->host[16 + 4 * q + j] ? ex->host[j] : ex->host[16 + 4 * q + j];
+  } else if (hipMemcpyAsync(ex->host, R.ar.at(o_maxc), 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return TL_ERR_LAUNCH;   // host sync #1
   ex->flag_in_flight = false;           // (the flag copy of the previous forward on this context was enqueued on a stream this forward just drained ...
   if (ex->host[3]) return TL_ERR_EXTENT;
   if (ex->host[8]) {                    // ... so its verdict is in: the block-local builder's error flag of the PREVIOUS forward, unless tl_exec_check took it)
@@ -468,8 +484,14 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
     R.o_lrb = take(9 * n1); R.o_pmask = take(n1); o_bws = take(nbws);
     if (feats) R.o_nn = take(27 * n1);            // the input conv of real features gathers: the plain table in the block-local order (tl_blk.nn)
   }
+  // inverse tables (pre-set to -1 by one fill).  Level 1's inverse conv (64 -> 32) runs on the gather-once kernel in the 16-bit dtypes and in
+  // bf16x3: that kernel reads the packed form, 4 B per row instead of the 32 B of the one-hot table (59 MB less to fill, write and read per tile)
+  const bool packed0 = nl > 1 && net->u[0].C == 32 && net->u[1].C == 64 && (net->dtype != TL_F32 || net->u[0].wu.x3) && tl_conv_one_hot_direct_enabled();
   const int64_t o_m1 = cur;
-  for (int l = 0; l + 1 < nl; ++l) { R.lv[l].parent = take(R.lv[l].n); R.lv[l].inv = take(8 * R.lv[l].n); }
+  for (int l = 0; l + 1 < nl; ++l) {
+    if (l == 0 && packed0) R.lv[l].invp = take(R.lv[l].n);
+    else R.lv[l].inv = take(8 * R.lv[l].n);
+  }
   const int64_t o_m1_end = cur;
   R.g0 = R.ar.take(4 * cur);
 
@@ -490,7 +512,7 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
     for (int j = 0; j < 4; ++j) t.dims[j] = v.dims[j];
     t.n = v.n;
     t.bitmap = reinterpret_cast<const uint64_t*>(p0 + 8 * woff[l]); t.prefix = reinterpret_cast<const uint32_t*>(p0 + 8 * tw + 4 * woff[l]);
-    t.coords = W(v.coords); t.nbr = W(v.nbr); t.compact = W(v.ct); t.child = W(v.child); t.parent = W(v.parent); t.inv = W(v.inv); t.o2n = nullptr;
+    t.coords = W(v.coords); t.nbr = W(v.nbr); t.compact = W(v.ct); t.child = W(v.child); t.parent = nullptr; t.inv = W(v.inv); t.inv_packed = W(v.invp); t.o2n = nullptr;
   }
   hipStream_t side = s;
   // whatever happens after the fork below, `s` waits for the side stream before this call returns: the caller may reuse or free the arena

@@ -142,6 +142,102 @@ __global__ void __launch_bounds__(kBlock) k_point_coords(const float* __restrict
   }
 }
 
+// ---- single-tile form of the two kernels above (B = 1: the tile loop's forward).  Same arithmetic, NO same-address atomics (they retire at
+// ~12 ns each: 256 x 6 of them were 18 of k_minmax's 30 us): every workgroup writes its partial minimum / maximum, k_point_coords_one folds
+// the <= 256 partials at its start (one per thread), and its own per-workgroup maxima go home as they are -- the caller reads them back
+// with the 16-byte extent it already waits for and folds them on the host.
+__global__ void __launch_bounds__(kBlock) k_minmax_one(const float* __restrict__ xyz, const int64_t* __restrict__ bid, int64_t N_all,
+                                                       uint32_t* __restrict__ parts) {
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  auto take = [&](int64_t b, float x, float y, float z) {
+    if (b != 0) return;                                          // (an id outside [0, B) is reported by k_point_coords_one)
+    const uint32_t e[3] = {enc_f32(x), enc_f32(y), enc_f32(z)};
+    for (int j = 0; j < 3; ++j) { lo[j] = min(lo[j], e[j]); hi[j] = max(hi[j], e[j]); }
+  };
+  const int64_t per_blk = (N_all + gridDim.x - 1) / gridDim.x;
+  const int64_t lo_i = (int64_t)blockIdx.x * per_blk, N = min(N_all, lo_i + per_blk);
+  const int64_t stride = blockDim.x;
+  int64_t i = lo_i + threadIdx.x;
+  for (; i + 3 * stride < N; i += 4 * stride) {
+    int64_t b[4]; float p[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = i + u * stride;
+      b[u] = bid[q]; p[u][0] = xyz[q * 3]; p[u][1] = xyz[q * 3 + 1]; p[u][2] = xyz[q * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(b[u], p[u][0], p[u][1], p[u][2]);
+  }
+  for (; i < N; i += stride) take(bid[i], xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]);
+  __shared__ uint32_t red[kBlock / 64][6];
+  for (int j = 0; j < 3; ++j)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[j] = min(lo[j], (uint32_t)__shfl_xor((int)lo[j], off));
+      hi[j] = max(hi[j], (uint32_t)__shfl_xor((int)hi[j], off));
+    }
+  if ((threadIdx.x & 63) == 0) { for (int j = 0; j < 3; ++j) { red[threadIdx.x >> 6][j] = lo[j]; red[threadIdx.x >> 6][3 + j] = hi[j]; } }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int j = threadIdx.x;
+    uint32_t v = red[0][j];
+    for (int w = 1; w < kBlock / 64; ++w) v = j < 3 ? min(v, red[w][j]) : max(v, red[w][j]);
+    parts[blockIdx.x * 6 + j] = v;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_point_coords_one(const float* __restrict__ xyz, const int64_t* __restrict__ bid, int64_t N, float vs,
+                                                             const uint32_t* __restrict__ parts, int nparts, int32_t* __restrict__ pc,
+                                                             int32_t* __restrict__ maxc_parts) {
+  static_assert(kBlock >= 256, "one partial per thread");
+  __shared__ uint32_t sred[kBlock / 64][3];
+  __shared__ float smn[3];
+  {
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if ((int)threadIdx.x < nparts) { for (int j = 0; j < 3; ++j) lo[j] = parts[threadIdx.x * 6 + j]; }
+    for (int j = 0; j < 3; ++j)
+      for (int off = 32; off > 0; off >>= 1) lo[j] = min(lo[j], (uint32_t)__shfl_xor((int)lo[j], off));
+    if ((threadIdx.x & 63) == 0) { for (int j = 0; j < 3; ++j) sred[threadIdx.x >> 6][j] = lo[j]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      uint32_t v = sred[0][threadIdx.x];
+      for (int w = 1; w < kBlock / 64; ++w) v = min(v, sred[w][threadIdx.x]);
+      smn[threadIdx.x] = dec_f32(v);
+    }
+    __syncthreads();
+  }
+  const float mn[3] = {smn[0], smn[1], smn[2]};
+  int mx[3] = {0, 0, 0};
+  int err = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = bid[i];
+    int c[3] = {0, 0, 0};
+    if (b != 0) {
+      err = 1;
+    } else {
+      for (int j = 0; j < 3; ++j) {
+        const float q = floorf(__fdiv_rn(__fsub_rn(xyz[i * 3 + j], mn[j]), vs));
+        int v = (int)q;
+        if (!(q >= 0.f) || q >= 65536.f) { err = 1; v = 0; }
+        c[j] = v;
+        mx[j] = max(mx[j], v);
+      }
+    }
+    reinterpret_cast<int4*>(pc)[i] = make_int4((int)b, c[0], c[1], c[2]);
+  }
+  __shared__ int smx[kBlock / 64][4];
+  for (int j = 0; j < 3; ++j) {
+    for (int off = 32; off > 0; off >>= 1) mx[j] = max(mx[j], __shfl_xor(mx[j], off));
+  }
+  err = __any(err);
+  if ((threadIdx.x & 63) == 0) { for (int j = 0; j < 3; ++j) smx[threadIdx.x >> 6][j] = mx[j]; smx[threadIdx.x >> 6][3] = err; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int e = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { for (int j = 0; j < 3; ++j) mx[j] = max(mx[j], smx[w][j]); e |= smx[w][3]; }
+    reinterpret_cast<int4*>(maxc_parts)[blockIdx.x] = make_int4(mx[0], mx[1], mx[2], e);
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) k_set_bits(const int32_t* __restrict__ pc, int64_t N, TlDims d,
                                                      unsigned long long* __restrict__ bm) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
@@ -199,6 +295,7 @@ __global__ void __launch_bounds__(kBlock) k_bitmap_down(const uint64_t* __restri
 // ---------------------------------------------------------------- popcount exclusive scan (3 passes)
 constexpr int kScanItems = 8;                       // words per thread
 constexpr int kScanTile = kBlock * kScanItems;      // words per block
+constexpr int kScanMaxLevels = 8;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total_out) {
   __shared__ uint32_t wsum[kBlock / 64];
@@ -242,6 +339,60 @@ __global__ void __launch_bounds__(kBlock) k_scan_blocks(uint32_t* __restrict__ p
 __global__ void __launch_bounds__(kBlock) k_scan_final(const uint64_t* __restrict__ bm, int64_t n, const uint32_t* __restrict__ part,
                                                        uint32_t* __restrict__ prefix) {
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t c[kScanItems];
+  uint32_t s = 0;
+  for (int j = 0; j < kScanItems; ++j) { c[j] = (base + j < n) ? __popcll(bm[base + j]) : 0; s += c[j]; }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot) + part[blockIdx.x];
+  for (int j = 0; j < kScanItems; ++j) { if (base + j < n) prefix[base + j] = ex; ex += c[j]; }
+}
+
+// The popcount scans of SEVERAL levels in one launch per pass (tl_pyramid_build: the big levels of the pyramid; their bitmaps are complete
+// before the first pass starts).  Workgroup b works on level l with first[l] <= b < first[l + 1]; the partials of a level are contiguous.
+struct ScanPack {
+  int nl;
+  int first[kScanMaxLevels + 1];
+  int64_t off[kScanMaxLevels];          // word offset of the level's bitmap / prefix
+  int64_t nw[kScanMaxLevels];
+};
+__device__ __forceinline__ int scan_level(const ScanPack& p) {
+  int l = 0;
+  while (l + 1 < p.nl && (int)blockIdx.x >= p.first[l + 1]) ++l;
+  return l;
+}
+__global__ void __launch_bounds__(kBlock) k_scan_partials_multi(const uint64_t* __restrict__ bm_all, ScanPack p, uint32_t* __restrict__ part) {
+  const int l = scan_level(p);
+  const uint64_t* bm = bm_all + p.off[l];
+  const int64_t n = p.nw[l];
+  const int64_t base = (int64_t)(blockIdx.x - p.first[l]) * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+  for (int j = 0; j < kScanItems; ++j) if (base + j < n) s += __popcll(bm[base + j]);
+  uint32_t tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(kBlock) k_scan_blocks_multi(uint32_t* __restrict__ part, ScanPack p, uint32_t* __restrict__ totals) {
+  for (int l = 0; l < p.nl; ++l) {                  // single block: level after level, each walking its own partials
+    uint32_t carry = 0;
+    const int64_t lo = p.first[l], nb = p.first[l + 1] - p.first[l];
+    for (int64_t base = 0; base < nb; base += kBlock) {
+      const int64_t i = base + threadIdx.x;
+      const uint32_t v = i < nb ? part[lo + i] : 0;
+      uint32_t tot;
+      const uint32_t ex = block_exclusive_scan(v, &tot);
+      if (i < nb) part[lo + i] = carry + ex;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) totals[l] = carry;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_scan_final_multi(const uint64_t* __restrict__ bm_all, ScanPack p, const uint32_t* __restrict__ part,
+                                                             uint32_t* __restrict__ prefix_all) {
+  const int l = scan_level(p);
+  const uint64_t* bm = bm_all + p.off[l];
+  uint32_t* prefix = prefix_all + p.off[l];
+  const int64_t n = p.nw[l];
+  const int64_t base = (int64_t)(blockIdx.x - p.first[l]) * kScanTile + (int64_t)threadIdx.x * kScanItems;
   uint32_t c[kScanItems];
   uint32_t s = 0;
   for (int j = 0; j < kScanItems; ++j) { c[j] = (base + j < n) ? __popcll(bm[base + j]) : 0; s += c[j]; }
@@ -393,7 +544,7 @@ __global__ void __launch_bounds__(kBlock) k_rulebook_subm(const int32_t* __restr
 __device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
                                                    const uint32_t* __restrict__ fpf, const TlDims& f, int64_t Mf, int32_t* __restrict__ child,
                                                    int32_t* __restrict__ parent, int32_t* __restrict__ inv, int64_t first, int64_t stride,
-                                                   const int32_t* __restrict__ fo2n = nullptr) {
+                                                   const int32_t* __restrict__ fo2n = nullptr, int32_t* __restrict__ invp = nullptr) {
   for (int64_t q = first; q < Mc; q += stride) {
     const int4 c = reinterpret_cast<const int4*>(cc)[q];
 #pragma unroll
@@ -403,7 +554,11 @@ __device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ c
       if (x < f.X && y < f.Y && z < f.Z) r = tl_rank_at(fbm, fpf, tl_col_word(f, c.x, x, y), z);
       if (fo2n && r >= 0) r = fo2n[r];
       child[(int64_t)k * Mc + q] = r;
-      if (r >= 0) { parent[r] = (int)q; inv[(int64_t)k * Mf + r] = (int)q; }
+      if (r >= 0) {                                   // (each of the three forms is optional: tl_level)
+        if (parent) parent[r] = (int)q;
+        if (inv) inv[(int64_t)k * Mf + r] = (int)q;
+        if (invp) invp[r] = (int)((q << 3) | k);
+      }
     }
   }
 }
@@ -411,8 +566,8 @@ __device__ __forceinline__ void rulebook_down_body(const int32_t* __restrict__ c
 __global__ void __launch_bounds__(kBlock) k_rulebook_down(const int32_t* __restrict__ cc, int64_t Mc, const uint64_t* __restrict__ fbm,
                                                           const uint32_t* __restrict__ fpf, TlDims f, int64_t Mf,
                                                           int32_t* __restrict__ child, int32_t* __restrict__ parent, int32_t* __restrict__ inv,
-                                                          const int32_t* __restrict__ fo2n) {
-  rulebook_down_body(cc, Mc, fbm, fpf, f, Mf, child, parent, inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, fo2n);
+                                                          const int32_t* __restrict__ fo2n, int32_t* __restrict__ invp) {
+  rulebook_down_body(cc, Mc, fbm, fpf, f, Mf, child, parent, inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, fo2n, invp);
 }
 
 // One launch over several small levels: workgroup b works on level l with first[l] <= b < first[l+1].
@@ -549,6 +704,21 @@ int tl_voxel_point_coords(const float* xyz, const int64_t* batch_ids, int64_t N,
   return TL_OK;
 }
 
+// Single-tile form for tl_forward (B = 1; not part of the public header): no atomics, partial results instead.  ws: 6 * 256 words;
+// maxc_parts: [TL_POINT_COORDS_MAX_PARTS][4] words, *n_parts rows of it are written (x, y, z maxima and the error flag of one workgroup each).
+int tl_voxel_point_coords_one(const float* xyz, const int64_t* batch_ids, int64_t N, float voxel_size, uint32_t* ws, int32_t* pcoords,
+                              int32_t* maxc_parts, int* n_parts, tl_stream_t stream) {
+  if (!xyz || !batch_ids || !ws || !pcoords || !maxc_parts || !n_parts || N <= 0 || !(voxel_size > 0.f)) return TL_ERR_ARG;
+  hipStream_t s = tl_s(stream);
+  const int g1 = (int)(tl_grid(N, kBlock * 4) < 256 ? tl_grid(N, kBlock * 4) : 256);
+  const int g2 = (int)(tl_grid(N, kBlock * 2) < TL_POINT_COORDS_MAX_PARTS ? tl_grid(N, kBlock * 2) : TL_POINT_COORDS_MAX_PARTS);
+  k_minmax_one<<<g1, kBlock, 0, s>>>(xyz, batch_ids, N, ws);
+  k_point_coords_one<<<g2, kBlock, 0, s>>>(xyz, batch_ids, N, voxel_size, ws, g1, pcoords, maxc_parts);
+  TL_CHECK_LAUNCH();
+  *n_parts = g2;
+  return TL_OK;
+}
+
 int tl_bitmap_from_points(const int32_t* pcoords, int64_t N, const int32_t dims[4], uint64_t* bitmap, tl_stream_t stream) {
   if (!pcoords || !dims || !bitmap || N <= 0) return TL_ERR_ARG;
   const TlDims d = tl_dims(dims);
@@ -637,7 +807,7 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
   hipStream_t s = tl_s(stream);
   if (hipMemsetAsync(parent, 0xFF, Mf * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   if (hipMemsetAsync(inv, 0xFF, Mf * 8 * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
-  k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv, nullptr);
+  k_rulebook_down<<<tl_grid(Mc, kBlock), kBlock, 0, s>>>(ccoords, Mc, fbitmap, fprefix, tl_dims(fdims), Mf, child, parent, inv, nullptr, nullptr);
   TL_CHECK_LAUNCH();
   return TL_OK;
 }
@@ -647,16 +817,16 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
 int64_t tl_pyramid_ws_words(const int32_t dims0[4], int num_levels, int64_t* level_word_offsets) {
   if (!dims0 || num_levels < 1 || num_levels > kPyrMaxLevels) return -1;
   int32_t d[4] = {dims0[0], dims0[1], dims0[2], dims0[3]};
-  int64_t off = 0, mx = 0;
+  int64_t off = 0, ws = 0;
   for (int l = 0; l < num_levels; ++l) {
     const int64_t nw = tl_nwords(tl_dims(d));
     if (level_word_offsets) level_word_offsets[l] = off;
     off += nw;
-    if (nw > mx) mx = nw;
+    ws += tl_scan_ws_words(nw);                          // one partial per scan tile of EVERY level: the big levels are scanned in one launch per pass
     for (int j = 1; j < 4; ++j) d[j] = (d[j] + 1) / 2;
   }
   if (level_word_offsets) level_word_offsets[num_levels] = off;
-  return tl_scan_ws_words(mx);
+  return ws;
 }
 
 int tl_pyramid_build(const int32_t* pcoords, int64_t N, const int32_t dims0[4], const int32_t shape0[3], int num_levels,
@@ -679,17 +849,22 @@ int tl_pyramid_build(const int32_t* pcoords, int64_t N, const int32_t dims0[4], 
   }
   if (hipMemsetAsync(bitmaps, 0, tl_nwords(d[0]) * 8, s) != hipSuccess) return TL_ERR_LAUNCH;
   k_set_bits<<<tl_grid(N, kBlock), kBlock, 0, s>>>(pcoords, N, d[0], reinterpret_cast<unsigned long long*>(bitmaps));
+  // the big levels: every bitmap first (one down-sampling launch per level), then ONE three-pass popcount scan over all of them (eleven small
+  // dependent launches were five microseconds each on the path to the second read-back; the per-level entry points above keep the plain form)
   int l = 0;
+  ScanPack sp;
+  sp.first[0] = 0;
   for (; l < num_levels; ++l) {
     const int64_t nw = tl_nwords(d[l]);
     if (l > 0 && nw <= kPyrSmallWords) break;           // the rest goes into one workgroup
     if (l > 0)
       k_bitmap_down<<<tl_grid(nw, kBlock), kBlock, 0, s>>>(bitmaps + off[l - 1], d[l - 1], out[l][0], out[l][1], out[l][2], bitmaps + off[l], d[l]);
-    const int64_t nb = tl_cdiv(nw, kScanTile);
-    k_scan_partials<<<(unsigned)nb, kBlock, 0, s>>>(bitmaps + off[l], nw, ws);
-    k_scan_blocks<<<1, kBlock, 0, s>>>(ws, nb, counts + l);
-    k_scan_final<<<(unsigned)nb, kBlock, 0, s>>>(bitmaps + off[l], nw, ws, prefixes + off[l]);
+    sp.off[l] = off[l]; sp.nw[l] = nw; sp.first[l + 1] = sp.first[l] + (int)tl_cdiv(nw, kScanTile);
   }
+  sp.nl = l;
+  k_scan_partials_multi<<<(unsigned)sp.first[l], kBlock, 0, s>>>(bitmaps, sp, ws);
+  k_scan_blocks_multi<<<1, kBlock, 0, s>>>(ws, sp, counts);
+  k_scan_final_multi<<<(unsigned)sp.first[l], kBlock, 0, s>>>(bitmaps, sp, ws, prefixes);
   if (l < num_levels) {
     PyrSmall p;
     p.nl = num_levels - l; p.first = l;
@@ -712,19 +887,22 @@ int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, i
     if ((!lv[l].coords || !lv[l].nbr) && !lv[l].o2n) return TL_ERR_ARG;      // only a level in block-local order may go without them
     if (lv[l].nbr && !lv[l].coords) return TL_ERR_ARG;
     if (l > 0 && !lv[l].coords) return TL_ERR_ARG;                            // the down tables walk the coarse level's coordinates
-    if (l + 1 < num_levels && (!lv[l].child || !lv[l].parent || !lv[l].inv)) return TL_ERR_ARG;
+    if (l + 1 < num_levels && (!lv[l].child || (!lv[l].inv && !lv[l].inv_packed))) return TL_ERR_ARG;     // (parent is optional, inv in at least one form)
+    if (lv[l].inv_packed && lv[l].n >= (1ll << 28)) return TL_ERR_ARG;
   }
   hipStream_t s = tl_s(stream);
   // parent / inv default to -1: one fill when the caller carved them out of one block, else one per array
   auto inside = [&](const int32_t* q, int64_t words) { return minus_one && q >= minus_one && q + words <= minus_one + minus_one_words; };
   if (minus_one && minus_one_words > 0 && hipMemsetAsync(minus_one, 0xFF, minus_one_words * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   for (int l = 0; l + 1 < num_levels; ++l) {
-    if (!inside(lv[l].parent, lv[l].n) && hipMemsetAsync(lv[l].parent, 0xFF, lv[l].n * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
-    if (!inside(lv[l].inv, lv[l].n * 8) && hipMemsetAsync(lv[l].inv, 0xFF, lv[l].n * 32, s) != hipSuccess) return TL_ERR_LAUNCH;
+    if (lv[l].parent && !inside(lv[l].parent, lv[l].n) && hipMemsetAsync(lv[l].parent, 0xFF, lv[l].n * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
+    if (lv[l].inv && !inside(lv[l].inv, lv[l].n * 8) && hipMemsetAsync(lv[l].inv, 0xFF, lv[l].n * 32, s) != hipSuccess) return TL_ERR_LAUNCH;
+    if (lv[l].inv_packed && !inside(lv[l].inv_packed, lv[l].n) && hipMemsetAsync(lv[l].inv_packed, 0xFF, lv[l].n * 4, s) != hipSuccess) return TL_ERR_LAUNCH;
   }
   int small = num_levels;                               // levels small .. L-1 share launches
   for (int l = num_levels - 1; l >= 1; --l) {
-    if (tl_nwords(tl_dims(lv[l].dims)) <= kPyrSmallWords && lv[l].n <= 64 * kPyrSmallWords && !lv[l].compact && !lv[l].o2n && !lv[l - 1].o2n) small = l; else break;
+    if (tl_nwords(tl_dims(lv[l].dims)) <= kPyrSmallWords && lv[l].n <= 64 * kPyrSmallWords && !lv[l].compact && !lv[l].o2n && !lv[l - 1].o2n &&
+        !lv[l].inv_packed && !lv[l - 1].inv_packed) small = l; else break;
   }
   if (num_levels - small < 2) small = num_levels;
   for (int l = 0; l < small; ++l) {
@@ -748,7 +926,7 @@ int tl_rulebooks_build(const tl_level* lv, int num_levels, int32_t* minus_one, i
   }
   for (int l = 0; l + 1 < num_levels && l < small; ++l) {   // fine level l big (or the last big one): its own launch
     const tl_level &f = lv[l], &c = lv[l + 1];
-    k_rulebook_down<<<tl_grid(c.n, kBlock), kBlock, 0, s>>>(c.coords, c.n, f.bitmap, f.prefix, tl_dims(f.dims), f.n, f.child, f.parent, f.inv, f.o2n);
+    k_rulebook_down<<<tl_grid(c.n, kBlock), kBlock, 0, s>>>(c.coords, c.n, f.bitmap, f.prefix, tl_dims(f.dims), f.n, f.child, f.parent, f.inv, f.o2n, f.inv_packed);
   }
   if (p.nl > 1) {                                           // fine levels small .. L-2: workgroups over the coarse rows
     p.nl -= 1;                                              // slots 0 .. nl-2 are fine levels; slot j+1 is read as the coarse one
