@@ -30,7 +30,7 @@ def _packs(w):
     return exact, x3
 
 
-@pytest.mark.parametrize("cin,cout,kind,level", [(32, 32, "subm", 0), (64, 64, "subm", 0), (128, 64, "subm", 0), (96, 96, "subm", 0), (128, 128, "subm", 0),
+@pytest.mark.parametrize("cin,cout,kind,level", [(32, 32, "subm", 0), (64, 64, "subm", 0), (128, 64, "subm", 0), (96, 96, "subm", 0), (192, 96, "subm", 0), (128, 128, "subm", 0),
                                                  (64, 32, "subm", 0), (32, 64, "down", 0), (64, 96, "down", 0), (96, 128, "down", 1)])
 def test_x3_conv_vs_exact_fp32_and_float64(cin, cout, kind, level):
     from treelearn_amd import ops

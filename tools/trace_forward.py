@@ -1,5 +1,5 @@
 """Timeline of ONE lone forward from a rocprofv3 kernel trace (`--kernel-trace --output-format csv`, one tile at a time): every dispatch
-between two occurrences of the marker kernel (default: the first kernel of a forward, k_init_minmax) with its start offset, duration and
+between two occurrences of the marker kernel (default: the first big kernel of a forward, k_minmax*) with its start offset, duration and
 the idle gap in front of it; then the totals per phase (geometry = up to the input conv, network, head).
 
     python tools/trace_forward.py DIR [which forward, default the last complete one] [marker]
@@ -16,7 +16,7 @@ def short(name):
 
 src = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
-marker = sys.argv[3] if len(sys.argv) > 3 else "k_init_minmax"
+marker = sys.argv[3] if len(sys.argv) > 3 else "k_minmax"          # (k_minmax_one in tl_forward's single-tile form, k_minmax otherwise)
 files = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(files[0])))
 cuts = [i for i, r in enumerate(rows) if marker in r[2]]

@@ -61,4 +61,4 @@ __device__ __forceinline__ int tl_rank_at(const uint64_t* __restrict__ bm, const
   return (int)(pf[w] + __popcll(word & (bit - 1)));
 }
 
-bool tl_conv_one_hot_direct_enabled();     // tl_conv.hip: the gather-once (one-hot) form of the direct kernel is switched on (tl_set_tuning)
+bool tl_conv_one_hot_direct_enabled(int64_t n_out);     // tl_conv.hip: the gather-once (one-hot) form of the direct kernel is switched on (tl_set_tuning)

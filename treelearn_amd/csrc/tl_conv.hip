@@ -369,6 +369,7 @@ extern int g_wgrad_rows;                          // tl_wgrad_rows.hip
 extern int g_wgrad_dma, g_wgrad_dense_gx;         // tl_wgrad_dense.hip
 static int g_stream = 1;                          // use the streamed-weights register-gather kernel where it applies
 static int g_streamq = 1;                         // ... and its quad-gather form for bf16 with Cin % 64 == 0
+static int g_streamq_x3 = 1;                      // ... and for fp32 rows in the parity-fast mode (tl_set_tuning "streamq_x3")
 static int g_direct = 1;                          // use the weights-in-LDS direct kernel where it applies
 static int g_direct_oh = 1;                       // ... and its gather-once form for the level-1 inverse conv
 static int g_blk = 1;                             // use the staged-unit kernel when the caller passes the block-local rulebook form
@@ -380,7 +381,7 @@ static int64_t g_win_min_rows = 65536;            // below this a 512-row tiling
 #endif
 
 // (tl_exec.hip: may the forward hand the level-1 inverse conv its packed table?  Developer switches can take the gather-once kernel away.)
-bool tl_conv_one_hot_direct_enabled() { return g_direct && g_direct_oh; }
+bool tl_conv_one_hot_direct_enabled(int64_t n_out) { return g_direct && g_direct_oh && n_out > g_small_rows; }     // (small levels: the small-level kernel serves the conv, from the [8][n] table)
 
 extern "C" {
 
@@ -402,6 +403,7 @@ int tl_set_tuning(const char* key, int64_t value) {
 #endif
   if (!strcmp(key, "stream")) { g_stream = (int)value; return TL_OK; }
   if (!strcmp(key, "streamq")) { g_streamq = (int)value; return TL_OK; }
+  if (!strcmp(key, "streamq_x3")) { g_streamq_x3 = (int)value; return TL_OK; }
   if (!strcmp(key, "stream_rb")) return tl_stream_set_rb((int)value);
   if (!strcmp(key, "x3_chunks")) return tl_conv_blk_x3_set_chunks((int)value);
   if (!strcmp(key, "small_rows")) { g_small_rows = value; return TL_OK; }
@@ -524,6 +526,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       (!a->residual || (a->res_ld % 4 == 0 && ((uintptr_t)a->residual) % 16 == 0)) &&
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
     if (g_direct) { const int rc = L_direct(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
+    if (g_stream && g_streamq && g_streamq_x3 && p.w_x3 && !train && a->n_out > g_small_rows) {     // bf16x3: quad-coalesced gathers where the shape has an instantiation
+      const int rc = tl_launch_conv_streamq_x3(p, s);
+      if (rc != TL_ERR_UNSUPPORTED) return rc;
+    }
     if (g_stream) { const int rc = L_stream(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
   }
   if (train && dt == TL_F32) return TL_ERR_UNSUPPORTED;

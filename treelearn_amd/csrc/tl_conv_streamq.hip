@@ -21,6 +21,7 @@
 // epilogue are those of tl_conv_stream.hip.  Deterministic; all K taps contracted.
 #include "tl_conv_internal.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -58,7 +59,13 @@ static __device__ __forceinline__ void quad_transpose(const u32x4 (&S)[4], u32x4
 // ABL: developer ablation bits (1 no transposition, 2 no gathers, 4 no barrier, 8 no MFMA, 16 timers, 32 MFMAs for taps < 16 only)
 // SP: the input channels are walked in SP slices of PN * 64: step v of the K * SP steps contracts slice v % SP of tap v / SP
 // (same registers and LDS as the PN-wide kernel; 256 -> 128 as SP = 2 x 128 instead of a PN = 4 kernel that spills).
-template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL, int SP = 1>
+// X3 (round 6; fp32 rows, the parity-fast mode "bf16x3"): a 128-B part is 32 fp32 channels.  The gathers and the transposition do not care --
+// afterwards register s of lane half h holds the fp32 channels 16 h + 4 s .. + 3 of the part --, and the pairs (s, s + 2) = (t, t + 2) are
+// exactly the two 16-B pieces x3_split8 turns into the hi / lo operand of weight slot (J = h, fh = t) of tl_pack_weight_x3's layout
+// (channels 16 J + 4 fh + {0..3} and 16 J + 8 + 4 fh + {0..3}), whose rows [K][Cout][Cin / 32][128 B] are byte for byte the weight rows this
+// kernel streams: two k-steps per part, three MFMAs each (lo.Whi + hi.Wlo + hi.Whi), fp32 epilogue.  The split-bf16 form of tl_conv_stream.hip
+// issues one 16-B request per lane and piece (fragment shape); here four adjacent lanes read 64 contiguous bytes.
+template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL, int SP = 1, bool X3 = false>
 __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   constexpr bool TM = (ABL & 16) != 0;
   constexpr int KV = K * SP;
@@ -111,8 +118,8 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  const int in_ld_b = (int)(p.in_ld * 2);
-  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * SP * 2;
+  const int in_ld_b = (int)(p.in_ld * (X3 ? 4 : 2));
+  const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)CIN * SP * 2;          // (CIN * 2 = PN * 128 bytes per slice in either mode)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)in_bytes, 0x00020000);
   const unsigned qoff = (unsigned)(fh * 64 + (lane & 3) * 16);
   const int* iq = iw + ((lane >> 2) & 7) * 4;
@@ -185,6 +192,70 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
     }
   };
   tick(-1);
+  // one step of the tap loop; U = k % DA (and the parity of k: DA is even) as a compile-time constant, so that the register arrays keep
+  // static indices when the loop is NOT fully unrolled (the X3 bodies are three times the size of the bf16 ones: hipcc refuses to unroll
+  // 27 / 54 of them and would otherwise index a[] / bw[] dynamically, i.e. through scratch memory)
+  auto step = [&](int k, auto Uc) __attribute__((always_inline)) {
+    constexpr int U = decltype(Uc)::value;
+    if (k + 1 < KV) store_b((U + 1) & 1, bw[(U + 1) % RW]);
+    if (k + WA < KV) load_b(k + WA, bw[(U + WA) % RW]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TM) { if (k + DA < KV) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (LA + BPT) + BPT)); else asm volatile("s_waitcnt vmcnt(0)"); }
+    tick(0);
+    u32x4 F[RB][PN][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int pp = 0; pp < PN; ++pp) {
+        if constexpr (ABL & 1) { for (int i = 0; i < 4; ++i) F[rb][pp][i] = a[U][rb][pp][i]; }
+        else quad_transpose(a[U][rb][pp], F[rb][pp], o0, o1);
+      }
+    const char* bl = Bs + (U & 1) * COUT * BROW + fi * BROW + fh * 64;
+    if constexpr (X3) {
+#pragma unroll
+      for (int pp = 0; pp < PN; ++pp)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          u32x4 ah[RB], al[RB];
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) x3_split8(F[rb][pp][t], F[rb][pp][2 + t], ah[rb], al[rb]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const char* wb = bl - fh * 64 + nb * 32 * BROW + pp * 128;                      // the unit's 128 B: hi slots 2 J + fh, lo slots 4 + 2 J + fh (J = lane half)
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(wb + (2 * fh + t) * 16);
+            const u32x4 blo = *reinterpret_cast<const u32x4*>(wb + (4 + 2 * fh + t) * 16);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) mma16_x3(acc[rb][nb], ah[rb], al[rb], bh, blo);
+          }
+        }
+    } else
+#pragma unroll
+    for (int pp = 0; pp < PN; ++pp)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const u32x4 bf = *reinterpret_cast<const u32x4*>(bl + nb * 32 * BROW + (pp * 8 + s) * 16);
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            if constexpr ((ABL & 8) != 0) acc[rb][nb][0] += __uint_as_float(F[rb][pp][s][0] ^ bf[0]);
+            else if ((ABL & 32) != 0 && k / SP >= 16) acc[rb][nb][0] += __uint_as_float(F[rb][pp][s][0] ^ bf[0]);
+            else mma16<true>(acc[rb][nb], F[rb][pp][s], bf);
+          }
+        }
+    tick(1);
+    if (k + DA < KV) { issue_a(k + DA, a[U]); if (k + DA + 1 < KV) read_idx(k + DA + 1); }
+    tick(2);
+    if constexpr ((ABL & 4) == 0) { if (k + 1 < KV) __syncthreads(); }
+    tick(3);
+  };
+  if constexpr (X3 && DA == 2 && RW == 1) {
+    for (int k0 = 0; k0 < KV; k0 += 2) {
+      step(k0, std::integral_constant<int, 0>{});
+      if (k0 + 1 < KV) step(k0 + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    // (the 16-bit instantiations keep the fully unrolled loop they were tuned with)
 #pragma unroll
   for (int k = 0; k < KV; ++k) {
     if (k + 1 < KV) store_b((k + 1) & 1, bw[(k + 1) % RW]);
@@ -221,6 +292,7 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
     if constexpr ((ABL & 4) == 0) { if (k + 1 < KV) __syncthreads(); }
     tick(3);
   }
+  }
   if constexpr (TM) {
     if (lane == 0) {
 #pragma unroll
@@ -243,23 +315,24 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
       for (int r = 0; r < 16; ++r) ew[(2 * (r >> 2) + fh + 8 * (r & 3)) * EP + fi] = acc[rb][nb][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      epi_block32<true, EP>(p, ew, lane, r0 + rb * 32, nb * 32, red0[nb], red1[nb]);
+      epi_block32<!X3, EP>(p, ew, lane, r0 + rb * 32, nb * 32, red0[nb], red1[nb]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   if (p.epi_mode != TL_EPI_NONE) epi_finish_wg<W, EP, NB>(p, Es, tid, red0, red1);
 }
 
-template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0, int SP = 1>
+template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0, int SP = 1, bool X3 = false>
 int launch(ConvP p, hipStream_t s) {
   constexpr int OCC = 2;
+  if constexpr (X3) p.w = p.w_x3;
   const size_t wt = 2 * (size_t)NB * 32 * (PN * 128 + 16) + (size_t)W * K * 32 * RB * 4, ep = (size_t)W * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
-  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP>), 160 * 1024)) return TL_ERR_LAUNCH;
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP, X3>), 160 * 1024)) return TL_ERR_LAUNCH;
   p.nblk = (int)tl_cdiv(p.n_out, W * 32 * RB);
-  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP><<<p.nblk, W * 64, lds, s>>>(p);
+  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP, X3><<<p.nblk, W * 64, lds, s>>>(p);
   if (p.red_nparts) *p.red_nparts = p.nblk;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
@@ -322,3 +395,18 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
   }
   return TL_ERR_UNSUPPORTED;
 }
+
+#ifndef TL_F16_BUILD
+// fp32 rows, split-bf16 contraction (p.w_x3 in the tl_pack_weight_x3 layout), 27 taps, Cin a multiple of 32 (one 128-B part per 32 channels)
+int tl_launch_conv_streamq_x3(const ConvP& p, hipStream_t s) {
+  if (!p.w_x3 || p.in_scale || p.in_relu || p.Cin % 32 || p.Cout % 32 || p.K != 27 || p.epi_mode != TL_EPI_NONE || p.Cin >= 256) return TL_ERR_UNSUPPORTED;
+  const int64_t ld_b = p.in_ld * 4, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 4;
+  if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll) || ((uintptr_t)p.w_x3) % 16) return TL_ERR_UNSUPPORTED;
+  const int nb = p.Cout / 32, pn = p.Cin / 32;
+  if (nb == 2 && pn == 2) return launch<27, 2, 2, 2, 8, 1, 0, 1, true>(p, s);          // 64 -> 64   (level 2)
+  if (nb == 2 && pn == 4) return launch<27, 2, 2, 2, 8, 1, 0, 2, true>(p, s);          // 128 -> 64  (level 2 decoder): two 64-channel slices per tap
+  if (nb == 3 && pn == 3) return launch<27, 3, 3, 2, 8, 1, 0, 1, true>(p, s);          // 96 -> 96   (level 3)
+  if (nb == 3 && pn == 6) return launch<27, 3, 3, 2, 8, 1, 0, 2, true>(p, s);          // 192 -> 96  (level 3 decoder)
+  return TL_ERR_UNSUPPORTED;
+}
+#endif

@@ -486,7 +486,7 @@ int tl_forward(tl_exec* ex, const tl_net_desc* net, tl_forward_args* a, tl_strea
   }
   // inverse tables (pre-set to -1 by one fill).  Level 1's inverse conv (64 -> 32) runs on the gather-once kernel in the 16-bit dtypes and in
   // bf16x3: that kernel reads the packed form, 4 B per row instead of the 32 B of the one-hot table (59 MB less to fill, write and read per tile)
-  const bool packed0 = nl > 1 && net->u[0].C == 32 && net->u[1].C == 64 && (net->dtype != TL_F32 || net->u[0].wu.x3) && tl_conv_one_hot_direct_enabled();
+  const bool packed0 = nl > 1 && net->u[0].C == 32 && net->u[1].C == 64 && (net->dtype != TL_F32 || net->u[0].wu.x3) && tl_conv_one_hot_direct_enabled(n1);
   const int64_t o_m1 = cur;
   for (int l = 0; l + 1 < nl; ++l) {
     if (l == 0 && packed0) R.lv[l].invp = take(R.lv[l].n);
