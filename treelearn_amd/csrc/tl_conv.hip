@@ -527,7 +527,7 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
       (!a->out_scale || (((uintptr_t)a->out_scale) % 16 == 0 && ((uintptr_t)a->out_shift) % 16 == 0))) {
     if (g_direct) { const int rc = L_direct(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
     if (g_stream && g_streamq && g_streamq_x3 && p.w_x3 && !train && a->n_out > g_small_rows) {     // bf16x3: quad-coalesced gathers where the shape has an instantiation
-      const int rc = tl_launch_conv_streamq_x3(p, s);
+      const int rc = tl_launch_conv_streamq_x3(p, g_streamq_x3, s);
       if (rc != TL_ERR_UNSUPPORTED) return rc;
     }
     if (g_stream) { const int rc = L_stream(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }

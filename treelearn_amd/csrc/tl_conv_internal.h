@@ -343,7 +343,7 @@ int tl_launch_conv_blk(const ConvP& p, hipStream_t s);                  // 16-bi
 #ifndef TL_F16_BUILD
 int tl_launch_conv_blk_x3(const ConvP& p, hipStream_t s);               // fp32 rows, split-bf16 contraction (bf16x3), 27 taps, 32 -> 32: staged units, two 16-channel launches
 int tl_conv_blk_x3_set_chunks(int n);
-int tl_launch_conv_streamq_x3(const ConvP& p, hipStream_t s);          // fp32 rows, split-bf16 contraction: quad-coalesced gathers (levels 2-3)
+int tl_launch_conv_streamq_x3(const ConvP& p, int mode, hipStream_t s);          // fp32 rows, split-bf16 contraction: quad-coalesced gathers (levels 2-3)
 #endif
 
 // tl_conv_stream.hip

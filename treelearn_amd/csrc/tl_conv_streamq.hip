@@ -398,15 +398,23 @@ int tl_launch_conv_streamq(const ConvP& p, hipStream_t s) {
 
 #ifndef TL_F16_BUILD
 // fp32 rows, split-bf16 contraction (p.w_x3 in the tl_pack_weight_x3 layout), 27 taps, Cin a multiple of 32 (one 128-B part per 32 channels)
-int tl_launch_conv_streamq_x3(const ConvP& p, hipStream_t s) {
+int tl_launch_conv_streamq_x3(const ConvP& p, int mode, hipStream_t s) {
   if (!p.w_x3 || p.in_scale || p.in_relu || p.Cin % 32 || p.Cout % 32 || p.K != 27 || p.epi_mode != TL_EPI_NONE || p.Cin >= 256) return TL_ERR_UNSUPPORTED;
   const int64_t ld_b = p.in_ld * 4, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 4;
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll) || ((uintptr_t)p.w_x3) % 16) return TL_ERR_UNSUPPORTED;
   const int nb = p.Cout / 32, pn = p.Cin / 32;
-  if (nb == 2 && pn == 2) return launch<27, 2, 2, 2, 8, 1, 0, 1, true>(p, s);          // 64 -> 64   (level 2)
-  if (nb == 2 && pn == 4) return launch<27, 2, 2, 2, 8, 1, 0, 2, true>(p, s);          // 128 -> 64  (level 2 decoder): two 64-channel slices per tap
+  // Measured on the config-2 rulebooks (profiles/r6_x3/): the 96-channel shapes of level 3 gain (96 -> 96 0.43 -> 0.41 ms, 192 -> 96 0.91 -> 0.76),
+  // the 64-channel shapes of level 2 LOSE (64 -> 64 0.80-0.92 -> 1.02-1.05: 161 registers leave one workgroup per CU where the fragment-shape
+  // kernel keeps two) -- they stay on tl_conv_stream.hip unless a developer mode asks (tl_set_tuning "streamq_x3": 2 = 8 waves, 3 = 4 waves,
+  // 4 = prefetch depth 1)
   if (nb == 3 && pn == 3) return launch<27, 3, 3, 2, 8, 1, 0, 1, true>(p, s);          // 96 -> 96   (level 3)
-  if (nb == 3 && pn == 6) return launch<27, 3, 3, 2, 8, 1, 0, 2, true>(p, s);          // 192 -> 96  (level 3 decoder)
+  if (nb == 3 && pn == 6) return launch<27, 3, 3, 2, 8, 1, 0, 2, true>(p, s);          // 192 -> 96  (level 3 decoder): two 96-channel slices per tap
+  if (mode >= 2 && nb == 2 && pn == 2) {                                                // 64 -> 64   (level 2)
+    if (mode == 3) return launch<27, 2, 2, 2, 4, 1, 0, 1, true>(p, s);
+    if (mode == 4) return launch<27, 2, 2, 1, 8, 1, 0, 1, true>(p, s);
+    return launch<27, 2, 2, 2, 8, 1, 0, 1, true>(p, s);
+  }
+  if (mode >= 2 && nb == 2 && pn == 4) return launch<27, 2, 2, 2, 8, 1, 0, 2, true>(p, s);          // 128 -> 64  (level 2 decoder)
   return TL_ERR_UNSUPPORTED;
 }
 #endif
