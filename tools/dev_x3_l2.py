@@ -1,6 +1,6 @@
 """Dev: the parity-fast mode's level-2 / level-3 convs (fp32 rows, split-bf16 contraction) on the config-2 rulebooks: the fragment-shape gather
 kernel (tl_conv_stream.hip, X3) against the quad-coalesced form (tl_conv_streamq.hip, X3) and its variants (tl_set_tuning "streamq_x3":
-0 off, 1 = the shipped choice, 2 = every shape on 8-wave workgroups, 3 = 64 -> 64 on 4-wave workgroups, 4 = 64 -> 64 with prefetch depth 1)."""
+0 off, 1 = the shipped choice, 2 / 3 = prefetch depth 2 / 1 with the two-step loop for every shape)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,7 +31,7 @@ for li, cin, cout in ((1, 64, 64), (1, 128, 64), (2, 96, 96), (2, 192, 96)):
     ops.PACK_X3 = False
     o1 = torch.empty(n, cout, device="cuda"); o2 = torch.empty_like(o1)
     sc = torch.rand(cout, device="cuda") + 0.5; sh = torch.randn(cout, device="cuda") * 0.1
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 0, 1):
         _hip.check(L.tl_set_tuning(b"streamq_x3", mode), "streamq_x3")
         t0 = timeit(lambda: ops.conv_fwd(x, w, lv.nbr, n, out=o1))
         t1 = timeit(lambda: ops.conv_fwd(x, w, lv.nbr, n, out=o1, residual=res, out2=(o2, sc, sh, True)))

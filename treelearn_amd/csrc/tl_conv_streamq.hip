@@ -65,7 +65,7 @@ static __device__ __forceinline__ void quad_transpose(const u32x4 (&S)[4], u32x4
 // (channels 16 J + 4 fh + {0..3} and 16 J + 8 + 4 fh + {0..3}), whose rows [K][Cout][Cin / 32][128 B] are byte for byte the weight rows this
 // kernel streams: two k-steps per part, three MFMAs each (lo.Whi + hi.Wlo + hi.Whi), fp32 epilogue.  The split-bf16 form of tl_conv_stream.hip
 // issues one 16-B request per lane and piece (fragment shape); here four adjacent lanes read 64 contiguous bytes.
-template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL, int SP = 1, bool X3 = false>
+template <int K, int NB, int PN, int DA, int W, int RB, int OCC, int ABL, int SP = 1, bool X3 = false, bool UL = false>
 __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   constexpr bool TM = (ABL & 16) != 0;
   constexpr int KV = K * SP;
@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int pp = 0; pp < PN; ++pp) {
-        if constexpr (ABL & 1) { for (int i = 0; i < 4; ++i) F[rb][pp][i] = a[U][rb][pp][i]; }
-        else quad_transpose(a[U][rb][pp], F[rb][pp], o0, o1);
+        if constexpr (ABL & 1) { for (int i = 0; i < 4; ++i) F[rb][pp][i] = a[U % DA][rb][pp][i]; }
+        else quad_transpose(a[U % DA][rb][pp], F[rb][pp], o0, o1);
       }
     const char* bl = Bs + (U & 1) * COUT * BROW + fi * BROW + fh * 64;
     if constexpr (X3) {
@@ -244,15 +244,21 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
           }
         }
     tick(1);
-    if (k + DA < KV) { issue_a(k + DA, a[U]); if (k + DA + 1 < KV) read_idx(k + DA + 1); }
+    if (k + DA < KV) { issue_a(k + DA, a[U % DA]); if (k + DA + 1 < KV) read_idx(k + DA + 1); }
     tick(2);
     if constexpr ((ABL & 4) == 0) { if (k + 1 < KV) __syncthreads(); }
     tick(3);
   };
-  if constexpr (X3 && DA == 2 && RW == 1) {
+  if constexpr (X3 && !UL) {                        // two steps per trip: the parity of k (and with it every register-array index) stays static
     for (int k0 = 0; k0 < KV; k0 += 2) {
       step(k0, std::integral_constant<int, 0>{});
       if (k0 + 1 < KV) step(k0 + 1, std::integral_constant<int, 1>{});
+    }
+  } else if constexpr (X3) {                          // UL: fully unrolled (the instantiations small enough for hipcc to do it without spilling)
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      if ((k & 1) == 0) step(k, std::integral_constant<int, 0>{});
+      else step(k, std::integral_constant<int, 1>{});
     }
   } else {
     // (the 16-bit instantiations keep the fully unrolled loop they were tuned with)
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(W * 64, OCC) k_conv_streamq(ConvP p) {
   if (p.epi_mode != TL_EPI_NONE) epi_finish_wg<W, EP, NB>(p, Es, tid, red0, red1);
 }
 
-template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0, int SP = 1, bool X3 = false>
+template <int K, int NB, int PN, int DA, int W = 8, int RB = 1, int ABL = 0, int SP = 1, bool X3 = false, bool UL = false>
 int launch(ConvP p, hipStream_t s) {
   constexpr int OCC = 2;
   if constexpr (X3) p.w = p.w_x3;
@@ -330,9 +336,9 @@ int launch(ConvP p, hipStream_t s) {
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
   static TlAttrOnce attr_once;                     // per kernel instantiation AND device (the attribute is per device)
-  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP, X3>), 160 * 1024)) return TL_ERR_LAUNCH;
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP, X3, UL>), 160 * 1024)) return TL_ERR_LAUNCH;
   p.nblk = (int)tl_cdiv(p.n_out, W * 32 * RB);
-  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP, X3><<<p.nblk, W * 64, lds, s>>>(p);
+  k_conv_streamq<K, NB, PN, DA, W, RB, OCC, ABL, SP, X3, UL><<<p.nblk, W * 64, lds, s>>>(p);
   if (p.red_nparts) *p.red_nparts = p.nblk;
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
@@ -403,18 +409,24 @@ int tl_launch_conv_streamq_x3(const ConvP& p, int mode, hipStream_t s) {
   const int64_t ld_b = p.in_ld * 4, in_bytes = (p.n_in - 1) * ld_b + (int64_t)p.Cin * 4;
   if (!(in_bytes > 0 && in_bytes + 2 * ld_b < 0xFFFFFFFFll) || ((uintptr_t)p.w_x3) % 16) return TL_ERR_UNSUPPORTED;
   const int nb = p.Cout / 32, pn = p.Cin / 32;
-  // Measured on the config-2 rulebooks (profiles/r6_x3/): the 96-channel shapes of level 3 gain (96 -> 96 0.43 -> 0.41 ms, 192 -> 96 0.91 -> 0.76),
-  // the 64-channel shapes of level 2 LOSE (64 -> 64 0.80-0.92 -> 1.02-1.05: 161 registers leave one workgroup per CU where the fragment-shape
-  // kernel keeps two) -- they stay on tl_conv_stream.hip unless a developer mode asks (tl_set_tuning "streamq_x3": 2 = 8 waves, 3 = 4 waves,
-  // 4 = prefetch depth 1)
-  if (nb == 3 && pn == 3) return launch<27, 3, 3, 2, 8, 1, 0, 1, true>(p, s);          // 96 -> 96   (level 3)
-  if (nb == 3 && pn == 6) return launch<27, 3, 3, 2, 8, 1, 0, 2, true>(p, s);          // 192 -> 96  (level 3 decoder): two 96-channel slices per tap
-  if (mode >= 2 && nb == 2 && pn == 2) {                                                // 64 -> 64   (level 2)
-    if (mode == 3) return launch<27, 2, 2, 2, 4, 1, 0, 1, true>(p, s);
-    if (mode == 4) return launch<27, 2, 2, 1, 8, 1, 0, 1, true>(p, s);
-    return launch<27, 2, 2, 2, 8, 1, 0, 1, true>(p, s);
+  // developer modes (tl_set_tuning "streamq_x3"): 0 = off, 1 = the shipped choice, 2 = prefetch depth 2 / two-step loop for every shape, 3 = depth 1 /
+  // two-step loop for every shape
+  if (mode == 2) {
+    if (nb == 2 && pn == 2) return launch<27, 2, 2, 2, 8, 1, 0, 1, true>(p, s);
+    if (nb == 2 && pn == 4) return launch<27, 2, 2, 2, 8, 1, 0, 2, true>(p, s);
+    if (nb == 3 && pn == 3) return launch<27, 3, 3, 2, 8, 1, 0, 1, true>(p, s);
+    if (nb == 3 && pn == 6) return launch<27, 3, 3, 2, 8, 1, 0, 2, true>(p, s);
   }
-  if (mode >= 2 && nb == 2 && pn == 4) return launch<27, 2, 2, 2, 8, 1, 0, 2, true>(p, s);          // 128 -> 64  (level 2 decoder)
+  if (mode == 3) {
+    if (nb == 2 && pn == 2) return launch<27, 2, 2, 1, 8, 1, 0, 1, true>(p, s);
+    if (nb == 2 && pn == 4) return launch<27, 2, 2, 1, 8, 1, 0, 2, true>(p, s);
+    if (nb == 3 && pn == 3) return launch<27, 3, 3, 1, 8, 1, 0, 1, true>(p, s);
+    if (nb == 3 && pn == 6) return launch<27, 3, 3, 1, 8, 1, 0, 2, true>(p, s);
+  }
+  // shipped (config-2 rulebooks, profiles/r6_x3/x3_l2.txt; fragment-shape kernel -> this one): the 96 -> 96 shape gains nothing and stays there
+  if (nb == 2 && pn == 2) return launch<27, 2, 2, 1, 8, 1, 0, 1, true, true>(p, s);    // 64 -> 64  (level 2): 0.79-0.88 -> 0.74-0.82 ms (depth 1, fully unrolled: 114 registers, two workgroups per CU)
+  if (nb == 2 && pn == 4) return launch<27, 2, 2, 1, 8, 1, 0, 2, true>(p, s);          // 128 -> 64 (level 2 decoder): 1.75 -> 1.52 ms
+  if (nb == 3 && pn == 6) return launch<27, 3, 3, 2, 8, 1, 0, 2, true>(p, s);          // 192 -> 96 (level 3 decoder): 0.89 -> 0.82 ms
   return TL_ERR_UNSUPPORTED;
 }
 #endif
