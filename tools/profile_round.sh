@@ -37,3 +37,7 @@ python bench.py --dtype fp32 --no-cpu-baseline --no-power-probe --no-extra-workl
 python bench.py --tiles-in-flight 1 $Q --layer-table $O/layer_table_bf16.txt > /dev/null 2>> $O/bench_unprofiled.err
 python tools/dev_k8.py > $O/k8_table.txt 2>&1
 python tools/dev_geom_value.py > $O/geom_value.txt 2>&1
+# round 6: the LDS scatter-add roof, the parity-fast mode's staged level-1 kernel and its level-2 / 3 quad-gather kernels
+[ -x tools/lds_add_roof ] && ./tools/lds_add_roof > $O/lds_add_roof.txt 2>&1
+python tools/dev_x3_blk.py > $O/x3_blk.txt 2>&1
+python tools/dev_x3_l2.py > $O/x3_l2.txt 2>&1
