@@ -124,7 +124,8 @@ int tl_rulebook_down(const int32_t* ccoords, int64_t Mc, const uint64_t* fbitmap
 /* ---- the whole pyramid in two calls (what treelearn_amd.geometry uses; same kernels and results as the per-level calls
  * above, enqueued back to back, the deep levels -- a few thousand words each -- batched into shared launches).
  *
- * tl_pyramid_ws_words: scan scratch (u32 words) for a pyramid whose level 1 has dims0 = {B,X,Y,Z}; level l+1 has
+ * tl_pyramid_ws_words: scratch (u32 words: the scans' partial sums + a byte map of level 1, 64 B per bitmap word) for a pyramid whose level 1
+ *   has dims0 = {B,X,Y,Z}; level l+1 has
  *   ceil(dims_l / 2).  level_word_offsets (optional, i64[num_levels+1]) receives the word offset of every level inside the
  *   `bitmaps` / `prefixes` arrays (the last entry = total words).
  * tl_pyramid_build: occupancy bitmap of level 1 from pcoords, then per level the k2s2 down-sampling (cells at or beyond
