@@ -113,7 +113,7 @@ class Executor:
             with c[2]:
                 self._drop_arena(c, torch.cuda.ExternalStream(k[1], device=torch.device("cuda", k[0])) if k[1] else None)
 
-    def _context(self, dev, stream):
+    def _context(self, dev, stream, pin=False):
         """The (device, stream) context, most recently used last.  Beyond MAX_CONTEXTS the least recently used one that no thread is inside
         goes: its arena returns to torch's allocator (stream-ordered: kernels already enqueued on its stream finish first), its handle is
         destroyed.  A caller that runs every request on a fresh stream therefore holds MAX_CONTEXTS arenas, not one per stream it ever used."""
@@ -125,15 +125,18 @@ class Executor:
                 ex = _hip.lib().tl_exec_create()
                 if not ex:
                     raise RuntimeError("tl_exec_create failed")
-                c = self._ctx[key] = [ex, None, threading.Lock()]      # handle, arena, and a lock: one forward at a time per (device, stream) context
+                c = self._ctx[key] = [ex, None, threading.Lock(), 0]   # handle, arena, a lock (one forward at a time per context), callers holding it
             else:
                 self._ctx.move_to_end(key)
+            if pin:
+                c[3] += 1                                              # (released by the caller through _unpin: an eviction must not take a context
+                                                                       #  between this look-up and the caller's acquisition of its lock)
             if len(self._ctx) > max(MAX_CONTEXTS, 1):
                 for k in list(self._ctx.keys()):
                     if len(self._ctx) <= max(MAX_CONTEXTS, 1):
                         break
                     old = self._ctx[k]
-                    if k != key and old[2].acquire(blocking=False):   # (a context another thread is running a forward on stays)
+                    if k != key and old[3] == 0 and old[2].acquire(blocking=False):   # (a context another thread holds or runs a forward on stays)
                         del self._ctx[k]
                         evicted.append((k, old))
         for k, old in evicted:
@@ -144,6 +147,10 @@ class Executor:
                 _hip.lib().tl_exec_destroy(old[0])
                 old[2].release()
         return c
+
+    def _unpin(self, c):
+        with self._ctx_lock:
+            c[3] -= 1
 
     @staticmethod
     def _new_arena(nbytes, dev, stream):
@@ -227,41 +234,44 @@ class Executor:
             raise ValueError("empty tile")
         dev = coords.device
         stream = torch.cuda.current_stream(dev)
-        ctx = self._context(dev, stream)
-        if self.profiling:
-            L.tl_exec_profile(ctx[0], 1)
-        plan = self._plan_ref()
-        if plan is None:
-            raise RuntimeError("the InferencePlan of this executor is gone")
-        self.desc.blocked = int(plan.supports_blocked())
-        bb = torch.empty((N, self.head_C), dtype=torch.float32, device=dev) if want_backbone else None
-        logits = torch.empty((N, 2), dtype=torch.float32, device=dev)
-        offsets = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        a = _hip.ForwardArgs()
-        a.xyz = coords.data_ptr(); a.batch_ids = batch_ids.data_ptr(); a.N = N; a.B = int(batch_size)
-        a.backbone = _hip.ptr(bb); a.logits = logits.data_ptr(); a.offsets = offsets.data_ptr()
-        a.point_feats = input_feats.data_ptr() if self.needs_feats else None
-        # the unit builder beside the other levels' rulebook kernels for a lone forward on the default stream (geometry.build_geometry's rule)
-        want_side = os.environ.get("TL_BLK_SIDE")
-        use_side = (stream == torch.cuda.default_stream(dev)) if want_side is None else want_side != "0"
-        if use_side:
-            from ..geometry import _side_stream
-            a.side_stream = _side_stream(dev).cuda_stream
-        with ctx[2]:                                                   # (ctypes releases the GIL: two Python threads on one stream would share read-back buffer and arena)
-            for attempt in range(4):
-                if ctx[1] is None:
-                    ctx[1] = self._new_arena(max(1 << 20, int(N * 1536)), dev, stream)                    # first guess: ~1.5 KB per point
-                a.arena = ctx[1].data_ptr(); a.arena_bytes = ctx[1].numel()
-                rc = L.tl_forward(ctx[0], ctypes.byref(self.desc), ctypes.byref(a), stream.cuda_stream)
-                if rc != _hip.TL_ERR_ARENA:
-                    break
-                self._drop_arena(ctx, stream)                          # grow: the exact figure when the level counts were known, a guess before that
-                ctx[1] = self._new_arena(int(a.needed_bytes * 1.15) + (1 << 20), dev, stream)
-            # an arena far larger than this context's tiles need (a one-off big tile) goes back: the next forward allocates what it needs
-            if rc == _hip.TL_OK and ctx[1].numel() > 4 * int(a.needed_bytes) + (64 << 20):
-                self._drop_arena(ctx, stream)
-            if rc == _hip.TL_OK and os.environ.get("TL_EXEC_CHECK") == "1":
-                rc = L.tl_exec_check(ctx[0])                             # per-tile verdict of the unit builder's assertion (waits for this tile's geometry)
+        ctx = self._context(dev, stream, pin=True)
+        try:
+            if self.profiling:
+                L.tl_exec_profile(ctx[0], 1)
+            plan = self._plan_ref()
+            if plan is None:
+                raise RuntimeError("the InferencePlan of this executor is gone")
+            self.desc.blocked = int(plan.supports_blocked())
+            bb = torch.empty((N, self.head_C), dtype=torch.float32, device=dev) if want_backbone else None
+            logits = torch.empty((N, 2), dtype=torch.float32, device=dev)
+            offsets = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            a = _hip.ForwardArgs()
+            a.xyz = coords.data_ptr(); a.batch_ids = batch_ids.data_ptr(); a.N = N; a.B = int(batch_size)
+            a.backbone = _hip.ptr(bb); a.logits = logits.data_ptr(); a.offsets = offsets.data_ptr()
+            a.point_feats = input_feats.data_ptr() if self.needs_feats else None
+            # the unit builder beside the other levels' rulebook kernels for a lone forward on the default stream (geometry.build_geometry's rule)
+            want_side = os.environ.get("TL_BLK_SIDE")
+            use_side = (stream == torch.cuda.default_stream(dev)) if want_side is None else want_side != "0"
+            if use_side:
+                from ..geometry import _side_stream
+                a.side_stream = _side_stream(dev).cuda_stream
+            with ctx[2]:                                                   # (ctypes releases the GIL: two Python threads on one stream would share read-back buffer and arena)
+                for attempt in range(4):
+                    if ctx[1] is None:
+                        ctx[1] = self._new_arena(max(1 << 20, int(N * 1536)), dev, stream)                    # first guess: ~1.5 KB per point
+                    a.arena = ctx[1].data_ptr(); a.arena_bytes = ctx[1].numel()
+                    rc = L.tl_forward(ctx[0], ctypes.byref(self.desc), ctypes.byref(a), stream.cuda_stream)
+                    if rc != _hip.TL_ERR_ARENA:
+                        break
+                    self._drop_arena(ctx, stream)                          # grow: the exact figure when the level counts were known, a guess before that
+                    ctx[1] = self._new_arena(int(a.needed_bytes * 1.15) + (1 << 20), dev, stream)
+                # an arena far larger than this context's tiles need (a one-off big tile) goes back: the next forward allocates what it needs
+                if rc == _hip.TL_OK and ctx[1].numel() > 4 * int(a.needed_bytes) + (64 << 20):
+                    self._drop_arena(ctx, stream)
+                if rc == _hip.TL_OK and os.environ.get("TL_EXEC_CHECK") == "1":
+                    rc = L.tl_exec_check(ctx[0])                             # per-tile verdict of the unit builder's assertion (waits for this tile's geometry)
+        finally:
+            self._unpin(ctx)
         if rc == _hip.TL_ERR_BLK:
             self._raise_if_flagged(rc)
         if rc == _hip.TL_ERR_REACH_ZERO:
