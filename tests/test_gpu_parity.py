@@ -1390,3 +1390,96 @@ def test_hdbscan_prim_fallback_threshold_is_a_documented_knob():
         agree += cnts.max() if cl != -1 else int((prim[m] == -1).sum())
     print(f"hdbscan kept-tree vs Prim form on {n} tied points: {agree / n:.4f} identical assignments")
     assert agree / n >= 0.97
+
+
+# ------------------------------------------------------------------------------------------------ round 6: the forms tl_forward uses of two geometry steps
+@pytest.mark.parametrize("n,spread", [(1, 1.0), (37, 3.0), (5000, 9.0), (300_000, 30.0)])
+def test_point_coords_single_tile_form_equals_the_atomic_form(n, spread):
+    """tl_voxel_point_coords_one (no same-address atomics: per-workgroup partial minima, per-workgroup extents folded by the caller) against
+    tl_voxel_point_coords with B = 1: the same per-point voxel coordinates bit for bit, the same extent and error flag -- incl. negative
+    coordinates, points far from the origin, and a point whose batch id is not 0 (flagged by both)."""
+    import ctypes
+    from treelearn_amd import _hip
+    L = _hip.lib(); st = _hip.stream()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(n)
+    xyz = ((torch.rand((n, 3), device="cuda", generator=gen) - 0.5) * spread + torch.tensor([-4321.0, 98765.0, 12.5], device="cuda")).contiguous()
+    for bad in (False, True):
+        bid = torch.zeros(n, dtype=torch.int64, device="cuda")
+        if bad:
+            bid[n // 2] = 1
+        pc_a = torch.empty((n, 4), dtype=torch.int32, device="cuda"); maxc = torch.empty(4, dtype=torch.int32, device="cuda")
+        mm = torch.empty(6, dtype=torch.int32, device="cuda")
+        _hip.check(L.tl_voxel_point_coords(_hip.ptr(xyz), _hip.ptr(bid), n, 1, 0.1, _hip.ptr(mm), _hip.ptr(pc_a), _hip.ptr(maxc), st), "atomic form")
+        pc_b = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+        parts = torch.full((1024, 4), -7, dtype=torch.int32, device="cuda"); ws = torch.empty(6 * 256, dtype=torch.int32, device="cuda")
+        n_parts = ctypes.c_int32(0)
+        _hip.check(L.tl_voxel_point_coords_one(_hip.ptr(xyz), _hip.ptr(bid), n, 0.1, _hip.ptr(ws), _hip.ptr(pc_b), _hip.ptr(parts), ctypes.byref(n_parts), st),
+                   "single-tile form")
+        torch.cuda.synchronize()
+        assert 1 <= n_parts.value <= 1024
+        folded = parts[:n_parts.value].max(0).values
+        assert bool((parts[n_parts.value:] == -7).all())                    # rows beyond n_parts are not written
+        assert torch.equal(folded[:3], maxc[:3]) and int(folded[3]) == int(maxc[3]) == int(bad)
+        if not bad:
+            assert torch.equal(pc_a, pc_b)
+            assert int(pc_b[:, 1:].min()) == 0                                # the minimum point sits in voxel 0 of every axis
+
+
+def test_rulebooks_build_packed_inverse_table_and_optional_parent():
+    """tl_level.inv_packed / parent = NULL (what tl_forward passes for level 1): the packed table decodes to exactly the one-hot table of the
+    default call, the other tables are unchanged, and a conv through table_one_hot = 2 equals the conv through the one-hot table bit for bit
+    (16-bit and bf16x3); a shape the gather-once kernel does not serve is refused rather than misread."""
+    import ctypes
+    from treelearn_amd import _hip, ops
+    from treelearn_amd.geometry import build_geometry, _nwords
+    from treelearn_amd.synth import make_tile
+    L = _hip.lib(); st = _hip.stream()
+    t = make_tile(extent=13.0, voxel=0.1, n_trees=5, fill=0.1, seed=21)
+    pts = torch.from_numpy(t["points"]).cuda(); N = len(pts)
+    g = build_geometry(pts, torch.zeros(N, dtype=torch.int64, device="cuda"), 1, 0.1, 3, [500, 500, 1000])
+    f, c = g.levels[0], g.levels[1]
+    assert f.n > 20_000                                                     # (above the small-level threshold: the direct kernel serves the conv)
+    i32 = lambda *sh: torch.full(sh, 12345, dtype=torch.int32, device="cuda")   # noqa: E731
+    arr = (_hip.Level * 2)()
+    keep = []
+    for li, lv in enumerate((f, c)):
+        a = arr[li]
+        a.dims[:] = lv.dims; a.n = lv.n
+        a.bitmap = lv.bitmap.data_ptr(); a.prefix = lv.prefix.data_ptr()
+        co, nb = i32(lv.n, 4), i32(27, lv.n); keep += [co, nb]
+        a.coords = co.data_ptr(); a.nbr = nb.data_ptr()
+    child, invp = i32(8, c.n), i32(f.n)
+    arr[0].child = child.data_ptr(); arr[0].parent = None; arr[0].inv = None; arr[0].inv_packed = invp.data_ptr()
+    _hip.check(L.tl_rulebooks_build(arr, 2, None, 0, None, 0, None, st), "tl_rulebooks_build")
+    torch.cuda.synchronize()
+    assert torch.equal(child, f.child) and torch.equal(keep[0], f.coords) and torch.equal(keep[1], f.nbr)
+    dec = torch.full((8, f.n), -1, dtype=torch.int32, device="cuda")
+    rows = torch.nonzero(invp >= 0).squeeze(1)
+    dec[(invp[rows] & 7).long(), rows] = invp[rows] >> 3
+    assert torch.equal(dec, f.inv)
+    assert bool(((invp >= 0) == (f.parent >= 0)).all())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    w_ref = torch.randn((32, 2, 2, 2, 64), device="cuda", generator=gen) * 0.1
+    for dt, x3 in ((torch.bfloat16, False), (torch.float16, False), (torch.float32, True)):
+        ops.PACK_X3 = x3
+        try:
+            w = ops.pack_weight(w_ref, dt)
+        finally:
+            ops.PACK_X3 = False
+        x = torch.randn((c.n, 64), device="cuda", generator=gen).to(dt)
+        ref = ops.conv_fwd(x, w, f.inv, f.n, one_hot=True)
+        out = torch.empty_like(ref)
+        a = _hip.ConvArgs()
+        a.in_ = x.data_ptr(); a.in_ld = 64; a.weight = w.data_ptr(); a.weight_frag = _hip.ptr(getattr(w, "_tl_frag", None)); a.weight_x3 = _hip.ptr(getattr(w, "_tl_x3", None))
+        a.table = invp.data_ptr(); a.table_one_hot = 2; a.n_out = f.n; a.n_in = c.n; a.K = 8; a.Cin = 64; a.Cout = 32; a.dtype = _hip.dtype_code(dt)
+        a.out = out.data_ptr(); a.out_ld = 32
+        _hip.check(L.tl_conv_fwd(ctypes.byref(a), st), "packed one-hot conv")
+        assert torch.equal(out, ref), dt
+    # ... and the exact fp32 kernels (no split-bf16 weights) do not know the packed form
+    w32 = ops.pack_weight(w_ref, torch.float32)
+    x32 = torch.randn((c.n, 64), device="cuda", generator=gen)
+    out32 = torch.empty((f.n, 32), device="cuda")
+    a = _hip.ConvArgs()
+    a.in_ = x32.data_ptr(); a.in_ld = 64; a.weight = w32.data_ptr(); a.table = invp.data_ptr(); a.table_one_hot = 2
+    a.n_out = f.n; a.n_in = c.n; a.K = 8; a.Cin = 64; a.Cout = 32; a.dtype = _hip.TL_F32; a.out = out32.data_ptr(); a.out_ld = 32
+    assert L.tl_conv_fwd(ctypes.byref(a), st) == _hip.TL_ERR_UNSUPPORTED
