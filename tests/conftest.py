@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """CPU tests take seconds each (the whole `-m "not gpu"` suite ~40 s): a 300 s ceiling per test (pytest-timeout, where installed) turns a
+    hang into a failure with every thread's stack instead of a run that never returns."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") is None and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(300))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
