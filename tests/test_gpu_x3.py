@@ -31,30 +31,38 @@ def _packs(w):
 
 
 @pytest.mark.parametrize("cin,cout,kind,level", [(32, 32, "subm", 0), (64, 64, "subm", 0), (128, 64, "subm", 0), (96, 96, "subm", 0), (192, 96, "subm", 0), (128, 128, "subm", 0),
-                                                 (64, 32, "subm", 0), (32, 64, "down", 0), (64, 96, "down", 0), (96, 128, "down", 1)])
+                                                 (64, 32, "subm", 0), (32, 64, "down", 0), (64, 96, "down", 0), (96, 128, "down", 1),
+                                                 (96, 64, "inverse", 0), (128, 96, "inverse", 0), (128, 64, "1x1", 0), (64, 32, "inverse", 0)])
 def test_x3_conv_vs_exact_fp32_and_float64(cin, cout, kind, level):
     from treelearn_amd import ops
     g = _geom()
     lv = g.levels[level]
-    table, n_out = (lv.nbr, lv.n) if kind == "subm" else (lv.child, g.levels[level + 1].n)
+    if kind == "inverse":                                  # SparseInverseConv3d: the coarse level's rows through the one-hot table
+        table, n_out, n_in = lv.inv, lv.n, g.levels[level + 1].n
+    elif kind == "1x1":
+        table, n_out, n_in = None, lv.n, lv.n
+    else:
+        table, n_out = (lv.nbr, lv.n) if kind == "subm" else (lv.child, g.levels[level + 1].n)
+        n_in = lv.n
     assert n_out > 16384                                   # the large-level kernels (direct / stream), not the small-level one
-    K = table.shape[0]
-    k = 3 if K == 27 else 2
+    K = table.shape[0] if table is not None else 1
+    k = {27: 3, 8: 2, 1: 1}[K]
     gen = torch.Generator(device="cuda"); gen.manual_seed(cin * 1000 + cout)
     w = torch.randn((cout, k, k, k, cin), device="cuda", generator=gen) / (cin * K) ** 0.5
-    x = torch.randn((lv.n, cin), device="cuda", generator=gen)
+    x = torch.randn((n_in, cin), device="cuda", generator=gen)
     res = torch.randn((n_out, cout), device="cuda", generator=gen)
+    oh = dict(one_hot=True) if kind == "inverse" else {}
     sc = torch.rand(cout, device="cuda", generator=gen) + 0.5; sh = torch.randn(cout, device="cuda", generator=gen)
     w_exact, w_x3 = _packs(w)
-    y_exact = ops.conv_fwd(x, w_exact, table, n_out, residual=res, out_scale=sc, out_shift=sh, out_relu=True)
+    y_exact = ops.conv_fwd(x, w_exact, table, n_out, residual=res, out_scale=sc, out_shift=sh, out_relu=True, **oh)
     y2 = torch.empty_like(y_exact)
-    y_x3 = ops.conv_fwd(x, w_x3, table, n_out, residual=res, out_scale=sc, out_shift=sh, out_relu=True, out2=(y2, None, None, False))
+    y_x3 = ops.conv_fwd(x, w_x3, table, n_out, residual=res, out_scale=sc, out_shift=sh, out_relu=True, out2=(y2, None, None, False), **oh)
     assert not torch.equal(y_exact, y_x3), "the split-bf16 kernel did not run (results are bit-identical to the exact fp32 kernel)"
     scale = float(y_exact.abs().max())
     assert float((y_exact - y_x3).abs().max()) / scale < 1e-4
     # float64 reference on a sample of rows: the x3 result is as close to it as 2^-15-per-product allows
     rows = torch.randperm(n_out, device="cuda", generator=gen)[:2048].sort().values
-    sub = table[:, rows].T.contiguous().cpu().numpy()
+    sub = table[:, rows].T.contiguous().cpu().numpy() if table is not None else rows.cpu().numpy()[:, None].astype(np.int32)
     ref = osp.conv_table(x.double().cpu(), w.double().cpu(), sub).numpy() + res[rows].double().cpu().numpy()
     raw = y2[rows].double().cpu().numpy()
     assert np.abs(raw - ref).max() / np.abs(ref).max() < 5e-5

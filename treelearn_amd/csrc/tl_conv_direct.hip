@@ -575,6 +575,14 @@ int dispatch(const ConvP& p, hipStream_t s) {
     if (nb == 3 && un == 6) return launch<true, 1, 3, 6, 1, 8>(p, s);
     if (nb == 4 && un == 8) return launch<true, 1, 4, 8, 1, 8>(p, s);
   }
+  if constexpr (!BF16 && K == 1) {
+    // the 2C -> C 1x1 conv of the level-2 decoder block on fp32 rows (exact or split-bf16): pure streaming with resident weights, as in bf16
+    // (the stream kernel moved its 0.86 GB at 2.3 TB/s)
+    if (nb == 2 && un == 4 && p.epi_mode == TL_EPI_NONE) {
+      if (p.w_x3) return launch<false, 1, 2, 4, 1, 8, 0, false, false, false, true>(p, s);
+      return launch<false, 1, 2, 4, 1, 8>(p, s);
+    }
+  }
   if constexpr (!BF16 && K == 8) {
     // ... and the same conv in the parity-fast mode (fp32 rows, split-bf16 weights: 64 KB resident + twelve epilogue buffers)
     if (p.one_hot && p.w_x3 && p.epi_mode == TL_EPI_NONE && nb == 1 && un == 2) return launch<false, 8, 1, 2, G, 12, 0, false, false, true, true>(p, s);

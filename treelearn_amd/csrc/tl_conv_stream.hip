@@ -27,7 +27,7 @@ __device__ unsigned long long g_tm[8];   // developer timing mode (tl_dev_stream
 // X3 (fp32 storage only): the contraction runs as split-bf16 products (tl_conv_internal.h: mma16_x3) on weights in the tl_pack_weight_x3 form
 template <bool BF16, int K, int NB, int UN, int DA, int RB, int OCC, bool TM = false, bool OH = false, bool X3 = false>
 __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
-  static_assert(!X3 || (!BF16 && !OH), "the split-bf16 contraction reads fp32 rows");
+  static_assert(!X3 || !BF16, "the split-bf16 contraction reads fp32 rows");
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32, SLOTS = UB / 16;
   constexpr int COUT = NB * 32, CIN = UN * 32;
   constexpr int BROW = CIN * EB + 16;                  // LDS pitch of a weight row (one output channel, one tap): +16 B pad =>
@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
   // prologue: weights of tap 0 -> LDS; taps 1..WA-1 of the weights and 0..DA-1 of A in flight, interleaved in tap order
   load_b(0, bw0);
   [[maybe_unused]] u32x4 a1[RB][UN][NJ];                   // OH: the one gathered row per output row
+  [[maybe_unused]] u32x4 ah1[RB][UN][2], al1[RB][UN][2];   // OH && X3: its hi / lo halves, split ONCE (at the first tap, when the row has landed)
   if constexpr (OH) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -159,8 +160,18 @@ __global__ void __launch_bounds__(NT, OCC) k_conv_stream(ConvP p) {
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
           u32x4 ah[RB], al[RB];
+          if constexpr (OH) {
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) x3_split8(a[k % DA][rb][c][2 * J], a[k % DA][rb][c][2 * J + 1], ah[rb], al[rb]);
+            for (int rb = 0; rb < RB; ++rb) {
+              if (k == 0) x3_split8(a1[rb][c][2 * J], a1[rb][c][2 * J + 1], ah1[rb][c][J], al1[rb][c][J]);
+              const bool mine = idx[k][rb] >= 0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { ah[rb][q] = mine ? ah1[rb][c][J][q] : 0u; al[rb][q] = mine ? al1[rb][c][J][q] : 0u; }
+            }
+          } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) x3_split8(a[k % DA][rb][c][2 * J], a[k % DA][rb][c][2 * J + 1], ah[rb], al[rb]);
+          }
           // the three products of a column block form a dependent chain on its accumulator: issue term by term ACROSS the column blocks
           u32x4 bh[NB], blo[NB];
 #pragma unroll
@@ -237,7 +248,8 @@ int launch(ConvP p, hipStream_t s) {
   constexpr int EB = BF16 ? 2 : 4;
   constexpr int BPTL = (NB * 32 * UN * (BF16 ? 4 : 8) + NT - 1) / NT;
   constexpr int VG = RB * NB * 16 + DA * RB * UN * (BF16 ? 8 : 16) + (K <= 8 ? 8 : 27) * RB + 4 * BPTL * (DA > 2 ? DA - 1 : 1) + 20;   // rough VGPR need
-  constexpr int OCC = (VG <= 120 || (X3 && NB * UN <= 4)) ? 4 : 2;      // (the split-bf16 form is latency-bound at two waves per SIMD: measured)
+  constexpr int OCC = (OH && X3) ? 2 : ((VG <= 120 || (X3 && NB * UN <= 4)) ? 4 : 2);      // (the split-bf16 form is latency-bound at two waves per SIMD: measured;
+                                                                                             //  its one-hot form also holds the split row: 48 registers more)
   const size_t wt = 2 * (size_t)NB * 32 * (UN * 32 * EB + 16), ep = (size_t)WAVES * 32 * 36 * 4;
   const size_t lds = wt > ep ? wt : ep;
   if (lds > 160 * 1024) return TL_ERR_UNSUPPORTED;
@@ -261,6 +273,14 @@ int dispatch(const ConvP& p, hipStream_t s) {
       if (nb == 2 && un == 3) return launch<true, 8, 2, 3, 1, 1, false, true>(p, s);
       if (nb == 1 && un == 2) return launch<true, 8, 1, 2, 1, 1, false, true>(p, s);
       if (nb == 3 && un == 4) return launch<true, 8, 3, 4, 1, 1, false, true>(p, s);
+    }
+  }
+  if constexpr (!BF16 && K == 8) {
+    // ... and the same convs in the parity-fast mode (fp32 rows, split-bf16 weights): the one row gathered and split once instead of eight
+    // gathered rows -- seven of them absent -- split per tap (level 2 <- 3: 0.37 ms for 0.39 GB)
+    if (p.one_hot == 1 && p.w_x3 && p.epi_mode == TL_EPI_NONE) {
+      if (nb == 2 && un == 3) return launch<false, 8, 2, 3, 1, 1, false, true, true>(p, s);
+      if (nb == 3 && un == 4) return launch<false, 8, 3, 4, 1, 1, false, true, true>(p, s);
     }
   }
   if constexpr (BF16 && K == 8) {
