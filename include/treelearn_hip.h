@@ -291,7 +291,10 @@ int tl_conv_fwd(const tl_conv_args* args, tl_stream_t stream);
  * into the kernel layout [K=k^3][Cout][Cin] with dtype conversion. */
 int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed, int dtype, tl_stream_t stream);
 /* The split-bf16 form of a reference-layout fp32 conv weight for tl_conv_args.weight_x3 (Cin % 32 == 0): [K][Cout][Cin / 32][64 bf16] =
- * per 32-channel unit the hi parts bf16(w) of its four 8-channel MFMA pieces, then the lo parts bf16(w - hi); as many bytes as [K][Cout][Cin] fp32. */
+ * per 32-channel unit the hi parts bf16(w) of its four 8-channel MFMA pieces, then the lo parts bf16(w - hi): as many bytes as [K][Cout][Cin] fp32;
+ * for Cin < 256 and Cout % 32 == 0 a second copy of the same bytes in MFMA-fragment order follows (1 KB contiguous per fragment load: the
+ * small-level kernel).  tl_pack_weight_x3_bytes = the size of the buffer to pass. */
+int64_t tl_pack_weight_x3_bytes(int Cout, int K, int Cin);
 int tl_pack_weight_x3(const float* w_ref, int Cout, int K, int Cin, void* w_x3, tl_stream_t stream);
 /* Weights of the input-gradient ("dgrad") conv of the same layer, for tl_conv_fwd over the transposed rulebook: w_t[k][ci][co] =
  * w_ref[co][flip ? K-1-k : k][ci] (taps flip for SubM convs: nbr[k][o] = i <=> nbr[K-1-k][i] = o), with dtype conversion. */

@@ -136,6 +136,7 @@ PROTOTYPES = {
     "tl_bn_train_bwd_from_parts": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "tl_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weight_x3": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "tl_pack_weight_x3_bytes": (_i64, [_i32, _i32, _i32]),
     "tl_pack_weight_frag": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "tl_pack_weights_batch": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "tl_pack_weight_dgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

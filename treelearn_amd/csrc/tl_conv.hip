@@ -223,6 +223,14 @@ __global__ void k_pack_weight_x3(const float* __restrict__ w, int Cout, int K, i
     const __hip_bfloat16 hi = __float2bfloat16(v);
     const __hip_bfloat16 lo = __float2bfloat16(v - __bfloat162float(hi));
     o[t0] = half ? __builtin_bit_cast(uint16_t, lo) : __builtin_bit_cast(uint16_t, hi);
+    // second copy in MFMA-fragment order (Cout % 32 == 0, Cin < 256) behind the first: the 16-B piece j (0, 1 = hi of channel group J = j; 2, 3 =
+    // lo of J = j - 2) of lane (n & 31, fh) for (tap, column block, unit) is one contiguous KB -- what the small-level kernel loads per
+    // instruction (tl_conv_small.hip, FR): slot 2 J + fh / 4 + 2 J + fh of the record above
+    if (halves == 1 && Cout % 32 == 0) {
+      const int j = half ? 2 + J : J;
+      const int lane = (n & 31) + 32 * fh, cbt = n >> 5, CBt = Cout >> 5;
+      o[total + ((((((int64_t)k * CBt + cbt) * un + c) * 4 + j) * 64 + lane) * 8) + q] = half ? __builtin_bit_cast(uint16_t, lo) : __builtin_bit_cast(uint16_t, hi);
+    }
   }
 }
 
@@ -600,6 +608,12 @@ int tl_pack_weight(const float* w_ref, int Cout, int K, int Cin, void* w_packed,
   k_pack_weight<<<tl_grid((int64_t)Cout * K * Cin, 256), 256, 0, tl_s(stream)>>>(w_ref, Cout, K, Cin, w_packed, dtype);
   TL_CHECK_LAUNCH();
   return TL_OK;
+}
+
+int64_t tl_pack_weight_x3_bytes(int Cout, int K, int Cin) {
+  if (Cout <= 0 || K <= 0 || Cin <= 0 || Cin % 32) return -1;
+  const int64_t one = (int64_t)K * Cout * Cin * 4;
+  return (Cin < 256 && Cout % 32 == 0) ? 2 * one : one;
 }
 
 int tl_pack_weight_x3(const float* w_ref, int Cout, int K, int Cin, void* w_x3, tl_stream_t stream) {

@@ -18,7 +18,7 @@ namespace {
 // b[..][J] / b[..][2 + J] are then the hi / lo parts of channel group J of the unit
 template <bool BF16, int NBB, int WV, bool FR, bool X3 = false>
 __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
-  static_assert(!X3 || (!BF16 && !FR), "split-bf16: fp32 rows, weights in their own layout");
+  static_assert(!X3 || !BF16, "split-bf16: fp32 rows, weights in their own layout (FR: its fragment-order second copy)");
   constexpr int EB = BF16 ? 2 : 4, UB = 32 * EB, NJ = UB / 32;
   constexpr int PF = 4;                                       // steps per batch and wave (their independent loads are issued together)
   constexpr int KMAX = 27;
@@ -43,7 +43,9 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
   const int64_t in_bytes = ((int64_t)p.n_in - 1) * in_ld_b + (int64_t)p.Cin * EB;
   const bool buf_ok = in_bytes > 0 && in_bytes + 2 * (int64_t)in_ld_b < 0xFFFFFFFFll;       // else: clamp + mask path
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, buf_ok ? (int)in_bytes : 0, 0x00020000);
-  const char* inb = (const char*)p.in; const char* Wb = (const char*)(X3 ? p.w_x3 : (FR ? p.w_frag : p.w));
+  const char* inb = (const char*)p.in;
+  const char* Wb = (const char*)(X3 ? p.w_x3 : (FR ? p.w_frag : p.w));
+  if constexpr (X3 && FR) Wb += (int64_t)p.K * p.Cout * p.Cin * 4;             // tl_pack_weight_x3: the fragment-order copy follows the slot-order one
   const int CBt = p.Cout / 32;
 
   f32x16 acc[NBB];
@@ -78,7 +80,8 @@ __global__ void __launch_bounds__(WV * 64) k_conv_small(ConvP p, int ncolblk) {
       for (int nb = 0; nb < NBB; ++nb)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          if constexpr (FR) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk * CBt + col0 / 32 + nb) * nchunk + B.ch[u]) * NJ + j) * 64 + lane) * 16);
+          if constexpr (FR && X3) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk * CBt + col0 / 32 + nb) * nchunk + B.ch[u]) * 4 + j) * 64 + lane) * 16);
+          else if constexpr (FR) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + ((((int64_t)(kk * CBt + col0 / 32 + nb) * nchunk + B.ch[u]) * NJ + j) * 64 + lane) * 16);
           else if constexpr (X3) B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk * p.Cout + col0 + nb * 32 + fi) * p.Cin + B.ch[u] * 32) * EB +
                                                                                   ((j < 2 ? 2 * j : 4 + 2 * (j - 2)) + fh) * 16);
           else B.b[u][nb][j] = *reinterpret_cast<const u32x4*>(Wb + (((int64_t)kk * p.Cout + col0 + nb * 32 + fi) * p.Cin + B.ch[u] * 32) * EB + j * 32 + fh * 16);
@@ -259,6 +262,11 @@ int tl_launch_conv_small(const ConvP& p, int dtype, hipStream_t s) {
   // fp32 rows with split-bf16 weights (the bf16x3 mode; weights of >= 256 input channels come as two half-width convs: exact kernel)
   const bool x3 = dtype == TL_F32 && p.w_x3 != nullptr && p.Cin < 256 && !p.in_scale && !p.in_relu;
   if (dtype == TL_BF16) { if (fr) TL_SMALL(true, true); else TL_SMALL(true, false); }
+  else if (x3 && g_small_mode != 3 && p.Cout % 32 == 0) {                        // (fragment-order copy of the split weights: 1 KB per load instead of 64 x 16 B)
+    if (eight) k_conv_small<false, 1, 8, true, true><<<g, 512, 0, s>>>(p, ncb);
+    else if (two) k_conv_small<false, 2, 4, true, true><<<g, 256, 0, s>>>(p, ncb);
+    else k_conv_small<false, 1, 4, true, true><<<g, 256, 0, s>>>(p, ncb);
+  }
   else if (x3) {
     if (eight) k_conv_small<false, 1, 8, false, true><<<g, 512, 0, s>>>(p, ncb);
     else if (two) k_conv_small<false, 2, 4, false, true><<<g, 256, 0, s>>>(p, ncb);

@@ -34,7 +34,7 @@ def pack_weight(w_ref: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         out._tl_frag = frag
     if PACK_X3 and dtype == torch.float32 and ci % 32 == 0:
         # split-bf16 copy (hi / lo bf16 parts in MFMA-piece order; as many bytes as the fp32 tensor): tl_conv_args.weight_x3
-        x3 = torch.empty(K * co * ci, dtype=torch.float32, device=w.device)
+        x3 = torch.empty(int(L.tl_pack_weight_x3_bytes(co, K, ci)) // 4, dtype=torch.float32, device=w.device)
         _hip.check(L.tl_pack_weight_x3(_hip.ptr(w), co, K, ci, _hip.ptr(x3), _hip.stream()), "tl_pack_weight_x3")
         out._tl_x3 = x3
     return out
