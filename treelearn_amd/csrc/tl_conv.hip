@@ -541,6 +541,10 @@ int tl_conv_fwd(const tl_conv_args* a, tl_stream_t stream) {
     if (g_stream) { const int rc = L_stream(p, TL_F32, s); if (rc != TL_ERR_UNSUPPORTED) return rc; }
   }
   if (train && dt == TL_F32) return TL_ERR_UNSUPPORTED;
+  // fp32 shapes none of the resident-weight / streamed-weight kernels has an instantiation for (the level-4 <- 5 inverse conv 160 -> 128 on 38 k
+  // rows): the small-level kernel before the tile kernel while the level is still small (0.198 -> 0.082 ms in the parity-fast mode)
+  if (dt == TL_F32 && !f16 && vec_ok && a->n_out <= 4 * g_small_rows && a->Cin % 32 == 0 && a->Cout % 32 == 0 && !a->in_scale && !a->in_relu)
+    return L_small(p, dt, s);
   if (dt == TL_F32 && aligned && a->Cin % KC == 0 && a->Cout % 32 == 0 && a->Cout <= 224) {
     switch (a->Cout / 32) {
       case 1: return launch_mfma_f32<1>(p, s);
