@@ -312,6 +312,20 @@ def test_tile_loop_same_results_with_tiles_in_flight(device_tiles, monkeypatch):
             assert rows == ref[1], (nf, keep)
             for a, b_ in zip(res, ref[0]):
                 np.testing.assert_array_equal(a, b_, err_msg=f"tiles in flight {nf}, keep_on_device {keep}")
+    # the numpy results land in pinned buffers asynchronously; with a zero budget every tile's buffer is folded into pageable memory at once
+    # (the path a plot of thousands of tiles takes every ~70 tiles): same arrays, and the labels keep the batch's integer type
+    monkeypatch.setenv("TL_D2H_PINNED_MB", "0")
+    res, rows = get_pointwise_preds(model, tiles, dict(voxel_size=0.1), return_tile_rows=True)
+    assert rows == ref[1]
+    for a, b_ in zip(res, ref[0]):
+        np.testing.assert_array_equal(a, b_, err_msg="pinned budget 0")
+        assert a.dtype == b_.dtype
+    assert res[1].dtype == tiles[0]["semantic_labels"].cpu().numpy().dtype and res[5].dtype == tiles[0]["instance_labels"].cpu().numpy().dtype
+    host = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in t.items()} for t in tiles]
+    inner = np.concatenate([t["semantic_labels"].numpy()[t["masks_inner"].numpy()] for t in host])
+    np.testing.assert_array_equal(res[1], inner)                         # (bit patterns through the float columns: exact)
+    cc = np.concatenate([(t["coords"] + t["centers"]).numpy()[t["masks_inner"].numpy()] for t in host])
+    np.testing.assert_array_equal(res[4], cc)
 
 
 @pytest.mark.parametrize("n_pts", [1, 31, 32, 33, 4097, 70001])

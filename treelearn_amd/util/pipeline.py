@@ -81,6 +81,18 @@ def _h2d_ring(depth, stream):
     return r
 
 
+def _cat_rows_numpy(parts):
+    """torch.cat(parts, 0).numpy(), written into memory numpy allocated: numpy asks for transparent huge pages on large blocks (madvise), torch's
+    CPU allocator does not, and with 4 KB pages the page faults of a fresh result cost more than the copy (measured on the GPU box's host: 12.5 MB
+    of results per tile, 0.8 ms to fault in + 1.2 ms to unmap, against a 7.3 ms forward)."""
+    if any(p.dtype != parts[0].dtype or p.shape[1:] != parts[0].shape[1:] for p in parts):
+        return torch.cat(parts, 0).numpy()                             # mixed tiles: torch's promotion rules decide, as in the reference's torch.cat
+    out = np.empty((sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:]), dtype=parts[0][:0].numpy().dtype)
+    if out.size:
+        torch.cat(parts, 0, out=torch.from_numpy(out))
+    return out
+
+
 def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True, return_tile_rows=False,
                         keep_on_device=False):
     """Per tile: forward, keep only `masks_inner` rows (filtered ON THE DEVICE, then one packed D2H copy instead of the
@@ -96,6 +108,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     keep_on_device=True returns the 8 results as device tensors instead of numpy arrays (no D2H at all), for a consumer that
     continues on the GPU -- `postprocess.ensemble` accepts them."""
     outs = [[] for _ in range(8)]
+    d2h_pending, deferred, d2h_bytes = [], [], [0]                     # asynchronous packed D2H copies (numpy results): events, deferred host arithmetic
+    pinned_limit = int(os.environ.get("TL_D2H_PINNED_MB", "1024")) << 20  # pinned landing buffers held before they are folded into pageable memory
     tile_rows = []                                                     # (position in the iterable, inner rows) of every tile that produced output
     use_gpu = torch.cuda.is_available()
     copy_stream = torch.cuda.Stream() if use_gpu else None
@@ -104,7 +118,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
 
     def read_back(pos, batch, gbatch, output, done, slot=None):
-        n0 = sum(len(o) for o in outs[0])
+        n0 = sum(len(o) for o in outs[0])                              # (len() of a landing view is its row count: no read)
         _read_back_on(batch, gbatch, output, done)
         tile_rows.append((pos, sum(len(o) for o in outs[0]) - n0))
         if slot is not None:                                           # the tile's staging slot may take the next host tile once this read-back has run
@@ -123,17 +137,18 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
         if done_on_other_stream and gbatch['masks_inner'].is_cuda and not getattr(gbatch['masks_inner'], "_tl_ring", False):
             gbatch['masks_inner'].record_stream(torch.cuda.current_stream())
         idx = torch.nonzero(gbatch['masks_inner'].to(dev)).squeeze(1)          # one small sync; 4-5 % of the rows survive
-        ci = None
+        n_in = idx.shape[0]
+        src_of = lambda k: gbatch[k] if (torch.is_tensor(gbatch.get(k)) and gbatch[k].is_cuda) else batch[k]      # noqa: E731
+        # the row list goes home FIRST (a small synchronous copy) when any per-point array has to be selected on the host: behind the packed
+        # copy below it would wait for that copy
+        ci = idx.cpu() if any(not src_of(k).is_cuda for k in ('semantic_labels', 'instance_labels', 'offset_labels', 'coords', 'centers', 'input_feats')) else None
 
         def rows(t):
             """Inner rows of a per-point array: gathered on the device if it lives there, else on the host."""
-            nonlocal ci
             if t.is_cuda:
                 if done_on_other_stream and not getattr(t, "_tl_ring", False):
                     t.record_stream(torch.cuda.current_stream())       # allocated on a compute stream, read here on the read-back stream
                 return t.index_select(0, idx)
-            if ci is None:
-                ci = idx.cpu()
             return t.index_select(0, ci)
 
         bb = output['backbone_feats'] if return_backbone_feats else None        # a model without the switch still returns them: not shipped
@@ -143,23 +158,75 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             cols.append(rows(bb).float())
         on_dev = {}
         for k in ('offset_labels', 'coords', 'centers', 'input_feats'):
-            src = gbatch[k] if (torch.is_tensor(gbatch.get(k)) and gbatch[k].is_cuda) else batch[k]
+            src = src_of(k)
             if src.is_cuda:
-                on_dev[k] = len(cols); cols.append(rows(src).float().reshape(idx.shape[0], -1))
+                on_dev[k] = len(cols); cols.append(rows(src).float().reshape(n_in, -1))
+        lab_dev = {}
+        if not keep_on_device:
+            for k in ('semantic_labels', 'instance_labels'):                    # device-resident integer labels ride along as bit patterns: exact for any dtype
+                src = src_of(k)
+                if src.is_cuda and src.dim() == 1 and src.element_size() in (4, 8):
+                    lab_dev[k] = (len(cols), src.dtype); cols.append(rows(src).contiguous().view(torch.float32).reshape(n_in, -1))
         widths = [c.shape[1] for c in cols]
         packed = torch.cat(cols, 1)
+        asynchronous = False
         if keep_on_device and packed.is_cuda:
             packed.record_stream(main_stream)                          # produced on the read-back stream, consumed on the main one
-        parts = list(torch.split(packed if keep_on_device else packed.cpu(), widths, dim=1))
-        get = lambda k: parts[on_dev[k]] if k in on_dev else rows(batch[k])                  # noqa: E731
+            host = packed
+        elif packed.is_cuda:
+            # asynchronous copy into pinned memory: the host goes on to enqueue the next tile.  Everything taken from `host` below is a VIEW of
+            # the landing buffer; arithmetic on it is deferred to `settle()`, which first waits for the copies.
+            host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            host.copy_(packed, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            d2h_pending.append(ev)
+            d2h_bytes[0] += host.numel() * 4
+            asynchronous = True
+        else:
+            host = packed
+        parts = list(torch.split(host, widths, dim=1))
         home = (lambda t: t.to(dev)) if keep_on_device else (lambda t: t.cpu() if t.is_cuda else t)   # noqa: E731
-        get0 = get
-        get = lambda k: home(get0(k))                                                        # noqa: E731
-        lab = lambda k: home(rows(batch[k]))                                                 # noqa: E731
-        outs[0].append(parts[0]); outs[1].append(lab('semantic_labels'))
-        outs[2].append(parts[1]); outs[3].append(get('offset_labels'))
-        outs[4].append(get('coords') + get('centers')); outs[5].append(lab('instance_labels'))
-        outs[6].append(parts[2] if bb is not None else torch.zeros((idx.shape[0], 0), device=parts[0].device)); outs[7].append(get('input_feats'))
+        get = lambda k: parts[on_dev[k]] if k in on_dev else home(rows(src_of(k)))                    # noqa: E731
+
+        def put(i, make):
+            """Result i of this tile is make(): now, or once the packed copy has landed when it reads the landing buffer."""
+            if asynchronous:
+                outs[i].append(None); deferred.append((i, len(outs[i]) - 1, make))
+            else:
+                outs[i].append(make())
+
+        def lab(k):
+            if k in lab_dev:
+                c, dt = lab_dev[k]
+                return parts[c].contiguous().view(dt).reshape(-1)
+            return home(rows(src_of(k)))
+        c_host = None if 'coords' in on_dev else get('coords')          # host-side selections happen now, while the copy is in flight
+        z_host = None if 'centers' in on_dev else get('centers')
+        outs[0].append(parts[0]); outs[2].append(parts[1])
+        if 'semantic_labels' in lab_dev: put(1, lambda: lab('semantic_labels'))
+        else: outs[1].append(lab('semantic_labels'))
+        outs[3].append(get('offset_labels'))
+        if c_host is not None and z_host is not None: outs[4].append(c_host + z_host)
+        else: put(4, lambda: (parts[on_dev['coords']] if c_host is None else c_host) + (parts[on_dev['centers']] if z_host is None else z_host))
+        if 'instance_labels' in lab_dev: put(5, lambda: lab('instance_labels'))
+        else: outs[5].append(lab('instance_labels'))
+        outs[6].append(parts[2] if bb is not None else torch.zeros((n_in, 0), device=parts[0].device)); outs[7].append(get('input_feats'))
+        if d2h_bytes[0] > pinned_limit:
+            settle(consolidate=True)
+
+    def settle(consolidate=False):
+        """Wait for the asynchronous D2H copies, run the arithmetic deferred on them; `consolidate` also moves what has arrived into pageable
+        memory, which frees the pinned landing buffers of a long plot (thousands of tiles) for re-use."""
+        for ev in d2h_pending:
+            ev.synchronize()
+        d2h_pending.clear()
+        for i, j, make in deferred:
+            outs[i][j] = make()
+        deferred.clear()
+        if consolidate:
+            for i in range(8):
+                outs[i] = [torch.from_numpy(_cat_rows_numpy(outs[i]))]
+            d2h_bytes[0] = 0
 
     # Tiles in flight: consecutive tiles run on NF compute streams round-robin, so that the stretches of one forward that leave
     # most CUs idle (the 36 small launches of the deep levels, the geometry kernels and their two host syncs) are filled by the
@@ -245,7 +312,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             main_stream.wait_stream(rb_stream)
         res = tuple(torch.cat(o, 0) for o in outs)
     else:
-        res = tuple(torch.cat(o, 0).numpy() for o in outs)
+        settle()                                                       # the views appended above point into pinned buffers that are landing
+        res = tuple(_cat_rows_numpy(o) for o in outs)
     return (res, tile_rows) if return_tile_rows else res
 
 
