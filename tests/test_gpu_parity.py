@@ -312,14 +312,23 @@ def test_tile_loop_same_results_with_tiles_in_flight(device_tiles, monkeypatch):
             assert rows == ref[1], (nf, keep)
             for a, b_ in zip(res, ref[0]):
                 np.testing.assert_array_equal(a, b_, err_msg=f"tiles in flight {nf}, keep_on_device {keep}")
-    # the numpy results land in pinned buffers asynchronously; with a zero budget every tile's buffer is folded into pageable memory at once
-    # (the path a plot of thousands of tiles takes every ~70 tiles): same arrays, and the labels keep the batch's integer type
-    monkeypatch.setenv("TL_D2H_PINNED_MB", "0")
-    res, rows = get_pointwise_preds(model, tiles, dict(voxel_size=0.1), return_tile_rows=True)
-    assert rows == ref[1]
-    for a, b_ in zip(res, ref[0]):
-        np.testing.assert_array_equal(a, b_, err_msg="pinned budget 0")
-        assert a.dtype == b_.dtype
+    # the numpy results are assembled by a worker thread from pinned landing buffers (util/pipeline._ResultSink); the plain form (every tile
+    # copied home synchronously, one torch.cat at the end) and an iterable without a length (the result arrays grow) give the same arrays,
+    # and the labels keep the batch's integer type
+    for how in ("plain", "generator", "generator, labels int16 on the device"):
+        monkeypatch.setenv("TL_RESULT_SINK", "0" if how == "plain" else "1")
+        src = tiles if how == "plain" else (t for t in tiles)
+        if how.endswith("device"):
+            src = [dict(t, semantic_labels=t["semantic_labels"].to(torch.int16).cuda(), instance_labels=t["instance_labels"].to(torch.int32).cuda()) for t in tiles]
+        res, rows = get_pointwise_preds(model, src, dict(voxel_size=0.1), return_tile_rows=True)
+        assert rows == ref[1]
+        for i, (a, b_) in enumerate(zip(res, ref[0])):
+            np.testing.assert_array_equal(a, b_, err_msg=how)
+            assert a.dtype == b_.dtype or (how.endswith("device") and i in (1, 5)), (how, i, a.dtype, b_.dtype)
+        if how.endswith("device"):
+            assert res[1].dtype == np.int16 and res[5].dtype == np.int32
+    monkeypatch.setenv("TL_RESULT_SINK", "1")
+    res = get_pointwise_preds(model, tiles, dict(voxel_size=0.1))
     assert res[1].dtype == tiles[0]["semantic_labels"].cpu().numpy().dtype and res[5].dtype == tiles[0]["instance_labels"].cpu().numpy().dtype
     host = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in t.items()} for t in tiles]
     inner = np.concatenate([t["semantic_labels"].numpy()[t["masks_inner"].numpy()] for t in host])

@@ -402,3 +402,39 @@ def test_load_checkpoint_handles_mismatched_missing_and_unexpected_keys(tmp_path
     assert len(opt2.state_dict()["state"]) == len(opt.state_dict()["state"]) > 0
     torch.save(dict(net=sd), f)
     assert load_checkpoint(f, None, model) == 1 and model._plan is None
+
+
+def test_result_sink_files_tiles_in_order_grows_and_reports_errors():
+    """util/pipeline._ResultSink (the worker thread that assembles the tile loop's numpy results): tiles are filed in the order they were
+    pushed whatever their sizes, the arrays grow past the first estimate, mixed integer types promote as torch.cat / np.concatenate would,
+    an empty loop gives None, and an exception on the worker thread is re-raised by finish()."""
+    from treelearn_amd.util.pipeline import _ResultSink
+    rng = np.random.default_rng(3)
+    for hint in (None, 5, 40):
+        sink = _ResultSink(hint)
+        want = [[] for _ in range(3)]
+        for t in range(40):
+            n = int(rng.integers(0, 700)) if t else 3
+            a = torch.from_numpy(rng.normal(size=(n, 7)).astype(np.float32))
+            lab = torch.from_numpy(rng.integers(0, 9, n).astype(np.int32 if t < 20 else np.int64))
+            z = torch.zeros((n, 0))
+            for w, x in zip(want, (a, lab, z)):
+                w.append(x.numpy())
+            sink.push(None, (lambda a=a, lab=lab, z=z: [a[:, :7], lab, z]))
+        res = sink.finish()
+        for r, w in zip(res, want):
+            ref = np.concatenate(w, 0)
+            assert r.dtype == ref.dtype and r.shape == ref.shape
+            np.testing.assert_array_equal(r, ref)
+    assert _ResultSink(3).finish() is None
+    sink = _ResultSink()
+    sink.push(None, lambda: [torch.zeros(4, 2)])
+    sink.push(None, lambda: 1 / 0)
+    sink.push(None, lambda: [torch.zeros(4, 2)])
+    with pytest.raises(ZeroDivisionError):
+        sink.finish()
+    sink = _ResultSink()
+    sink.push(None, lambda: [torch.zeros(4, 2)])
+    sink.push(None, lambda: [torch.zeros(4, 3)])
+    with pytest.raises(RuntimeError, match="different widths"):
+        sink.finish()

@@ -81,16 +81,76 @@ def _h2d_ring(depth, stream):
     return r
 
 
-def _cat_rows_numpy(parts):
-    """torch.cat(parts, 0).numpy(), written into memory numpy allocated: numpy asks for transparent huge pages on large blocks (madvise), torch's
-    CPU allocator does not, and with 4 KB pages the page faults of a fresh result cost more than the copy (measured on the GPU box's host: 12.5 MB
-    of results per tile, 0.8 ms to fault in + 1.2 ms to unmap, against a 7.3 ms forward)."""
-    if any(p.dtype != parts[0].dtype or p.shape[1:] != parts[0].shape[1:] for p in parts):
-        return torch.cat(parts, 0).numpy()                             # mixed tiles: torch's promotion rules decide, as in the reference's torch.cat
-    out = np.empty((sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:]), dtype=parts[0][:0].numpy().dtype)
-    if out.size:
-        torch.cat(parts, 0, out=torch.from_numpy(out))
-    return out
+class _ResultSink:
+    """Where the numpy results of the tile loop are assembled, by a worker thread, while the launch thread goes on with the next tiles.
+
+    Per tile the launch thread hands over an event and a closure; the worker waits for the event (the tile's packed D2H copy into a pinned
+    landing buffer), runs the closure (-> the tile's 8 host arrays: views of the landing buffer, host-side row selections, `coords + centers`)
+    and copies them to the end of 8 growing numpy arrays.  What this buys (16 tiles of 40 m, 12.5 MB of results each): the copy into pageable
+    memory and the page faults of that memory -- 1.2 ms per tile when done at the end of the loop, more than the D2H itself -- run beside the
+    forwards instead of after them, and a landing buffer goes back to torch's pinned cache as soon as its tile is filed, so a plot of thousands
+    of tiles holds a handful of them.  The arrays are numpy-allocated (numpy asks for transparent huge pages on big blocks, torch's CPU
+    allocator does not: 4 KB faults doubled the cost) and over-allocated from the first tile's size x the number of tiles when the iterable
+    has a length (x 1.5 growth otherwise); the results are views of them, trimmed by a copy only if more than a quarter would be wasted."""
+
+    def __init__(self, n_tiles_hint=None):
+        import queue
+        import threading
+        self.hint = n_tiles_hint
+        self.bufs, self.n, self.err = None, 0, None
+        self.q = queue.Queue()
+        self.t = threading.Thread(target=self._run, name="tl-result-sink", daemon=True)
+        self.t.start()
+
+    def push(self, event, make):
+        self.q.put((event, make))
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            if self.err is not None:
+                continue                                                # drain: the launch thread re-raises in finish()
+            try:
+                event, make = job
+                if event is not None:
+                    event.synchronize()
+                self._append([a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a)) for a in make()])
+            except BaseException as e:                                 # noqa: BLE001
+                self.err = e
+
+    def _append(self, arrays):
+        n = arrays[0].shape[0]
+        if self.bufs is None:
+            cap = int(n * (self.hint if self.hint else 4) * 1.15) + 1024
+            self.bufs = [np.empty((cap,) + tuple(a.shape[1:]), dtype=a[:0].numpy().dtype) for a in arrays]
+        for i, a in enumerate(arrays):
+            buf = self.bufs[i]
+            dt = np.result_type(buf.dtype, a[:0].numpy().dtype)       # tiles of mixed types: numpy's promotion, as torch.cat's in the reference
+            if self.n + n > buf.shape[0] or dt != buf.dtype or tuple(a.shape[1:]) != buf.shape[1:]:
+                if tuple(a.shape[1:]) != buf.shape[1:]:
+                    raise RuntimeError(f"tile results of different widths: {tuple(a.shape)} after {buf.shape}")
+                grown = np.empty((max(int(buf.shape[0] * 1.5), self.n + n) + 1024,) + buf.shape[1:], dtype=dt)
+                grown[:self.n] = buf[:self.n]
+                buf = self.bufs[i] = grown
+            if n:
+                torch.from_numpy(buf[self.n:self.n + n]).copy_(a)
+        self.n += n
+
+    def finish(self):
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
+        if self.bufs is None:
+            return None
+        return tuple((b[:self.n] if self.n * 4 >= b.shape[0] * 3 else b[:self.n].copy()) for b in self.bufs)
+
+    def abandon(self):
+        if self.t.is_alive():
+            self.q.put(None)
+            self.t.join()
 
 
 def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_feats=True, return_tile_rows=False,
@@ -108,19 +168,18 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
     keep_on_device=True returns the 8 results as device tensors instead of numpy arrays (no D2H at all), for a consumer that
     continues on the GPU -- `postprocess.ensemble` accepts them."""
     outs = [[] for _ in range(8)]
-    d2h_pending, deferred, d2h_bytes = [], [], [0]                     # asynchronous packed D2H copies (numpy results): events, deferred host arithmetic
-    pinned_limit = int(os.environ.get("TL_D2H_PINNED_MB", "1024")) << 20  # pinned landing buffers held before they are folded into pageable memory
+    sink = None                                                        # numpy results of device tensors: assembled by a worker thread (_ResultSink)
     tile_rows = []                                                     # (position in the iterable, inner rows) of every tile that produced output
     use_gpu = torch.cuda.is_available()
+    if use_gpu and not keep_on_device and os.environ.get("TL_RESULT_SINK", "1") != "0":
+        sink = _ResultSink(len(dataloader) if hasattr(dataloader, "__len__") else None)
     copy_stream = torch.cuda.Stream() if use_gpu else None
     rb_stream = torch.cuda.Stream() if use_gpu else None
     main_stream = torch.cuda.current_stream() if use_gpu else None
     vs = getattr(config, 'voxel_size', None) if not isinstance(config, dict) else config.get('voxel_size')
 
     def read_back(pos, batch, gbatch, output, done, slot=None):
-        n0 = sum(len(o) for o in outs[0])                              # (len() of a landing view is its row count: no read)
-        _read_back_on(batch, gbatch, output, done)
-        tile_rows.append((pos, sum(len(o) for o in outs[0]) - n0))
+        tile_rows.append((pos, _read_back_on(batch, gbatch, output, done)))
         if slot is not None:                                           # the tile's staging slot may take the next host tile once this read-back has run
             ev = torch.cuda.Event(); ev.record(rb_stream if done is not None else torch.cuda.current_stream())
             ring.release(slot, ev)
@@ -139,9 +198,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
         idx = torch.nonzero(gbatch['masks_inner'].to(dev)).squeeze(1)          # one small sync; 4-5 % of the rows survive
         n_in = idx.shape[0]
         src_of = lambda k: gbatch[k] if (torch.is_tensor(gbatch.get(k)) and gbatch[k].is_cuda) else batch[k]      # noqa: E731
-        # the row list goes home FIRST (a small synchronous copy) when any per-point array has to be selected on the host: behind the packed
-        # copy below it would wait for that copy
-        ci = idx.cpu() if any(not src_of(k).is_cuda for k in ('semantic_labels', 'instance_labels', 'offset_labels', 'coords', 'centers', 'input_feats')) else None
+        to_sink = sink is not None and idx.is_cuda
+        ci = [None]                                                    # the row list on the host: fetched at most once, by whoever selects host rows
 
         def rows(t):
             """Inner rows of a per-point array: gathered on the device if it lives there, else on the host."""
@@ -149,7 +207,9 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                 if done_on_other_stream and not getattr(t, "_tl_ring", False):
                     t.record_stream(torch.cuda.current_stream())       # allocated on a compute stream, read here on the read-back stream
                 return t.index_select(0, idx)
-            return t.index_select(0, ci)
+            if ci[0] is None:
+                ci[0] = idx.cpu()
+            return t.index_select(0, ci[0])
 
         bb = output['backbone_feats'] if return_backbone_feats else None        # a model without the switch still returns them: not shipped
         # every device-side result goes home in ONE packed D2H copy (float columns) instead of one copy + sync per array
@@ -161,72 +221,49 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             src = src_of(k)
             if src.is_cuda:
                 on_dev[k] = len(cols); cols.append(rows(src).float().reshape(n_in, -1))
-        lab_dev = {}
-        if not keep_on_device:
-            for k in ('semantic_labels', 'instance_labels'):                    # device-resident integer labels ride along as bit patterns: exact for any dtype
+        bits = {}                                                      # columns riding along as bit patterns: (first column, carrier type, final type, row shape)
+        if to_sink:
+            # the worker thread must not touch device memory (its current stream is not this one): whatever lives on the device rides in the block
+            for k in ('semantic_labels', 'instance_labels'):
                 src = src_of(k)
-                if src.is_cuda and src.dim() == 1 and src.element_size() in (4, 8):
-                    lab_dev[k] = (len(cols), src.dtype); cols.append(rows(src).contiguous().view(torch.float32).reshape(n_in, -1))
+                if src.is_cuda:
+                    carrier = src.dtype if src.element_size() in (4, 8) else torch.float64           # (every 1- / 2-byte type is exact in a double)
+                    bits[k] = (len(cols), carrier, src.dtype, tuple(src.shape[1:]))
+                    cols.append(rows(src).to(carrier).contiguous().view(torch.float32).reshape(n_in, -1))
+            if any(not src_of(k).is_cuda for k in ('semantic_labels', 'instance_labels', 'offset_labels', 'coords', 'centers', 'input_feats')):
+                bits['_idx'] = (len(cols), torch.int64, torch.int64, ())                              # the worker selects the host rows
+                cols.append(idx.view(torch.float32).reshape(n_in, 2))
         widths = [c.shape[1] for c in cols]
         packed = torch.cat(cols, 1)
-        asynchronous = False
         if keep_on_device and packed.is_cuda:
             packed.record_stream(main_stream)                          # produced on the read-back stream, consumed on the main one
-            host = packed
-        elif packed.is_cuda:
-            # asynchronous copy into pinned memory: the host goes on to enqueue the next tile.  Everything taken from `host` below is a VIEW of
-            # the landing buffer; arithmetic on it is deferred to `settle()`, which first waits for the copies.
+        ev = None
+        if to_sink:
+            # asynchronous copy into a pinned landing buffer; everything that READS it runs on the sink's worker thread, after the event
             host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
             host.copy_(packed, non_blocking=True)
             ev = torch.cuda.Event(); ev.record()
-            d2h_pending.append(ev)
-            d2h_bytes[0] += host.numel() * 4
-            asynchronous = True
         else:
-            host = packed
-        parts = list(torch.split(host, widths, dim=1))
-        home = (lambda t: t.to(dev)) if keep_on_device else (lambda t: t.cpu() if t.is_cuda else t)   # noqa: E731
-        get = lambda k: parts[on_dev[k]] if k in on_dev else home(rows(src_of(k)))                    # noqa: E731
+            host = packed if (keep_on_device or not packed.is_cuda) else packed.cpu()
 
-        def put(i, make):
-            """Result i of this tile is make(): now, or once the packed copy has landed when it reads the landing buffer."""
-            if asynchronous:
-                outs[i].append(None); deferred.append((i, len(outs[i]) - 1, make))
-            else:
-                outs[i].append(make())
+        def finish():
+            """The tile's 8 results from the landed block (runs on the worker thread when the results go to the sink)."""
+            parts = list(torch.split(host, widths, dim=1))
+            unbits = lambda k: parts[bits[k][0]].contiguous().view(bits[k][1]).reshape((n_in,) + bits[k][3]).to(bits[k][2])   # noqa: E731
+            if '_idx' in bits:
+                ci[0] = unbits('_idx')
+            home = (lambda t: t.to(dev)) if keep_on_device else (lambda t: t.cpu() if t.is_cuda else t)   # noqa: E731
+            get = lambda k: parts[on_dev[k]] if k in on_dev else home(rows(src_of(k)))                    # noqa: E731
+            lab = lambda k: unbits(k) if k in bits else home(rows(src_of(k)))                             # noqa: E731
+            return [parts[0], lab('semantic_labels'), parts[1], get('offset_labels'), get('coords') + get('centers'), lab('instance_labels'),
+                    parts[2] if bb is not None else torch.zeros((n_in, 0), device=parts[0].device), get('input_feats')]
 
-        def lab(k):
-            if k in lab_dev:
-                c, dt = lab_dev[k]
-                return parts[c].contiguous().view(dt).reshape(-1)
-            return home(rows(src_of(k)))
-        c_host = None if 'coords' in on_dev else get('coords')          # host-side selections happen now, while the copy is in flight
-        z_host = None if 'centers' in on_dev else get('centers')
-        outs[0].append(parts[0]); outs[2].append(parts[1])
-        if 'semantic_labels' in lab_dev: put(1, lambda: lab('semantic_labels'))
-        else: outs[1].append(lab('semantic_labels'))
-        outs[3].append(get('offset_labels'))
-        if c_host is not None and z_host is not None: outs[4].append(c_host + z_host)
-        else: put(4, lambda: (parts[on_dev['coords']] if c_host is None else c_host) + (parts[on_dev['centers']] if z_host is None else z_host))
-        if 'instance_labels' in lab_dev: put(5, lambda: lab('instance_labels'))
-        else: outs[5].append(lab('instance_labels'))
-        outs[6].append(parts[2] if bb is not None else torch.zeros((n_in, 0), device=parts[0].device)); outs[7].append(get('input_feats'))
-        if d2h_bytes[0] > pinned_limit:
-            settle(consolidate=True)
-
-    def settle(consolidate=False):
-        """Wait for the asynchronous D2H copies, run the arithmetic deferred on them; `consolidate` also moves what has arrived into pageable
-        memory, which frees the pinned landing buffers of a long plot (thousands of tiles) for re-use."""
-        for ev in d2h_pending:
-            ev.synchronize()
-        d2h_pending.clear()
-        for i, j, make in deferred:
-            outs[i][j] = make()
-        deferred.clear()
-        if consolidate:
-            for i in range(8):
-                outs[i] = [torch.from_numpy(_cat_rows_numpy(outs[i]))]
-            d2h_bytes[0] = 0
+        if to_sink:
+            sink.push(ev, finish)
+        else:
+            for o, r in zip(outs, finish()):
+                o.append(r)
+        return n_in
 
     # Tiles in flight: consecutive tiles run on NF compute streams round-robin, so that the stretches of one forward that leave
     # most CUs idle (the 36 small launches of the deep levels, the geometry kernels and their two host syncs) are filled by the
@@ -299,21 +336,25 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             ex = getattr(getattr(model, "_plan", None), "_exec", None)
             if ex:
                 ex.check()
+    except BaseException:
+        if sink is not None:
+            sink.abandon()
+        raise
     finally:
         if restore_bb is not None:                                    # also when a tile raised: later callers must not inherit the flag
             model.return_backbone_feats = restore_bb
     if cstreams:
         for cs in cstreams:
             main_stream.wait_stream(cs)
-    if not outs[0]:                  # every tile skipped (the reference would fail in torch.cat here)
+    res = sink.finish() if sink is not None else None                  # (waits for the last tiles' copies; raises what the worker met)
+    if (sink is not None and res is None) or (sink is None and not outs[0]):  # every tile skipped (the reference would fail in torch.cat here)
         res = tuple(np.zeros((0,), np.float32) for _ in outs)
     elif keep_on_device:
         if use_gpu:
             main_stream.wait_stream(rb_stream)
         res = tuple(torch.cat(o, 0) for o in outs)
-    else:
-        settle()                                                       # the views appended above point into pinned buffers that are landing
-        res = tuple(_cat_rows_numpy(o) for o in outs)
+    elif sink is None:
+        res = tuple(torch.cat(o, 0).numpy() for o in outs)
     return (res, tile_rows) if return_tile_rows else res
 
 
