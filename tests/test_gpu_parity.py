@@ -231,6 +231,53 @@ def test_tile_loop_golden_g9(golden_dir):
         assert d.is_cuda and np.array_equal(d.cpu().numpy(), r)
 
 
+def test_tile_loop_edge_cases_of_the_result_path():
+    """The worker-thread result path (util/pipeline._ResultSink) at its edges, with a fake model: a FIRST tile without a single inner point
+    (the result arrays are sized from it), an iterable without a length, every tile skipped by the "reach zero" rule, an empty iterable, and
+    a forward that raises something else in the middle of the loop (the error reaches the caller, no thread is left behind)."""
+    import threading
+    from treelearn_amd.util.pipeline import get_pointwise_preds
+    rng = np.random.default_rng(5)
+
+    class Fake(torch.nn.Module):
+        def forward(self, batch, return_loss):
+            c = batch["coords"].cuda()
+            if float(c[0, 0]) > 900:
+                raise RuntimeError("your out spatial shape reach zero!!! (fake)")
+            if float(c[0, 0]) < -900:
+                raise ValueError("something else")
+            return dict(offset_predictions=c * 0.5 + 1, semantic_prediction_logits=torch.stack([c[:, 0], -c[:, 1]], 1), backbone_feats=c.repeat(1, 11)[:, :32])
+
+    def tile(n, n_inner, x0=0.0):
+        c = torch.from_numpy(rng.uniform(-5, 5, (n, 3)).astype(np.float32)); c[0, 0] = x0
+        m = torch.zeros(n, dtype=torch.bool); m[torch.from_numpy(rng.permutation(n)[:n_inner])] = True
+        return dict(coords=c, input_feats=torch.from_numpy(rng.normal(size=(n, 1)).astype(np.float32)), batch_ids=torch.zeros(n, dtype=torch.int64),
+                    semantic_labels=torch.from_numpy(rng.integers(0, 3, n)), instance_labels=torch.from_numpy(rng.integers(0, 50, n)), masks_inner=m,
+                    offset_labels=torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32)), centers=torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32)),
+                    batch_size=1)
+    tiles = [tile(500, 0), tile(3000, 700), tile(40, 40), tile(900, 0), tile(7000, 6500), tile(100, 1, x0=950.0), tile(2500, 800), tile(60, 1)]
+    want_rows = [(0, 0), (1, 700), (2, 40), (3, 0), (4, 6500), (6, 800), (7, 1)]
+    n_threads = threading.active_count()
+    for src in (tiles, (t for t in tiles), [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in t.items()} for t in tiles]):
+        res, rows = get_pointwise_preds(Fake(), src, dict(voxel_size=0.2), return_tile_rows=True)
+        assert rows == want_rows
+        keep = [t for i, t in enumerate(tiles) if i != 5]
+        np.testing.assert_array_equal(res[4], np.concatenate([(t["coords"] + t["centers"]).numpy()[t["masks_inner"].numpy()] for t in keep]))
+        np.testing.assert_array_equal(res[2], np.concatenate([(t["coords"] * 0.5 + 1).numpy()[t["masks_inner"].numpy()] for t in keep]))
+        for i, k in ((1, "semantic_labels"), (5, "instance_labels"), (3, "offset_labels"), (7, "input_feats")):
+            ref = np.concatenate([t[k].numpy()[t["masks_inner"].numpy()] for t in keep])
+            assert res[i].dtype == ref.dtype and res[i].shape == ref.shape
+            np.testing.assert_array_equal(res[i], ref)
+        assert res[6].shape == (8041, 32) and res[0].shape == (8041, 2)
+    res = get_pointwise_preds(Fake(), [tile(64, 10, x0=950.0), tile(64, 3, x0=990.0)], dict(voxel_size=0.2))       # every tile skipped
+    assert len(res) == 8 and all(len(r) == 0 for r in res)
+    res = get_pointwise_preds(Fake(), [], dict(voxel_size=0.2))
+    assert len(res) == 8 and all(len(r) == 0 for r in res)
+    with pytest.raises(ValueError, match="something else"):
+        get_pointwise_preds(Fake(), [tile(300, 30), tile(300, 30), tile(300, 30, x0=-950.0), tile(300, 30)], dict(voxel_size=0.2))
+    assert threading.active_count() == n_threads
+
+
 def _bf16_round(a):
     return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
 

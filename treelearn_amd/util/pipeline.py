@@ -216,11 +216,12 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
         cols = [rows(output['semantic_prediction_logits']).float(), rows(output['offset_predictions']).float()]
         if bb is not None:
             cols.append(rows(bb).float())
+        width = lambda t: int(np.prod(t.shape[1:], dtype=np.int64))     # noqa: E731  (explicit widths: a tile may have no inner row, and reshape(0, -1) is ambiguous)
         on_dev = {}
         for k in ('offset_labels', 'coords', 'centers', 'input_feats'):
             src = src_of(k)
             if src.is_cuda:
-                on_dev[k] = len(cols); cols.append(rows(src).float().reshape(n_in, -1))
+                on_dev[k] = len(cols); cols.append(rows(src).float().reshape(n_in, width(src)))
         bits = {}                                                      # columns riding along as bit patterns: (first column, carrier type, final type, row shape)
         if to_sink:
             # the worker thread must not touch device memory (its current stream is not this one): whatever lives on the device rides in the block
@@ -229,7 +230,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
                 if src.is_cuda:
                     carrier = src.dtype if src.element_size() in (4, 8) else torch.float64           # (every 1- / 2-byte type is exact in a double)
                     bits[k] = (len(cols), carrier, src.dtype, tuple(src.shape[1:]))
-                    cols.append(rows(src).to(carrier).contiguous().view(torch.float32).reshape(n_in, -1))
+                    cols.append(rows(src).to(carrier).contiguous().view(torch.float32).reshape(n_in, width(src) * (torch.empty((), dtype=carrier).element_size() // 4)))
             if any(not src_of(k).is_cuda for k in ('semantic_labels', 'instance_labels', 'offset_labels', 'coords', 'centers', 'input_feats')):
                 bits['_idx'] = (len(cols), torch.int64, torch.int64, ())                              # the worker selects the host rows
                 cols.append(idx.view(torch.float32).reshape(n_in, 2))
@@ -247,9 +248,10 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             host = packed if (keep_on_device or not packed.is_cuda) else packed.cpu()
 
         def finish():
-            """The tile's 8 results from the landed block (runs on the worker thread when the results go to the sink)."""
+            """The tile's 8 results from the landed block (runs on the worker thread when the results go to the sink).
+            (clone, not contiguous(): a one-row column slice IS contiguous and keeps its odd storage offset, which an 8-byte view refuses)"""
             parts = list(torch.split(host, widths, dim=1))
-            unbits = lambda k: parts[bits[k][0]].contiguous().view(bits[k][1]).reshape((n_in,) + bits[k][3]).to(bits[k][2])   # noqa: E731
+            unbits = lambda k: parts[bits[k][0]].clone(memory_format=torch.contiguous_format).view(bits[k][1]).reshape((n_in,) + bits[k][3]).to(bits[k][2])   # noqa: E731
             if '_idx' in bits:
                 ci[0] = unbits('_idx')
             home = (lambda t: t.to(dev)) if keep_on_device else (lambda t: t.cpu() if t.is_cuda else t)   # noqa: E731
