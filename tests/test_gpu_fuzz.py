@@ -202,3 +202,45 @@ def test_random_cloud_with_voxel_features(use_coords, use_feats):
             continue
         e = rel_err(p.grad.cpu().numpy().astype(np.float64), b)
         assert e < 2e-4, (name, e)
+
+
+def test_forward_input_formats_and_rejections():
+    """What a caller may hand `forward` besides contiguous float32 device tensors (the reference's `cuda_cast` + `voxelize`, util/train.py:28-43,
+    tree_learn.py:129-167, take whatever the DataLoader collated): a strided view, float64 coordinates, int32 batch ids and host tensors give
+    the SAME outputs bit for bit; a batch entry without a single point (batch_size 3, ids 0 and 2) runs -- tl_forward and the Python-driven
+    engine agree, the voxelization equals the oracle's --; no points at all, non-finite coordinates and batch ids outside [0, batch_size)
+    raise ValueError instead of reaching a kernel."""
+    rng = np.random.default_rng(4242)
+    m = _model(torch.bfloat16)
+    cloud = _cloud(rng, "blobs", 3000)
+    batch = _batch([cloud])
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    keys = ("backbone_feats", "semantic_prediction_logits", "offset_predictions")
+    with torch.no_grad():
+        ref = m(gb, return_loss=False)
+        wide = torch.zeros(len(cloud), 5, device="cuda"); wide[:, 1:4] = gb["coords"]
+        for name, over in (("strided coords", dict(coords=wide[:, 1:4])), ("float64 coords", dict(coords=gb["coords"].double())),
+                           ("int32 batch ids", dict(batch_ids=gb["batch_ids"].int())), ("host tensors", dict(coords=batch["coords"], batch_ids=batch["batch_ids"]))):
+            out = m(dict(gb, **over), return_loss=False)
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), (name, k)
+        nan = torch.cat([gb["coords"][:-1], torch.full((1, 3), float("nan"), device="cuda")])
+        for name, over in (("no points", dict(coords=gb["coords"][:0], batch_ids=gb["batch_ids"][:0], input_feats=gb["input_feats"][:0])),
+                           ("nan", dict(coords=nan)), ("inf", dict(coords=nan.nan_to_num(nan=float("inf")))), ("-inf", dict(coords=nan.nan_to_num(nan=float("-inf")))),
+                           ("batch id = batch_size", dict(batch_ids=gb["batch_ids"] + 1)), ("negative batch id", dict(batch_ids=gb["batch_ids"] - 1))):
+            with pytest.raises(ValueError):
+                m(dict(gb, **over), return_loss=False)
+            torch.cuda.synchronize()
+        out = m(gb, return_loss=False)                             # the context is still usable after the rejections
+        for k in keys:
+            assert torch.equal(out[k], ref[k]), k
+    # a batch entry without points
+    from treelearn_amd import geometry as G
+    ids = np.where(np.arange(len(cloud)) % 3 == 0, 0, 2).astype(np.int64)
+    hole = dict(coords=torch.from_numpy(cloud), input_feats=torch.ones(len(cloud), 1), batch_ids=torch.from_numpy(ids), batch_size=3)
+    geom = G.build_geometry(hole["coords"].cuda(), hole["batch_ids"].cuda(), 3, 0.1, 7, [500, 500, 1000])
+    _, vc, v2p, _ = ov.voxelize(cloud, hole["input_feats"].numpy(), ids, 3, 0.1)
+    assert np.array_equal(geom.levels[0].coords.cpu().numpy(), vc) and np.array_equal(geom.v2p.cpu().numpy(), v2p)
+    a, b = _run_both(m, hole)
+    for k in keys:
+        assert torch.equal(a[k], b[k]), k
