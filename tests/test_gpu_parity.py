@@ -1553,3 +1553,37 @@ def test_rulebooks_build_packed_inverse_table_and_optional_parent():
     a.in_ = x32.data_ptr(); a.in_ld = 64; a.weight = w32.data_ptr(); a.table = invp.data_ptr(); a.table_one_hot = 2
     a.n_out = f.n; a.n_in = c.n; a.K = 8; a.Cin = 64; a.Cout = 32; a.dtype = _hip.TL_F32; a.out = out32.data_ptr(); a.out_ld = 32
     assert L.tl_conv_fwd(ctypes.byref(a), st) == _hip.TL_ERR_UNSUPPORTED
+
+
+def test_postprocessing_edge_cases():
+    """The callers behind the tile loop at the sizes a sparse plot produces: grouping with 0 / 1 / 2 / 3 candidate points (DBSCAN with
+    min_samples 2 = components of the eps-graph, util/pipeline.py:173-180), `get_instances` when no point passes the masks, the k-NN fill
+    with nothing to fill and with fewer assigned points than neighbours (sklearn's ValueError, as in the reference, util/pipeline.py:287-296),
+    label propagation onto an empty target."""
+    from treelearn_amd.util.pipeline import get_instances, get_instances_device, group_dbscan
+    from treelearn_amd.util.postprocess import assign_remaining_points_nearest_neighbor, propagate_preds
+    pts = np.array([[0.0, 0.0], [0.1, 0.0], [5.0, 5.0]], np.float32)
+    assert group_dbscan(pts[:0], 0.5, 1, 0, 1).tolist() == []
+    assert group_dbscan(pts[:1], 0.5, 1, 0, 1).tolist() == [0]                      # a lone point is noise -> not assigned
+    assert group_dbscan(pts[:2], 0.5, 2, 0, 1).tolist() == [1, 1]
+    assert group_dbscan(pts[:2], 0.5, 3, 0, 1).tolist() == [0, 0]                   # a pair below tau_min
+    assert group_dbscan(pts, 0.5, 1, 0, 1).tolist() == [1, 1, 0]
+    rng = np.random.default_rng(8)
+    g = dict(tree_conf_thresh=0.5, tau_vert=0.6, tau_off=2.0, tau_min=3, tau_group=0.15, use_hdbscan=False)
+    for n in (0, 1, 40):
+        c = rng.uniform(0, 10, (n, 3)).astype(np.float32); off = rng.normal(size=(n, 3)).astype(np.float32)
+        logits = rng.normal(size=(n, 2)).astype(np.float32) - np.array([50, 0], np.float32); vert = rng.uniform(0, 1, n).astype(np.float32)
+        host = get_instances(c, off, logits, g, vert, 0, -1, 0, 1)                  # class 0 = tree never reaches the confidence threshold
+        assert host.dtype == np.int64 and host.tolist() == [-1] * n
+        T = lambda a: torch.from_numpy(a).cuda()                                      # noqa: E731
+        assert get_instances_device(T(c), T(off), T(logits), g, T(vert), 0, -1, 0, 1).cpu().tolist() == [-1] * n
+    q = rng.uniform(0, 10, (6, 3)).astype(np.float32)
+    pred = np.array([1, 1, 2, 3, 3, 3])
+    np.testing.assert_array_equal(assign_remaining_points_nearest_neighbor(q, pred, -1), pred)          # nothing to fill
+    with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+        assign_remaining_points_nearest_neighbor(q, np.array([1, 1, 2, -1, -1, -1]), -1)                # 3 assigned points, 5 neighbours
+    assert assign_remaining_points_nearest_neighbor(q, np.array([1, 1, 2, -1, -1, -1]), -1, n_neighbors=3).tolist()[:3] == [1, 1, 2]
+    out = propagate_preds(q, pred, q[:0], 5)
+    assert out.shape == (0,) and out.dtype == np.int64
+    with pytest.raises(ValueError):
+        propagate_preds(q[:2], pred[:2], q, 5)

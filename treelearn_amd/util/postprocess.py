@@ -61,7 +61,11 @@ def knn_vote(ref, lab, qry, k, force=None):
     `force` = "grid" / "brute" pins the path (tests)."""
     L = _hip.lib()
     nr, nq = ref.shape[0], qry.shape[0]
+    if k < 1 or k > nr:                                                # sklearn's rule (and message) for the classifier / NearestNeighbors the reference uses
+        raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, n_samples_fit = {nr}" if k >= 1 else f"Expected n_neighbors > 0. Got {k}")
     out = torch.empty(nq, dtype=torch.int64, device=ref.device)
+    if nq == 0:
+        return out
     use_grid = force == "grid" or (force is None and nr >= GRID_KNN_MIN_REF)
     if not use_grid:
         _hip.check(L.tl_knn_vote(_hip.ptr(ref), _hip.ptr(lab), nr, _hip.ptr(qry), nq, int(k), _hip.ptr(out), _hip.stream()), "tl_knn_vote")
