@@ -28,6 +28,47 @@ def test_library_exports_every_declared_symbol():
     assert _hip.lib().tl_error_string(-1) == b"invalid argument"
 
 
+def test_every_entry_point_rejects_null_arguments():
+    """The C ABI at its bluntest: every function include/treelearn_hip.h declares, called with null pointers, zero sizes and zeroed arrays.
+    Compute entries must come back with a negative code before touching a pointer or launching anything (no GPU is needed to find that
+    out); workspace-size queries may answer with a size.  Runs in a child process so that a fault names the function instead of ending pytest."""
+    import subprocess
+    import sys
+    child = r"""
+import ctypes, re, sys
+sys.path.insert(0, %r)
+from treelearn_amd import _hip
+L = _hip.lib()
+names = sorted(set(re.findall(r"\b(tl_[a-z0-9_]+)\s*\(", open(%r).read())))
+for n in names:
+    f = getattr(L, n)
+    args = []
+    for t in f.argtypes:
+        if issubclass(t, ctypes.Array): args.append(t())
+        elif t in (ctypes.c_float, ctypes.c_double): args.append(0.0)
+        elif issubclass(t, ctypes._SimpleCData) and t not in (ctypes.c_void_p, ctypes.c_char_p): args.append(0)
+        else: args.append(None)
+    print("CALL", n, flush=True)
+    r = f(*args)
+    print("RET", n, r if isinstance(r, int) else ("null" if r is None else "obj"), flush=True)
+print("DONE", len(names))
+""" % (REPO, os.path.join(REPO, "include", "treelearn_hip.h"))
+    p = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600)
+    lines = p.stdout.strip().splitlines()
+    assert p.returncode == 0 and lines and lines[-1].startswith("DONE"), (p.returncode, lines[-2:], p.stderr[-500:])
+    sizes = re.compile(r"_(ws_(bytes|words|doubles|floats)(_k)?|red_parts|bytes|slots|parts)$")
+    seen = 0
+    for ln in lines:
+        if not ln.startswith("RET"):
+            continue
+        _, n, r = ln.split()
+        seen += 1
+        if n in ("tl_version", "tl_error_string", "tl_exec_create", "tl_exec_destroy") or sizes.search(n):
+            continue                                                   # (tl_exec_create answers NULL without a GPU; a destroy of NULL is a no-op)
+        assert r not in ("null", "obj") and int(r) < 0, f"{n}(nulls) returned {r}"
+    assert seen >= 60
+
+
 def test_product_path_fails_loudly_without_gpu():
     from treelearn_amd.model import TreeLearn
     from treelearn_amd.synth import make_batch, make_tile
