@@ -327,6 +327,16 @@ int tl_conv_wgrad(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, i
 int tl_conv_wgrad_ref(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out,
                       int64_t n_in, int K, int Cin, int Cout, float* gw, float* ws, tl_stream_t stream);
 
+/* The weight gradient of a 27-tap 32 -> 32 SubM conv over a BLOCK-LOCAL level (tl_blk_build: x and gout rows in the new order) in the
+ * staged-unit form of the forward kernel: a unit's own and halo rows of x, its gout rows and its local rulebook are staged in LDS once and all
+ * 27 taps contract against them, instead of 27 gathers per output row through the plain table (level 1 of the training step,
+ * tools/training/train.py:40).  16-bit dtypes, Cin = Cout = 32; anything else returns TL_ERR_UNSUPPORTED and the caller uses tl_conv_wgrad over
+ * tl_blk.nn.  gw f32[27][32][32], or f32[32][27][32] with ref_layout != 0; ws f32[tl_conv_wgrad_blk_ws_floats()].  Deterministic. */
+int64_t tl_conv_wgrad_blk_ws_floats(void);
+int tl_conv_wgrad_blk(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* blk_unit, const int32_t* blk_counter,
+                      const int32_t* blk_halo, const uint32_t* blk_lrb, int64_t n, int Cin, int Cout, float* gw, int ref_layout, float* ws,
+                      tl_stream_t stream);
+
 /* ------------------------------------------------------------------ per-point heads
  * Replaces forward_head (tree_learn.py:97-103): features[v2p] gather, output_layer BN+ReLU
  * (tree_learn.py:42,93) as prologue, then both MLPs (blocks.py:8-18) with eval-mode BN folded:

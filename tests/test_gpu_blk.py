@@ -491,3 +491,42 @@ def test_training_step_staged_batchnorm_equals_the_apply_pass(monkeypatch):
         a, c = g0[k], g1[k]
         if float(a.norm()) > 1e-3 * nmax:                   # (a Linear bias in front of a BatchNorm has a zero gradient: pure rounding noise)
             assert float((a * c).sum() / (a.norm() * c.norm())) >= 0.995, k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["tile", "deep split", "batch of two", "64 -> 32"])
+def test_blk_weight_gradient_equals_the_plain_table_kernel(dtype, case, monkeypatch):
+    """tl_conv_wgrad_blk (level 1 of the training step: units staged once, 27 taps contracted against the staged rows) against tl_conv_wgrad over
+    the SAME rulebook as a plain table (tl_blk.nn) and against float64: same 16-bit operands, fp32 accumulation in a different order -> 2e-6 of
+    the largest entry.  Units of every size (halo bound 26), a batch of two tiles, the 64 -> 32 decoder conv as its two input halves, both
+    output layouts."""
+    import treelearn_amd.geometry as G
+    from treelearn_amd import ops
+    batch = _batch(14.0, [3, 5] if case == "batch of two" else [3])
+    old = G.BLK_HALO_MAX
+    if case == "deep split":
+        G.BLK_HALO_MAX = 26
+    try:
+        _, blk = _geoms(batch, blk_min_rows=1, nn_table=True)
+    finally:
+        G.BLK_HALO_MAX = old
+    r = blk.levels[0].nbr
+    n, ci = r.n, (64 if case == "64 -> 32" else 32)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.randn(n, ci, generator=gen) * 0.7).to(dtype).cuda()
+    g = (torch.randn(n, 32, generator=gen) * 0.3).to(dtype).cuda()
+    for ref_layout in (False, True):
+        monkeypatch.setattr(ops, "WGRAD_BLK", True)
+        a = ops._conv_wgrad_blk(x, g, r, ref_layout) if ci == 64 else ops.conv_wgrad(x, g, r, n, 27, ref_layout=ref_layout)     # (64 -> 32 is not routed there by default)
+        monkeypatch.setattr(ops, "WGRAD_BLK", False)
+        b = ops.conv_wgrad(x, g, r, n, 27, ref_layout=ref_layout)
+        assert a.shape == b.shape and a._tl_ref_layout == b._tl_ref_layout == ref_layout
+        scale = float(b.abs().max())
+        assert scale > 1.0 and float((a - b).abs().max()) < 2e-6 * scale * 27, (case, ref_layout, float((a - b).abs().max()), scale)
+    # float64 on the host for a few taps (a is in the reference layout [Cout][K][Cin] here)
+    tab = r.nn_table.long().cpu()
+    xd, gd = x.double().cpu(), g.double().cpu()
+    for k in (0, 13, 26):
+        t = tab[k]; ok = t >= 0
+        ref = gd[ok].T @ xd[t[ok]]
+        assert float((a[:, k, :].double().cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-4, k

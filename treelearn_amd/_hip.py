@@ -143,6 +143,8 @@ PROTOTYPES = {
     "tl_conv_wgrad_ws_floats": (_i64, [_i64, _i32, _i32, _i32]),
     "tl_conv_wgrad": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "tl_conv_wgrad_ref": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "tl_conv_wgrad_blk_ws_floats": (_i64, []),
+    "tl_conv_wgrad_blk": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
     "tl_head_mlp": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tl_affine_relu": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "tl_bn_ws_doubles": (_i64, [_i64, _i32]),

@@ -10,6 +10,8 @@
 #define tl_conv_wgrad_ws_floats tl_conv_wgrad_ws_floats_f16
 #define tl_conv_wgrad tl_conv_wgrad_f16
 #define tl_conv_wgrad_ref tl_conv_wgrad_ref_f16
+#define tl_conv_wgrad_blk tl_conv_wgrad_blk_f16
+#define tl_conv_wgrad_blk_ws_floats tl_conv_wgrad_blk_ws_floats_f16
 #define tl_dev_wgrad_mode tl_dev_wgrad_mode_f16
 #define g_wgrad_dma g_wgrad_dma_f16
 #define g_wgrad_dense g_wgrad_dense_f16
@@ -40,6 +42,8 @@ int tl_conv_wgrad_f16(const void* x, int64_t x_ld, const void* gout, int64_t g_l
                       int Cout, float* gw, float* ws, tl_stream_t stream);
 int tl_conv_wgrad_ref_f16(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* table, int64_t n_out, int64_t n_in, int K, int Cin,
                           int Cout, float* gw, float* ws, tl_stream_t stream);
+int tl_conv_wgrad_blk_f16(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* blk_unit, const int32_t* blk_counter,
+                          const int32_t* blk_halo, const uint32_t* blk_lrb, int64_t n, int Cin, int Cout, float* gw, int ref_layout, float* ws, tl_stream_t stream);
 int tl_linear_small_f32_f16(const void* x, int64_t x_ld, int dtype, const void* w, int Cin, int Cout, int64_t n, float* out, int64_t out_ld, tl_stream_t stream);
 int tl_gather_rows_f16(const void* in, int64_t in_ld, int dtype, int C, int64_t n_rows, const int64_t* idx, int64_t N, void* out, int64_t out_ld, tl_stream_t stream);
 int tl_scatter_add_rows_f16(const void* g, int64_t g_ld, int dtype, int C, const int64_t* order, const int64_t* sorted_idx, int64_t N, int64_t n_rows, void* gin,

@@ -525,6 +525,163 @@ int launch_dma(const uint16_t* x, int64_t x_ld, const uint16_t* g, int64_t g_ld,
   return hipGetLastError() == hipSuccess ? TL_OK : TL_ERR_LAUNCH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Level 1, block-local rows (tl_blk): the weight gradient of a 27-tap 32 -> 32 SubM conv in the staged-unit form of the forward kernel
+// (tl_conv_blk.hip).  The dense-over-taps kernel above gathers the input rows of every tap from memory -- 27 gathers per output row where 5.5
+// neighbours exist; here a workgroup walks UNITS (<= 64 own rows + their <= 126 halo rows, 1.8 staged rows per own row): the unit's x rows, its
+// gout rows and its local rulebook go to LDS once, and all 27 taps contract against them:
+//     gW[k][co][ci] += sum over the unit's rows r of gout[r][co] * X[pos(r, k)][ci]          pos = the 10-bit local rulebook entry >> 2, 191 = absent
+// Wave w owns taps 3w, 3w + 1, 3w + 2 -- exactly the three entries of word w of a row's nine rulebook words -- and keeps their three 32 x 32 fp32
+// tiles in registers for the whole kernel.  Per 16-row step: two transposing reads give the gout fragments (shared by the three taps), two reads the
+// rulebook words of the lane's two rows, and per tap two transposing reads AT THE NEIGHBOURS' staged positions (every lane supplies its row's
+// address) give the x fragments -- absent neighbours point at a zero row.  Staging goes through two register sets and two LDS buffers: while unit u
+// is contracted, the rows of unit u + 1 are landing and those of unit u + 2 (and the halo indices of unit u + 3) are requested; one barrier per unit.  Persistent workgroups, unit i -> workgroup
+// i mod G; every workgroup writes ONE partial set, k_wgrad_reduce_par adds them in workgroup order: deterministic.
+constexpr int kWB_NW = 9, kWB_NT = kWB_NW * 64;
+constexpr int kWB_XB = 192 * 64, kWB_GB = 64 * 64, kWB_LB = 64 * 9 * 4, kWB_BUF = kWB_XB + kWB_GB + kWB_LB;       // bytes per buffer: 12288 + 4096 + 2304
+constexpr int kWB_PARTS = 512;
+
+__global__ void __launch_bounds__(kWB_NT) k_wgrad_blk(const uint16_t* __restrict__ x, int64_t x_ld, const uint16_t* __restrict__ g, int64_t g_ld,
+                                                      const int32_t* __restrict__ unit, const int32_t* __restrict__ counter, const int32_t* __restrict__ halo,
+                                                      const uint32_t* __restrict__ lrb, int64_t n, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][X 192 rows x 64 B | G 64 rows x 64 B | L 64 rows x 9 words]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nu = counter[0];
+  const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(x), 0, (int)min((int64_t)0x7FFFFFFF, n * x_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g), 0, (int)min((int64_t)0x7FFFFFFF, n * g_ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(lrb), 0, (int)min((int64_t)0x7FFFFFFF, n * 36), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(halo), 0, (int)min((int64_t)0x7FFFFFFF, n * 128), 0x00020000);
+  // staged rows 190 and 191 of both buffers stay zero (191 = the row of absent neighbours); the pieces below cover positions 0..189
+  for (int e = tid; e < 2 * 32; e += kWB_NT) {
+    const int b = e >> 5, w = e & 31;
+    reinterpret_cast<uint32_t*>(smem + b * kWB_BUF + 190 * 64)[w] = 0;
+  }
+  // this thread's pieces of a unit: X pieces p = tid and tid + 576 (position p / 4, 16-B piece p % 4; p < 760), one G piece (tid < 256), one word
+  const int xp0 = tid, xp1 = tid + kWB_NT;
+  const int pos0 = xp0 >> 2, pos1 = xp1 >> 2;                       // pos0 in 0..143, pos1 in 144..189 (tid < 184)
+  const bool has1 = xp1 < 760;
+  auto unit_of = [&](int it) { const int u = wg + it * G; return u < nu ? u : -1; };
+
+  auto desc = [&](int it) { const int u = unit_of(it); return u >= 0 ? reinterpret_cast<const int4*>(unit)[u] : make_int4(0, 0, 0, 0); };
+  auto halo_load = [&](const int4& d, int& h0, int& h1) __attribute__((always_inline)) {
+    const int j0 = pos0 - 64, j1 = pos1 - 64;
+    h0 = __builtin_amdgcn_raw_buffer_load_b32(rh, (pos0 >= 64 && j0 < d.z) ? (int)(((int64_t)d.x * 32 + j0) * 4) : -1, 0, 0);
+    h1 = __builtin_amdgcn_raw_buffer_load_b32(rh, (has1 && j1 < d.z) ? (int)(((int64_t)d.x * 32 + j1) * 4) : -1, 0, 0);
+    if (!(pos0 >= 64 && j0 < d.z)) h0 = -1;
+    if (!(has1 && j1 < d.z)) h1 = -1;
+  };
+  // two register sets: while unit u is contracted, the rows of unit u + 1 are landing in one set and those of unit u + 2 are requested into the other
+  // (a unit's loads then have two contractions and a barrier to arrive: one was not enough, the loop ran at one memory latency per unit)
+  u32x4 xq0[2], xq1[2], gq[2]; uint32_t lw[2];
+  auto rows_load = [&](const int4& d, int h0, int h1, int S) __attribute__((always_inline)) {
+    // own rows: position < count -> row lo + position; halo rows through the list; everything else reads zeros (offset -1 = out of range)
+    const int r0 = pos0 < 64 ? (pos0 < d.y ? d.x + pos0 : -1) : h0;
+    const int r1 = has1 ? h1 : -1;
+    xq0[S] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, r0 >= 0 ? (int)((unsigned)((int64_t)r0 * x_ld * 2) + (unsigned)((xp0 & 3) * 16)) : -1, 0, 0));
+    xq1[S] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, r1 >= 0 ? (int)((unsigned)((int64_t)r1 * x_ld * 2) + (unsigned)((xp1 & 3) * 16)) : -1, 0, 0));
+    const int gr = tid >> 2;
+    gq[S] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (tid < 256 && gr < d.y) ? (int)((unsigned)((int64_t)(d.x + gr) * g_ld * 2) + (unsigned)((tid & 3) * 16)) : -1, 0, 0));
+    const int lr = tid / 9;                                        // 576 words = 64 rows x 9
+    lw[S] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rl, lr < d.y ? (int)(((int64_t)d.x * 9 + tid) * 4) : -1, 0, 0);
+    if (!(lr < d.y)) lw[S] = 0x2FFBFEFFu;                          // three entries "absent" (191 * 4 + 3 = 767 each): rows past the unit's end contribute nothing
+  };
+  auto rows_store = [&](char* buf, int S) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(buf + xp0 * 16) = xq0[S];
+    if (has1) *reinterpret_cast<u32x4*>(buf + xp1 * 16) = xq1[S];
+    if (tid < 256) *reinterpret_cast<u32x4*>(buf + kWB_XB + tid * 16) = gq[S];
+    *reinterpret_cast<uint32_t*>(buf + kWB_XB + kWB_GB + tid * 4) = lw[S];
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int fh = lane >> 5, ti = lane & 15, tg = (lane >> 4) & 1;
+  const int prow = 8 * fh + (ti >> 2), pcolb = 32 * tg + 8 * (ti & 3);      // row of the 16-row step / byte column this lane addresses in a transposing read
+
+  // All four 16-row steps of a unit, unrolled: the rulebook words and the gout fragments of every step are requested up front, the x fragments
+  // follow as their positions arrive -- the reads are independent, so the matrix instructions of one step run while the next steps' operands are on
+  // their way (with a loop over the steps every step paid two dependent LDS round trips: waves parked 51 % of their cycles).  Rows past the unit's
+  // end are zeros in the gout tile and "absent" in the rulebook words: a short unit costs four steps like a full one (1.5 % of the units).
+  auto contract = [&](const char* cur) __attribute__((always_inline)) {
+    const char* Xc = cur; const char* Gc = cur + kWB_XB; const uint32_t* Lc = reinterpret_cast<const uint32_t*>(cur + kWB_XB + kWB_GB);
+    uint32_t w2[4][2];
+    u32x4 A[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) w2[st][q] = Lc[(16 * st + prow + 4 * q) * 9 + wv];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Gc + (16 * st + prow + 4 * q) * 64 + pcolb)));
+        A[st][2 * q] = v[0]; A[st][2 * q + 1] = v[1];
+      }
+    // (skipping the (step, tap) pairs without a present neighbour among their 16 rows -- one ballot each -- was measured slower: 0.406 against 0.375 ms;
+    // in the block order few such pairs exist, as the forward's tile statistics say)
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        u32x4 B;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int pos = (int)((w2[st][q] >> (10 * t)) & 1023u) >> 2;
+          const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(Xc + pos * 64 + pcolb)));
+          B[2 * q] = v[0]; B[2 * q + 1] = v[1];
+        }
+        acc[t] = h16_mfma(A[st], B, acc[t]);
+      }
+  };
+
+  // prologue: unit 0 into buffer 0; the rows of unit 1 requested into set 1, the halo indices of unit 2 into slot 0
+  int4 ud[4];                                                      // descriptors of units u .. u + 3 (rotated by hand below); u + 4 is requested a phase before its use
+  int hh0[2], hh1[2];                                              // halo rows of this thread's two X pieces, per set
+  ud[0] = desc(0);
+  halo_load(ud[0], hh0[0], hh1[0]);
+  rows_load(ud[0], hh0[0], hh1[0], 0);
+  rows_store(smem, 0);
+  ud[1] = desc(1);
+  halo_load(ud[1], hh0[1], hh1[1]);
+  rows_load(ud[1], hh0[1], hh1[1], 1);
+  ud[2] = desc(2);
+  halo_load(ud[2], hh0[0], hh1[0]);
+  ud[3] = desc(3);
+  __syncthreads();
+  // phase for unit u (buffer u & 1 ready): set (u + 1) & 1 holds unit u + 1 (landing), set u & 1 is free and takes unit u + 2.  Every address a phase
+  // needs was loaded a phase earlier (descriptor -> halo indices -> rows are three dependent loads: each gets a phase of its own)
+  auto phase = [&](int u, int S) __attribute__((always_inline)) {            // S = u & 1, a constant after unrolling
+    const int4 d4 = desc(u + 4);
+    // (the index loads FIRST: memory operations retire in order, and the next phase starts by waiting for these indices -- behind the row loads
+    // that wait would drain the rows too and leave them one phase instead of two)
+    int n0, n1;
+    halo_load(ud[3], n0, n1);
+    rows_load(ud[2], hh0[S], hh1[S], S);                          // unit u + 2 (zeros when there is none)
+    hh0[S ^ 1] = n0; hh1[S ^ 1] = n1;                             // (slot S ^ 1 held unit u + 1's indices: its rows were requested a phase ago)
+    contract(smem + S * kWB_BUF);
+    rows_store(smem + (S ^ 1) * kWB_BUF, S ^ 1);                  // unit u + 1 has landed by now
+    ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = ud[3]; ud[3] = d4;
+    __syncthreads();
+  };
+  for (int u = 0; unit_of(u) >= 0; u += 2) {
+    phase(u, 0);
+    if (unit_of(u + 1) < 0) break;
+    phase(u + 1, 1);
+  }
+  // partial tiles of this workgroup: ws[wg][k][co][ci]
+  const int fi = lane & 31;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* wp = ws + ((int64_t)wg * 27 + (3 * wv + t)) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wp[((r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fi] = acc[t][r];
+  }
+}
+
 }  // namespace
 
 int g_wgrad_dma = 1;              // tl_set_tuning("wgrad_dma", 0): the register-staged form everywhere
@@ -601,3 +758,29 @@ int tl_launch_wgrad_dense(const uint16_t* x, int64_t x_ld, const uint16_t* g, in
   const int64_t per = (int64_t)K * Cout * Cin;
   return tl_launch_wgrad_reduce(ws, gx, per, gw, s, K, Cout, Cin, ref_layout);
 }
+
+extern "C" {
+
+// Weight gradient of a 27-tap 32 -> 32 SubM conv over a block-local level: see k_wgrad_blk.  16-bit dtypes only (TL_ERR_UNSUPPORTED otherwise:
+// the caller takes tl_conv_wgrad over the level's plain table); ws >= tl_conv_wgrad_blk_ws_floats() floats; gw [27][32][32] or, with
+// ref_layout, [32][27][32] (the parameter's own layout).
+int64_t tl_conv_wgrad_blk_ws_floats(void) { return (int64_t)kWB_PARTS * 27 * 1024; }
+
+int tl_conv_wgrad_blk(const void* x, int64_t x_ld, const void* gout, int64_t g_ld, int dtype, const int32_t* blk_unit, const int32_t* blk_counter,
+                      const int32_t* blk_halo, const uint32_t* blk_lrb, int64_t n, int Cin, int Cout, float* gw, int ref_layout, float* ws, tl_stream_t stream) {
+  if (!x || !gout || !blk_unit || !blk_counter || !blk_halo || !blk_lrb || !gw || !ws || n <= 0 || x_ld < Cin || g_ld < Cout) return TL_ERR_ARG;
+#ifndef TL_F16_BUILD
+  if (dtype == TL_F16) return tl_conv_wgrad_blk_f16(x, x_ld, gout, g_ld, TL_BF16, blk_unit, blk_counter, blk_halo, blk_lrb, n, Cin, Cout, gw, ref_layout, ws, stream);
+#endif
+  if (dtype != TL_BF16 || Cin != 32 || Cout != 32 || x_ld % 8 || g_ld % 8 || ((uintptr_t)x) % 16 || ((uintptr_t)gout) % 16 || ((uintptr_t)blk_unit) % 16) return TL_ERR_UNSUPPORTED;
+  if (n * x_ld * 2 > 0x7FFFFFFFll || n * g_ld * 2 > 0x7FFFFFFFll || n * 128 > 0x7FFFFFFFll) return TL_ERR_UNSUPPORTED;     // 32-bit buffer offsets
+  hipStream_t s = tl_s(stream);
+  static TlAttrOnce attr_once;
+  if (!tl_lds_attr(attr_once, reinterpret_cast<const void*>(&k_wgrad_blk), 160 * 1024)) return TL_ERR_LAUNCH;
+  k_wgrad_blk<<<kWB_PARTS, kWB_NT, 2 * kWB_BUF, s>>>(static_cast<const uint16_t*>(x), x_ld, static_cast<const uint16_t*>(gout), g_ld, blk_unit, blk_counter, blk_halo,
+                                                      blk_lrb, n, ws);
+  if (hipGetLastError() != hipSuccess) return TL_ERR_LAUNCH;
+  return tl_launch_wgrad_reduce(ws, kWB_PARTS, 27 * 1024, gw, s, 27, 32, 32, ref_layout);
+}
+
+}  // extern "C"
