@@ -162,6 +162,13 @@ struct BlkOut {
   int64_t n; int64_t nchunks; int64_t cap_units; int halo_max;
 };
 
+#ifdef TL_DEV
+__device__ int g_blk_abl = 0;              // developer build: k_blk_units stops after stage g_blk_abl (tools/dev_blk_units.py); results are wrong on purpose
+#define BLK_ABL(stage) if (g_blk_abl == (stage)) return
+#else
+#define BLK_ABL(stage)
+#endif
+
 // units, halo lists, local rulebooks: one wave per chunk of 64 new rows
 __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict__ bm, TlDims d, BlkOut p) {
   __shared__ uint32_t s_tab[kBlock / 64][HASH + 64];        // + the dummy slot idle lanes use
@@ -258,6 +265,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
     }
   }
 
+  BLK_ABL(1);                                                               // the neighbour ids and presence masks only
   // the hash table is sized to the chunk (load factor <= 0.7 even if every present neighbour were a distinct outside row)
   int nref = __popc(pm);
   for (int off = 32; off > 0; off >>= 1) nref += __shfl_xor(nref, off);
@@ -315,6 +323,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
         }
       }
     }
+    BLK_ABL(2);                                                             // + table clear, insert, verify, probing
     // the distinct outside rows, compacted in slot order: list[i] = key, lslot[i] = its slot
     int H = 0;
     for (int i0 = 0; i0 < TS; i0 += 512) {
@@ -331,6 +340,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
         H += __popcll(m);
       }
     }
+    BLK_ABL(3);                                                             // + compaction of the table
     if (H > p.halo_max && e - a > 1) {
       const int mid = a + (e - a) / 2;
       st_a[sp] = mid; st_e[sp] = e; ++sp;
@@ -381,6 +391,7 @@ __global__ void __launch_bounds__(kBlock) k_blk_units(const uint64_t* __restrict
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    BLK_ABL(4);                                                             // + rank sort and halo list
     // local rulebook rows: own rows directly, outside rows through the table (home slot first; the few displaced keys probe on)
     {
       uint32_t wds[9];
@@ -463,6 +474,10 @@ __global__ void k_blk_init(int32_t* counter, int32_t nchunks) {
 }
 
 }  // namespace
+
+#ifdef TL_DEV
+extern "C" int tl_dev_blk_abl(int stage) { return hipMemcpyToSymbol(HIP_SYMBOL(g_blk_abl), &stage, sizeof(int)) == hipSuccess ? TL_OK : TL_ERR_LAUNCH; }
+#endif
 
 extern "C" {
 
