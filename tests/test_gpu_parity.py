@@ -269,6 +269,13 @@ def test_tile_loop_edge_cases_of_the_result_path():
             assert res[i].dtype == ref.dtype and res[i].shape == ref.shape
             np.testing.assert_array_equal(res[i], ref)
         assert res[6].shape == (8041, 32) and res[0].shape == (8041, 2)
+    class OnHost(Fake):                                                 # a model that hands its results back on the host (on a GPU machine)
+        def forward(self, batch, return_loss):
+            return {k: v.cpu() for k, v in super().forward(batch, return_loss).items()}
+    res2, rows2 = get_pointwise_preds(OnHost(), tiles, dict(voxel_size=0.2), return_tile_rows=True)
+    assert rows2 == want_rows
+    for a, b_ in zip(res2, res):
+        np.testing.assert_array_equal(a, b_)
     res = get_pointwise_preds(Fake(), [tile(64, 10, x0=950.0), tile(64, 3, x0=990.0)], dict(voxel_size=0.2))       # every tile skipped
     assert len(res) == 8 and all(len(r) == 0 for r in res)
     res = get_pointwise_preds(Fake(), [], dict(voxel_size=0.2))

@@ -197,8 +197,8 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
             gbatch['masks_inner'].record_stream(torch.cuda.current_stream())
         idx = torch.nonzero(gbatch['masks_inner'].to(dev)).squeeze(1)          # one small sync; 4-5 % of the rows survive
         n_in = idx.shape[0]
-        src_of = lambda k: gbatch[k] if (torch.is_tensor(gbatch.get(k)) and gbatch[k].is_cuda) else batch[k]      # noqa: E731
-        to_sink = sink is not None and idx.is_cuda
+        src_of = lambda k: gbatch[k] if (torch.is_tensor(gbatch.get(k)) and gbatch[k].is_cuda and gbatch[k].device == dev) else batch[k]      # noqa: E731
+        to_sink = sink is not None                                     # (a tile whose results already live on the host goes through the sink as well: one order)
         ci = [None]                                                    # the row list on the host: fetched at most once, by whoever selects host rows
 
         def rows(t):
@@ -239,7 +239,7 @@ def get_pointwise_preds(model, dataloader, config, logger=None, return_backbone_
         if keep_on_device and packed.is_cuda:
             packed.record_stream(main_stream)                          # produced on the read-back stream, consumed on the main one
         ev = None
-        if to_sink:
+        if to_sink and packed.is_cuda:
             # asynchronous copy into a pinned landing buffer; everything that READS it runs on the sink's worker thread, after the event
             host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
             host.copy_(packed, non_blocking=True)
