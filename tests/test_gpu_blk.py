@@ -530,3 +530,33 @@ def test_blk_weight_gradient_equals_the_plain_table_kernel(dtype, case, monkeypa
         t = tab[k]; ok = t >= 0
         ref = gd[ok].T @ xd[t[ok]]
         assert float((a[:, k, :].double().cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-4, k
+
+
+def test_blk_weight_gradient_entry_point_refuses_what_it_does_not_cover():
+    """tl_conv_wgrad_blk answers TL_ERR_UNSUPPORTED (not a wrong gradient) for fp32 rows, other widths and unaligned rows -- ops.conv_wgrad then
+    takes tl_conv_wgrad over the plain table, and says so when the geometry was built without it."""
+    from treelearn_amd import _hip, ops
+    _, blk = _geoms(_batch(10.0, [2]), blk_min_rows=1, nn_table=True)
+    r = blk.levels[0].nbr
+    n = r.n
+    L = _hip.lib()
+    ws = torch.empty(int(L.tl_conv_wgrad_blk_ws_floats()), dtype=torch.float32, device="cuda")
+    gw = torch.empty(27 * 32 * 32, dtype=torch.float32, device="cuda")
+
+    def call(x, g, dt, ci=32, co=32):
+        return L.tl_conv_wgrad_blk(_hip.ptr(x), x.stride(0), _hip.ptr(g), g.stride(0), dt, _hip.ptr(r.unit), _hip.ptr(r.counter), _hip.ptr(r.halo), _hip.ptr(r.lrb), n, ci, co,
+                                   _hip.ptr(gw), 0, _hip.ptr(ws), _hip.stream())
+    xb = torch.randn(n, 40, device="cuda").bfloat16(); gb = torch.randn(n, 32, device="cuda").bfloat16()
+    assert call(xb[:, :32], gb, _hip.dtype_code(torch.bfloat16)) == _hip.TL_OK
+    assert call(xb.float()[:, :32].contiguous(), gb.float(), _hip.dtype_code(torch.float32)) == _hip.TL_ERR_UNSUPPORTED
+    assert call(xb[:, :32], gb, _hip.dtype_code(torch.bfloat16), ci=16) == _hip.TL_ERR_UNSUPPORTED
+    assert call(xb[:, 4:36], gb, _hip.dtype_code(torch.bfloat16)) == _hip.TL_ERR_UNSUPPORTED               # rows not 16-B aligned
+    assert call(torch.randn(n, 36, device="cuda").bfloat16()[:, :32], gb, _hip.dtype_code(torch.bfloat16)) == _hip.TL_ERR_UNSUPPORTED   # row pitch not a multiple of 8
+    torch.cuda.synchronize()
+    # fp32 rows through ops: the plain table serves them
+    a = ops.conv_wgrad(xb[:, :32].float().contiguous(), gb.float(), r, n, 27)
+    b = ops.conv_wgrad(xb[:, :32].contiguous(), gb, r, n, 27)
+    assert float((a - b).abs().max()) < 1e-3 * float(a.abs().max())
+    _, bare = _geoms(_batch(10.0, [2]), blk_min_rows=1)
+    with pytest.raises(ValueError, match="nn_table"):
+        ops.conv_wgrad(xb[:, :32].float().contiguous(), gb.float(), bare.levels[0].nbr, n, 27)
